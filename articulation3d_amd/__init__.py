@@ -1,0 +1,7 @@
+"""articulation3d_amd: MI355X-native (gfx950) implementation of Articulation3D's per-frame PlaneRCNN
+detection path, behind the reference's registry / config / Instances API.
+
+Compute runs in hand-written HIP kernels (articulation3d_amd/csrc, C ABI in include/a3d.h) loaded with
+ctypes; there is no CPU or eager-PyTorch fallback.
+"""
+__version__ = "0.1.0"

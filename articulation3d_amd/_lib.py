@@ -1,0 +1,144 @@
+"""ctypes binding of liba3d_hip.so (include/a3d.h).
+
+This is the only place the product touches the kernel library.  There is NO fallback: if the library
+is missing or a call returns a non-zero code, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liba3d_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+_ERR = {-1: "A3D_ERR_ARG", -2: "A3D_ERR_LAUNCH", -3: "A3D_ERR_UNSUPPORTED"}
+
+fptr = C.c_void_p  # device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", fptr), ("x2", fptr), ("w", fptr), ("scale", fptr), ("shift", fptr), ("res", fptr), ("y", fptr),
+        ("workspace", fptr),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cin2", C.c_int),
+        ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("Kpad", C.c_int), ("ups", C.c_int), ("act", C.c_int), ("res_ups", C.c_int), ("pixshuf", C.c_int),
+        ("stem", C.c_int), ("splitk", C.c_int),
+        ("m_dev", fptr),
+    ]
+
+
+class RpnDesc(C.Structure):
+    _fields_ = [
+        ("head", fptr * 5),
+        ("Hf", C.c_int * 5), ("Wf", C.c_int * 5), ("stride", C.c_int * 5),
+        ("cell_anchors", ((C.c_float * 4) * 3) * 5),
+        ("B", C.c_int), ("L", C.c_int), ("A", C.c_int), ("CH", C.c_int),
+        ("img_h", C.c_int), ("img_w", C.c_int),
+        ("pre_topk", C.c_int), ("post_topk", C.c_int),
+        ("nms_thresh", C.c_float), ("min_size", C.c_float),
+        ("weights", C.c_float * 4),
+        ("scale_clamp", C.c_float),
+        ("workspace", fptr),
+        ("out_boxes", fptr), ("out_scores", fptr), ("out_level", fptr), ("out_pos", fptr), ("out_count", fptr),
+    ]
+
+
+class BoxDetDesc(C.Structure):
+    _fields_ = [
+        ("pred", fptr), ("prop_boxes", fptr), ("prop_count", fptr),
+        ("B", C.c_int), ("R", C.c_int), ("C", C.c_int), ("CH", C.c_int),
+        ("img_h", C.c_int), ("img_w", C.c_int),
+        ("score_thresh", C.c_float), ("nms_thresh", C.c_float),
+        ("topk", C.c_int),
+        ("weights", C.c_float * 4),
+        ("scale_clamp", C.c_float),
+        ("workspace", fptr),
+        ("out_boxes", fptr), ("out_scores", fptr), ("out_classes", fptr), ("out_pos", fptr), ("out_count", fptr),
+    ]
+
+
+class RoiAlignDesc(C.Structure):
+    _fields_ = [
+        ("feat", fptr * 4),
+        ("Hf", C.c_int * 4), ("Wf", C.c_int * 4),
+        ("scale", C.c_float * 4),
+        ("L", C.c_int), ("C", C.c_int),
+        ("boxes", fptr), ("count", fptr), ("row_offset", fptr),
+        ("B", C.c_int), ("R", C.c_int),
+        ("P", C.c_int), ("sampling_ratio", C.c_int), ("aligned", C.c_int),
+        ("out", fptr), ("out_level", fptr),
+    ]
+
+
+class PasteDesc(C.Structure):
+    _fields_ = [
+        ("boxes", fptr), ("scores", fptr), ("count", fptr), ("row_offset", fptr), ("mask_prob", fptr),
+        ("normals", fptr), ("depth", fptr),
+        ("B", C.c_int), ("R", C.c_int), ("MS", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("post_score_thresh", C.c_float), ("mask_thresh", C.c_float),
+        ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("masks", fptr), ("planes", fptr), ("area", fptr), ("keep", fptr), ("out_boxes", fptr),
+    ]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [
+        ("boxes", fptr), ("scores", fptr), ("classes", fptr), ("count", fptr), ("row_offset", fptr), ("keep", fptr),
+        ("planes", fptr), ("rot_axis", fptr), ("tran_axis", fptr), ("mask_prob", fptr),
+        ("B", C.c_int), ("R", C.c_int), ("MS", C.c_int),
+        ("records", fptr), ("rec_count", fptr),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/a3d.h declares
+SIGNATURES = {
+    "a3d_version": (C.c_int, []),
+    "a3d_preprocess_u8hwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
+    "a3d_preprocess_f32chw": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
+    "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_maxpool3x3s2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_subsample2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_resize_bilinear_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_conv3x3_to1_nhwc": (C.c_int, [fptr, fptr, C.c_float, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_group_buffers_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), fptr]),
+    "a3d_box_detections": (C.c_int, [C.POINTER(BoxDetDesc), fptr]),
+    "a3d_group_nms": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_float, fptr]),
+    "a3d_roi_align_fpn": (C.c_int, [C.POINTER(RoiAlignDesc), fptr]),
+    "a3d_count_offsets": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr]),
+    "a3d_linear_small": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_paste_lsq": (C.c_int, [C.POINTER(PasteDesc), fptr]),
+    "a3d_plane_offset_dense": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fptr]),
+    "a3d_detections_pack": (C.c_int, [C.POINTER(PackDesc), fptr]),
+    "a3d_record_floats": (C.c_int, [C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded kernel library.  Raises if it has not been built (python -m articulation3d_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernel library has not been built. "
+                "Run `python -m articulation3d_amd.build` (or __graft_entry__.build()). There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with {_ERR.get(rc, rc)}")

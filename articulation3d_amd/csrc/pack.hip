@@ -1,0 +1,86 @@
+// Fixed-size detection records: the payload of the per-frame all-gather that feeds the host-side
+// temporal optimiser.  One record = the fields create_instances() materialises for one detection
+// (pkg/utils/arti_vis.py:162-186): box xyxy (4), score, class, plane normal*offset (3), rot axis (3),
+// tran axis (2) and the 28x28 soft mask (re-pasted deterministically by the receiver) = 798 floats.
+#include "a3d_common.h"
+#include "../../include/a3d.h"
+
+#define REC_HEAD 14
+
+struct PackArgs {
+    const float *boxes, *scores;
+    const int *classes, *count, *row_offset, *keep;
+    const float *planes, *rot_axis, *tran_axis, *mask_prob;
+    int B, R, MS;
+    float *records;
+    int *rec_count;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
+    __shared__ int dst[1024];
+    __shared__ int s_total;
+    const int b = blockIdx.x;
+    const int cnt = min(a.count[b], a.R);
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int r = 0; r < a.R; ++r) {
+            const bool k = r < cnt && a.keep[b * a.R + r];
+            dst[r] = k ? t : -1;
+            t += k ? 1 : 0;
+        }
+        s_total = t;
+        a.rec_count[b] = t;
+    }
+    __syncthreads();
+    const int mm = a.MS * a.MS, rec = REC_HEAD + mm;
+    const int total = s_total;
+    float *out = a.records + (size_t)b * a.R * rec;
+    for (int r = 0; r < a.R; ++r) {
+        const int d = dst[r];
+        if (d < 0) continue;
+        const int slot = b * a.R + r, row = a.row_offset[b] + r;
+        float *o = out + (size_t)d * rec;
+        if (threadIdx.x < REC_HEAD) {
+            const int t = threadIdx.x;
+            float v;
+            if (t < 4) v = a.boxes[slot * 4 + t];
+            else if (t == 4) v = a.scores[slot];
+            else if (t == 5) v = (float)a.classes[slot];
+            else if (t < 9) v = a.planes ? a.planes[slot * 3 + (t - 6)] : 0.f;
+            else if (t < 12) v = a.rot_axis ? a.rot_axis[(size_t)row * 3 + (t - 9)] : 0.f;
+            else v = a.tran_axis ? a.tran_axis[(size_t)row * 2 + (t - 12)] : 0.f;
+            o[t] = v;
+        }
+        if (a.mask_prob)
+            for (int i = threadIdx.x; i < mm; i += blockDim.x) o[REC_HEAD + i] = a.mask_prob[(size_t)row * mm + i];
+    }
+    // zero the unused tail so the gathered buffer is deterministic
+    for (size_t i = (size_t)total * rec + threadIdx.x; i < (size_t)a.R * rec; i += blockDim.x) out[i] = 0.f;
+}
+
+extern "C" int a3d_record_floats(int MS) { return REC_HEAD + MS * MS; }
+
+extern "C" int a3d_detections_pack(const a3d_pack_desc *d, void *stream) {
+    if (!d || !d->boxes || !d->scores || !d->classes || !d->count || !d->row_offset || !d->keep || !d->records ||
+        !d->rec_count)
+        return A3D_ERR_ARG;
+    if (d->B <= 0 || d->R <= 0 || d->R > 1024 || d->MS <= 0) return A3D_ERR_ARG;
+    PackArgs a;
+    a.boxes = d->boxes;
+    a.scores = d->scores;
+    a.classes = d->classes;
+    a.count = d->count;
+    a.row_offset = d->row_offset;
+    a.keep = d->keep;
+    a.planes = d->planes;
+    a.rot_axis = d->rot_axis;
+    a.tran_axis = d->tran_axis;
+    a.mask_prob = d->mask_prob;
+    a.B = d->B;
+    a.R = d->R;
+    a.MS = d->MS;
+    a.records = d->records;
+    a.rec_count = d->rec_count;
+    hipLaunchKernelGGL(pack_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, a);
+    return a3d_check_launch();
+}

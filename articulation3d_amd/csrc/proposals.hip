@@ -1,0 +1,500 @@
+// Proposal / detection selection kernels (integer + fp32 index work, latency-bound):
+//   rpn_select      per (image, level): radix-select the top-k objectness logits, sort them, decode
+//                   the anchor deltas, clip, flag invalid boxes           
+//   box_candidates  per (image, class): softmax, per-class delta decode, clip, score threshold, sort
+//                                                                            
+//   group_nms       per group (<=1024 score-sorted boxes): IoU bitmask in LDS + wavefront scan
+//                                                                            
+//   merge_topk      per image: merge the kept boxes of its groups by (score desc, position asc),
+//                   keep the first K
+// Built with -ffp-contract=off: box arithmetic must round exactly like the separate mul/add/div
+// sequence of the reference operators so that keep-masks are bit-exact on identical inputs.
+#include "a3d_common.h"
+#include "../../include/a3d.h"
+
+#define GROUP_CAP 1024
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t ordered_key(float f) {
+    f = f + 0.0f;  // -0 -> +0 so that equal floats give equal keys
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// Descending bitonic sort of n (power of two) 64-bit keys in LDS by the whole workgroup.
+__device__ void bitonic_sort_desc(u64 *k, int n) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 a = k[lo], b = k[hi];
+                if ((a < b) == desc) {
+                    k[lo] = b;
+                    k[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool finite4(float a, float b, float c, float d) {
+    return isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d);
+}
+
+// Box2BoxTransform.apply_deltas + Boxes.clip, op order of SURVEY.md A.5.
+__device__ __forceinline__ void decode_clip(const float ax1, const float ay1, const float ax2, const float ay2, float dx,
+                                            float dy, float dw, float dh, float wx, float wy, float ww, float wh,
+                                            float clampv, float img_w, float img_h, float out[4], bool &finite) {
+    const float w = ax2 - ax1, h = ay2 - ay1;
+    const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+    dx = dx / wx;
+    dy = dy / wy;
+    dw = dw / ww;
+    dh = dh / wh;
+    dw = fminf(dw, clampv);
+    dh = fminf(dh, clampv);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    finite = finite4(x1, y1, x2, y2);
+    out[0] = fminf(fmaxf(x1, 0.f), img_w);
+    out[1] = fminf(fmaxf(y1, 0.f), img_h);
+    out[2] = fminf(fmaxf(x2, 0.f), img_w);
+    out[3] = fminf(fmaxf(y2, 0.f), img_h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rpn_select: grid (L, B), block 1024.
+// head: [B, Hf, Wf, CH] with channels [0,A) = objectness, [A, 5A) = deltas (a*4 + coord).
+// ------------------------------------------------------------------------------------------------
+struct RpnLevel {
+    const float *head;
+    int Hf, Wf, stride;
+    float base[3][4];  // cell anchors (A = 3)
+};
+struct RpnSelectArgs {
+    RpnLevel lv[5];
+    int L, A, CH, pre_topk;
+    float wx, wy, ww, wh, clampv, img_w, img_h, min_size;
+    float *g_boxes;    // [B*L][GROUP_CAP][4]
+    float *g_scores;   // [B*L][GROUP_CAP]
+    int *g_pos;        // [B*L][GROUP_CAP]
+    int *g_valid;      // [B*L][GROUP_CAP]
+    int *g_n;          // [B*L]
+};
+
+__global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a) {
+    __shared__ u64 sel[GROUP_CAP];
+    __shared__ unsigned int hist[256];
+    __shared__ u64 s_prefix;
+    __shared__ int s_krem, s_cnt;
+    const int l = blockIdx.x, b = blockIdx.y, g = b * a.L + l;
+    const RpnLevel &lv = a.lv[l];
+    const int n = lv.Hf * lv.Wf * a.A;
+    const int k = min(a.pre_topk, min(n, GROUP_CAP));
+    const float *head = lv.head + (size_t)b * lv.Hf * lv.Wf * a.CH;
+    int nb = 8;
+    while ((1 << nb) < n) nb += 8;
+    const u64 idx_mask = ((u64)1 << nb) - 1;
+    const int total_bits = 32 + nb;
+    auto composite = [&](int i) -> u64 {
+        const int pix = i / a.A, an = i - pix * a.A;
+        const float s = head[(size_t)pix * a.CH + an];
+        return ((u64)ordered_key(s) << nb) | (idx_mask - (u64)i);
+    };
+    if (threadIdx.x == 0) {
+        s_prefix = 0;
+        s_krem = k;
+        s_cnt = 0;
+    }
+    // radix select (8 bits per pass, most significant first) of the k-th largest composite key
+    for (int shift = total_bits - 8; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 prefix = s_prefix;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const u64 c = composite(i);
+            if ((c >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(c >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int krem = s_krem, bin = 255;
+            unsigned cum = 0;
+            for (; bin > 0; --bin) {
+                if (cum + hist[bin] >= (unsigned)krem) break;
+                cum += hist[bin];
+            }
+            s_krem = krem - (int)cum;
+            s_prefix = (prefix << 8) | (u64)bin;
+        }
+        __syncthreads();
+    }
+    const u64 T = s_prefix;
+    for (int i = threadIdx.x; i < GROUP_CAP; i += blockDim.x) sel[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 c = composite(i);
+        if (c >= T) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            if (slot < GROUP_CAP) sel[slot] = c;
+        }
+    }
+    bitonic_sort_desc(sel, GROUP_CAP);
+    for (int r = threadIdx.x; r < GROUP_CAP; r += blockDim.x) {
+        float box[4] = {0.f, 0.f, 0.f, 0.f};
+        float score = 0.f;
+        int valid = 0;
+        if (r < k) {
+            const u64 c = sel[r];
+            const int i = (int)(idx_mask - (c & idx_mask));
+            score = key_to_float((uint32_t)(c >> nb));
+            const int pix = i / a.A, an = i - pix * a.A;
+            const int y = pix / lv.Wf, x = pix - y * lv.Wf;
+            const float sx = (float)(x * lv.stride), sy = (float)(y * lv.stride);
+            const float *dl = head + (size_t)pix * a.CH + a.A + an * 4;
+            bool fin;
+            decode_clip(sx + lv.base[an][0], sy + lv.base[an][1], sx + lv.base[an][2], sy + lv.base[an][3], dl[0], dl[1],
+                        dl[2], dl[3], a.wx, a.wy, a.ww, a.wh, a.clampv, a.img_w, a.img_h, box, fin);
+            const bool nonempty = (box[2] - box[0]) > a.min_size && (box[3] - box[1]) > a.min_size;
+            valid = (fin && isfinite(score) && nonempty) ? 1 : 0;
+        }
+        const size_t o = (size_t)g * GROUP_CAP + r;
+        *reinterpret_cast<f32x4 *>(a.g_boxes + o * 4) = f32x4{box[0], box[1], box[2], box[3]};
+        a.g_scores[o] = score;
+        a.g_pos[o] = (l << 10) | r;
+        a.g_valid[o] = valid;
+    }
+    if (threadIdx.x == 0) a.g_n[g] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// box_candidates: grid (C, B), block 1024.  pred: [B*R, CH] with channels [0, C] = class logits
+// (last = background), [C+1, C+1+4C) = per-class deltas.  proposals [B][R][4], counts [B].
+// ------------------------------------------------------------------------------------------------
+struct BoxCandArgs {
+    const float *pred;
+    const float *prop_boxes;
+    const int *prop_count;
+    int R, C, CH;
+    float wx, wy, ww, wh, clampv, img_w, img_h, score_thresh;
+    float *g_boxes, *g_scores;
+    int *g_pos, *g_valid, *g_n;
+};
+
+__global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandArgs a) {
+    __shared__ u64 sel[GROUP_CAP];
+    __shared__ int s_cnt;
+    const int c = blockIdx.x, b = blockIdx.y, g = b * a.C + c;
+    const int nprop = min(a.prop_count[b], min(a.R, GROUP_CAP));
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < GROUP_CAP; r += blockDim.x) {
+        u64 key = 0;
+        if (r < nprop) {
+            const float *p = a.pred + ((size_t)b * a.R + r) * a.CH;
+            // softmax over C+1 logits (max-subtracted, as aten's softmax)
+            float mx = p[0];
+            for (int j = 1; j <= a.C; ++j) mx = fmaxf(mx, p[j]);
+            float den = 0.f;
+            for (int j = 0; j <= a.C; ++j) den += expf(p[j] - mx);
+            const float prob = expf(p[c] - mx) / den;
+            bool row_ok = isfinite(den);  // valid_mask: every decoded box and score of the ROW finite
+            for (int j = 0; j <= a.C; ++j) row_ok = row_ok && isfinite(expf(p[j] - mx) / den);
+            const float *pbx = a.prop_boxes + ((size_t)b * a.R + r) * 4;
+            for (int j = 0; j < a.C; ++j) {
+                const float *dl = p + a.C + 1 + j * 4;
+                float tmp[4];
+                bool fin;
+                decode_clip(pbx[0], pbx[1], pbx[2], pbx[3], dl[0], dl[1], dl[2], dl[3], a.wx, a.wy, a.ww, a.wh, a.clampv,
+                            a.img_w, a.img_h, tmp, fin);
+                row_ok = row_ok && fin;
+            }
+            if (row_ok && prob > a.score_thresh) {
+                key = ((u64)ordered_key(prob) << 32) | (u64)(0xffffffffu - (uint32_t)r);
+                atomicAdd(&s_cnt, 1);
+            }
+        }
+        sel[r] = key;
+    }
+    bitonic_sort_desc(sel, GROUP_CAP);
+    const int n = s_cnt;
+    for (int r = threadIdx.x; r < GROUP_CAP; r += blockDim.x) {
+        float box[4] = {0.f, 0.f, 0.f, 0.f};
+        float score = 0.f;
+        int valid = 0, pos = 0;
+        if (r < n) {
+            const u64 key = sel[r];
+            const int row = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+            score = key_to_float((uint32_t)(key >> 32));
+            const float *p = a.pred + ((size_t)b * a.R + row) * a.CH + a.C + 1 + c * 4;
+            const float *pb = a.prop_boxes + ((size_t)b * a.R + row) * 4;
+            bool fin;
+            decode_clip(pb[0], pb[1], pb[2], pb[3], p[0], p[1], p[2], p[3], a.wx, a.wy, a.ww, a.wh, a.clampv, a.img_w,
+                        a.img_h, box, fin);
+            valid = fin ? 1 : 0;
+            pos = row * a.C + c;
+        }
+        const size_t o = (size_t)g * GROUP_CAP + r;
+        *reinterpret_cast<f32x4 *>(a.g_boxes + o * 4) = f32x4{box[0], box[1], box[2], box[3]};
+        a.g_scores[o] = score;
+        a.g_pos[o] = pos;
+        a.g_valid[o] = valid;
+    }
+    if (threadIdx.x == 0) a.g_n[g] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// group_nms: grid (G), block 1024.  Boxes of a group are already score-descending.
+// LDS: 1024 x 16 suppression words (128 KiB) + boxes (16 KiB).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
+                                                         const int *__restrict__ g_n, int *__restrict__ g_keep,
+                                                         float thr) {
+    __shared__ u64 mask[GROUP_CAP * 16];
+    __shared__ f32x4 sb[GROUP_CAP];
+    __shared__ unsigned char sv[GROUP_CAP];
+    const int g = blockIdx.x;
+    const int n = min(g_n[g], GROUP_CAP);
+    for (int i = threadIdx.x; i < GROUP_CAP; i += blockDim.x) {
+        sb[i] = *reinterpret_cast<const f32x4 *>(g_boxes + ((size_t)g * GROUP_CAP + i) * 4);
+        sv[i] = (i < n) ? (unsigned char)g_valid[(size_t)g * GROUP_CAP + i] : 0;
+    }
+    __syncthreads();
+    const int nwords = (n + 63) >> 6;
+    for (int wd = threadIdx.x; wd < n * 16; wd += blockDim.x) {
+        const int i = wd >> 4, w = wd & 15;
+        u64 bits = 0;
+        if (w < nwords && (w << 6) + 63 > i && sv[i]) {
+            const f32x4 bi = sb[i];
+            const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+            const int j0 = w << 6;
+            for (int t = 0; t < 64; ++t) {
+                const int j = j0 + t;
+                if (j <= i || j >= n || !sv[j]) continue;
+                const f32x4 bj = sb[j];
+                const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+                const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                const float inter = iw * ih;
+                const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+                const float ovr = inter / (ai + aj - inter);
+                if (ovr > thr) bits |= (u64)1 << t;
+            }
+        }
+        mask[wd] = bits;
+    }
+    __syncthreads();
+    // Wavefront scan by wave 0: lane l < 16 carries removed-word l.  Per 64-box block: resolve the
+    // block with its diagonal words in registers (v_readlane chain), then OR the kept rows' words
+    // into the carried state (4 row subsets x 16 words over the 64 lanes, xor-shuffle reduce).
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        u64 R = 0;
+        for (int wi = 0; wi < nwords; ++wi) {
+            const int row = (wi << 6) + lane;
+            const u64 diag = (row < n) ? mask[row * 16 + wi] : 0;
+            const u64 validbits = __ballot(row < n && sv[row]);
+            u64 cur = __shfl(R, wi, 64);  // removed bits of this block so far
+            u64 kept = 0;
+            for (int bq = 0; bq < 64; ++bq) {
+                const u64 d = __shfl(diag, bq, 64);
+                const bool alive = ((validbits >> bq) & 1) && !((cur >> bq) & 1);
+                if (alive) {
+                    kept |= (u64)1 << bq;
+                    cur |= d;
+                }
+            }
+            if (row < GROUP_CAP) g_keep[(size_t)g * GROUP_CAP + row] = (int)((kept >> lane) & 1);
+            const int w = lane & 15, sub = lane >> 4;
+            u64 acc = 0;
+            for (int t = 0; t < 16; ++t) {
+                const int rr = sub * 16 + t;
+                if ((kept >> rr) & 1) acc |= mask[((wi << 6) + rr) * 16 + w];
+            }
+            acc |= __shfl_xor(acc, 16, 64);
+            acc |= __shfl_xor(acc, 32, 64);
+            R |= acc;  // lanes >= 16 carry copies; only lanes < 16 are read via __shfl(R, wi)
+        }
+        for (int row = (nwords << 6) + lane; row < GROUP_CAP; row += 64) g_keep[(size_t)g * GROUP_CAP + row] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge_topk: grid (B), block 1024.  groups of image b: [b*NG, (b+1)*NG).
+// ------------------------------------------------------------------------------------------------
+#define MERGE_CAP 8192
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restrict__ g_boxes,
+                                                          const float *__restrict__ g_scores,
+                                                          const int *__restrict__ g_pos, const int *__restrict__ g_keep,
+                                                          const int *__restrict__ g_n, int NG, int K,
+                                                          float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                          int *__restrict__ out_cat, int *__restrict__ out_pos,
+                                                          int *__restrict__ out_count) {
+    __shared__ u64 keys[MERGE_CAP];
+    __shared__ unsigned short ref[MERGE_CAP];
+    __shared__ int s_cnt;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < MERGE_CAP; i += blockDim.x) keys[i] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int gl = 0; gl < NG; ++gl) {
+        const int g = b * NG + gl;
+        const int n = min(g_n[g], GROUP_CAP);
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            const size_t o = (size_t)g * GROUP_CAP + r;
+            if (g_keep[o]) {
+                const int pos = g_pos[o];
+                const int slot = atomicAdd(&s_cnt, 1);
+                keys[slot] = ((u64)ordered_key(g_scores[o]) << 32) | (u64)(0xffffffffu - (uint32_t)pos);
+                ref[pos] = (unsigned short)((gl << 10) | r);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = s_cnt;
+    int np2 = 2;
+    while (np2 < total) np2 <<= 1;
+    bitonic_sort_desc(keys, np2);
+    const int cnt = min(total, K);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        f32x4 box = {0.f, 0.f, 0.f, 0.f};
+        float sc = 0.f;
+        int cat = -1, pos = -1;
+        if (i < cnt) {
+            pos = (int)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffu));
+            const int rf = ref[pos];
+            cat = rf >> 10;
+            const size_t o = (size_t)(b * NG + cat) * GROUP_CAP + (rf & 1023);
+            box = *reinterpret_cast<const f32x4 *>(g_boxes + o * 4);
+            sc = g_scores[o];
+        }
+        *reinterpret_cast<f32x4 *>(out_boxes + ((size_t)b * K + i) * 4) = box;
+        out_scores[(size_t)b * K + i] = sc;
+        out_cat[(size_t)b * K + i] = cat;
+        out_pos[(size_t)b * K + i] = pos;
+    }
+    if (threadIdx.x == 0) out_count[b] = cnt;
+}
+
+// ================================= C ABI ==========================================================
+extern "C" size_t a3d_group_buffers_bytes(int n_groups) {
+    // boxes(16) + scores(4) + pos(4) + valid(4) + keep(4) per slot, + n per group
+    return (size_t)n_groups * GROUP_CAP * 32 + (size_t)n_groups * 4 + 256;
+}
+
+struct GroupBufs {
+    float *boxes, *scores;
+    int *pos, *valid, *keep, *n;
+};
+static GroupBufs carve(void *ws, int G) {
+    GroupBufs gb;
+    char *p = (char *)ws;
+    gb.boxes = (float *)p;
+    p += (size_t)G * GROUP_CAP * 16;
+    gb.scores = (float *)p;
+    p += (size_t)G * GROUP_CAP * 4;
+    gb.pos = (int *)p;
+    p += (size_t)G * GROUP_CAP * 4;
+    gb.valid = (int *)p;
+    p += (size_t)G * GROUP_CAP * 4;
+    gb.keep = (int *)p;
+    p += (size_t)G * GROUP_CAP * 4;
+    gb.n = (int *)p;
+    return gb;
+}
+
+extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
+    if (!d || d->L < 1 || d->L > 5 || d->A != 3 || !d->workspace || !d->out_boxes || !d->out_scores || !d->out_count)
+        return A3D_ERR_ARG;
+    if (d->pre_topk > GROUP_CAP || d->post_topk <= 0 || d->L * GROUP_CAP > MERGE_CAP) return A3D_ERR_UNSUPPORTED;
+    if (d->CH < 5 * d->A) return A3D_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = d->B * d->L;
+    GroupBufs gb = carve(d->workspace, G);
+    RpnSelectArgs a;
+    for (int l = 0; l < d->L; ++l) {
+        a.lv[l].head = d->head[l];
+        a.lv[l].Hf = d->Hf[l];
+        a.lv[l].Wf = d->Wf[l];
+        a.lv[l].stride = d->stride[l];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) a.lv[l].base[i][j] = d->cell_anchors[l][i][j];
+        if ((size_t)d->Hf[l] * d->Wf[l] * d->A >= ((size_t)1 << 24)) return A3D_ERR_UNSUPPORTED;
+    }
+    a.L = d->L;
+    a.A = d->A;
+    a.CH = d->CH;
+    a.pre_topk = d->pre_topk;
+    a.wx = d->weights[0];
+    a.wy = d->weights[1];
+    a.ww = d->weights[2];
+    a.wh = d->weights[3];
+    a.clampv = d->scale_clamp;
+    a.img_w = (float)d->img_w;
+    a.img_h = (float)d->img_h;
+    a.min_size = d->min_size;
+    a.g_boxes = gb.boxes;
+    a.g_scores = gb.scores;
+    a.g_pos = gb.pos;
+    a.g_valid = gb.valid;
+    a.g_n = gb.n;
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(d->L, d->B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->L,
+                       d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
+    if (!d || !d->pred || !d->prop_boxes || !d->prop_count || !d->workspace || !d->out_boxes || !d->out_scores ||
+        !d->out_classes || !d->out_count)
+        return A3D_ERR_ARG;
+    if (d->R > GROUP_CAP || d->C < 1 || d->C * GROUP_CAP > MERGE_CAP || d->R * d->C > MERGE_CAP) return A3D_ERR_UNSUPPORTED;
+    if (d->CH < 5 * d->C + 1) return A3D_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = d->B * d->C;
+    GroupBufs gb = carve(d->workspace, G);
+    BoxCandArgs a;
+    a.pred = d->pred;
+    a.prop_boxes = d->prop_boxes;
+    a.prop_count = d->prop_count;
+    a.R = d->R;
+    a.C = d->C;
+    a.CH = d->CH;
+    a.wx = d->weights[0];
+    a.wy = d->weights[1];
+    a.ww = d->weights[2];
+    a.wh = d->weights[3];
+    a.clampv = d->scale_clamp;
+    a.img_w = (float)d->img_w;
+    a.img_h = (float)d->img_h;
+    a.score_thresh = d->score_thresh;
+    a.g_boxes = gb.boxes;
+    a.g_scores = gb.scores;
+    a.g_pos = gb.pos;
+    a.g_valid = gb.valid;
+    a.g_n = gb.n;
+    hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
+                       d->topk, d->out_boxes, d->out_scores, d->out_classes, d->out_pos, d->out_count);
+    return a3d_check_launch();
+}
+
+// Stand-alone batched NMS over caller-sorted groups (unit-parity entry for the keep masks).
+extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int *g_n, int *g_keep, int n_groups,
+                             float thresh, void *stream) {
+    if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
+    hipLaunchKernelGGL(group_nms_kernel, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
+                       g_keep, thresh);
+    return a3d_check_launch();
+}

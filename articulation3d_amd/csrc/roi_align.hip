@@ -1,0 +1,138 @@
+// ROIPooler = FPN level assignment + ROIAlign over NHWC pyramids.
+// Replaces detectron2 ROIPooler -> torchvision.ops.roi_align reached from
+// pkg/modeling/roi_heads/roi_heads.py:185 (box, 7x7 aligned), :236 (mask, 14x14 ratio 2),
+// :250 (plane) and :268 (axis) (14x14 adaptive).
+//
+// HBM/L2-bound gather.  NHWC makes every bilinear corner a contiguous C-vector: one wave owns one
+// output bin, lane l owns channels 4l..4l+3 (C = 256 -> exactly one float4 per lane), so every corner
+// read and the bin store are 1 KiB coalesced accesses.  One workgroup (4 waves) owns one ROI and
+// walks its P*P bins; the ROI geometry is computed once per workgroup.
+#include "a3d_common.h"
+#include "../../include/a3d.h"
+
+struct RoiArgs {
+    const float *feat[4];
+    int Hf[4], Wf[4];
+    float scale[4];
+    int L, C;
+    const float *boxes;
+    const int *count;
+    const int *row_offset;
+    int R, P, ratio, aligned;
+    float *out;
+    int *out_level;
+};
+
+__global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
+    const int slot = blockIdx.x;
+    const int b = slot / a.R, r = slot - b * a.R;
+    const int cnt = a.count ? a.count[b] : a.R;
+    if (r >= cnt) return;
+    const int row = (a.row_offset ? a.row_offset[b] : b * a.R) + r;
+    const float *bx = a.boxes + (size_t)slot * 4;
+    const float bx1 = bx[0], by1 = bx[1], bx2 = bx[2], by2 = bx[3];
+    // level = floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to [2, 2+L-1]
+    const float size = sqrtf((bx2 - bx1) * (by2 - by1));
+    float lvf = floorf(4.0f + log2f(size / 224.0f + 1e-8f));
+    lvf = fminf(fmaxf(lvf, 2.0f), (float)(2 + a.L - 1));
+    const int lv = (int)lvf - 2;
+    if (a.out_level && threadIdx.x == 0) a.out_level[row] = lv;
+    const float *feat = a.feat[lv] + (size_t)b * a.Hf[lv] * a.Wf[lv] * a.C;
+    const int H = a.Hf[lv], W = a.Wf[lv];
+    const float s = a.scale[lv];
+    const float off = a.aligned ? 0.5f : 0.0f;
+    const float x1 = bx1 * s - off, y1 = by1 * s - off, x2 = bx2 * s - off, y2 = by2 * s - off;
+    float rw = x2 - x1, rh = y2 - y1;
+    if (!a.aligned) {
+        rw = fmaxf(rw, 1.0f);
+        rh = fmaxf(rh, 1.0f);
+    }
+    const float bh = rh / (float)a.P, bw = rw / (float)a.P;
+    const int gh = a.ratio > 0 ? a.ratio : (int)ceilf(rh / (float)a.P);
+    const int gw = a.ratio > 0 ? a.ratio : (int)ceilf(rw / (float)a.P);
+    const float count = (float)max(gh * gw, 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C4 = a.C >> 2;
+    float *orow = a.out + (size_t)row * a.P * a.P * a.C;
+    for (int bin = wave; bin < a.P * a.P; bin += 4) {
+        const int ph = bin / a.P, pw = bin - ph * a.P;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int iy = 0; iy < gh; ++iy) {
+                float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                if (y < -1.0f || y > (float)H) continue;
+                if (y <= 0.f) y = 0.f;
+                int yl = (int)y, yh;
+                if (yl >= H - 1) {
+                    yh = yl = H - 1;
+                    y = (float)yl;
+                } else
+                    yh = yl + 1;
+                const float ly = y - (float)yl, hy = 1.0f - ly;
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                    if (x < -1.0f || x > (float)W) continue;
+                    if (x <= 0.f) x = 0.f;
+                    int xl = (int)x, xh;
+                    if (xl >= W - 1) {
+                        xh = xl = W - 1;
+                        x = (float)xl;
+                    } else
+                        xh = xl + 1;
+                    const float lx = x - (float)xl, hx = 1.0f - lx;
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(feat + ((size_t)yl * W + xl) * a.C + c4 * 4);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4 *>(feat + ((size_t)yl * W + xh) * a.C + c4 * 4);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4 *>(feat + ((size_t)yh * W + xl) * a.C + c4 * 4);
+                    const f32x4 v4 = *reinterpret_cast<const f32x4 *>(feat + ((size_t)yh * W + xh) * a.C + c4 * 4);
+                    acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                }
+            }
+            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = acc / count;
+        }
+    }
+}
+
+extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
+    if (!d || !d->boxes || !d->out || d->L < 1 || d->L > 4 || (d->C & 3) || d->B <= 0 || d->R <= 0 || d->P <= 0)
+        return A3D_ERR_ARG;
+    RoiArgs a;
+    for (int l = 0; l < 4; ++l) {
+        a.feat[l] = l < d->L ? d->feat[l] : nullptr;
+        a.Hf[l] = d->Hf[l];
+        a.Wf[l] = d->Wf[l];
+        a.scale[l] = d->scale[l];
+        if (l < d->L && !d->feat[l]) return A3D_ERR_ARG;
+    }
+    a.L = d->L;
+    a.C = d->C;
+    a.boxes = d->boxes;
+    a.count = d->count;
+    a.row_offset = d->row_offset;
+    a.R = d->R;
+    a.P = d->P;
+    a.ratio = d->sampling_ratio;
+    a.aligned = d->aligned;
+    a.out = d->out;
+    a.out_level = d->out_level;
+    hipLaunchKernelGGL(roi_align_fpn_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    return a3d_check_launch();
+}
+
+// exclusive prefix sum of per-image counts (B <= 1024): offsets[b], total -> offsets[B]
+__global__ void count_offsets_kernel(const int *count, int *offsets, int B, int cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int b = 0; b < B; ++b) {
+            offsets[b] = s;
+            s += min(count[b], cap);
+        }
+        offsets[B] = s;
+    }
+}
+
+extern "C" int a3d_count_offsets(const int *count, int *offsets, int B, int cap, void *stream) {
+    if (!count || !offsets || B <= 0) return A3D_ERR_ARG;
+    hipLaunchKernelGGL(count_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, offsets, B, cap);
+    return a3d_check_launch();
+}

@@ -1,0 +1,210 @@
+// HBM-bound NHWC helpers of the detection path: frame normalisation, the stem max-pool, the FPN
+// p6 subsample, bilinear resizes of the depth head and its 64->1 3x3 prediction conv.
+// One thread owns one float4 of channels (16 B/lane, coalesced); grid-stride loops capped at 2048 WGs.
+#include "a3d_common.h"
+#include "../../include/a3d.h"
+
+static inline int grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b ? b : 1));
+}
+
+// ---- (x - mean)/std, uint8 HWC BGR -> fp32 NHWC4 ------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+                                                            size_t npix, float m0, float m1, float m2, float s0,
+                                                            float s1, float s2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = in + i * 3;
+        f32x4 v = {((float)p[0] - m0) / s0, ((float)p[1] - m1) / s1, ((float)p[2] - m2) / s2, 0.f};
+        *reinterpret_cast<f32x4 *>(out + i * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_chw_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                             int B, size_t hw, float m0, float m1, float m2, float s0,
+                                                             float s1, float s2) {
+    const size_t npix = (size_t)B * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / hw, r = i - b * hw;
+        const float *p = in + b * 3 * hw + r;
+        f32x4 v = {(p[0] - m0) / s0, (p[hw] - m1) / s1, (p[2 * hw] - m2) / s2, 0.f};
+        *reinterpret_cast<f32x4 *>(out + i * 4) = v;
+    }
+}
+
+extern "C" int a3d_preprocess_u8hwc(const uint8_t *frames, float *out, int B, int H, int W, const float mean[3],
+                                    const float std[3], void *stream) {
+    if (!frames || !out || B <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, frames, out, npix,
+                       mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_preprocess_f32chw(const float *images, float *out, int B, int H, int W, const float mean[3],
+                                     const float std[3], void *stream) {
+    if (!images || !out || B <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
+    const size_t hw = (size_t)H * W;
+    hipLaunchKernelGGL(preprocess_chw_kernel, dim3(grid_for(hw * B)), dim3(256), 0, (hipStream_t)stream, images, out, B,
+                       hw, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return a3d_check_launch();
+}
+
+// ---- max-pool 3x3 s2 p1 -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                           int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ow = (int)(p % Wo);
+        p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh * 2 - 1 + dy;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow * 2 - 1 + dx;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * H + ih) * W + iw) * (C4 * 4) + c * 4);
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+    }
+}
+
+extern "C" int a3d_maxpool3x3s2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream) {
+    if (!x || !y || (C & 3) || B <= 0) return A3D_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W,
+                       C / 4, Ho, Wo);
+    return a3d_check_launch();
+}
+
+// ---- kernel-1 stride-2 pool: y[b,oh,ow] = x[b,2oh,2ow] -------------------------------------------
+__global__ __launch_bounds__(256) void subsample2_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                         int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ow = (int)(p % Wo);
+        p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        *reinterpret_cast<f32x4 *>(y + i * 4) =
+            *reinterpret_cast<const f32x4 *>(x + (((size_t)b * H + 2 * oh) * W + 2 * ow) * (C4 * 4) + c * 4);
+    }
+}
+
+extern "C" int a3d_subsample2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream) {
+    if (!x || !y || (C & 3) || B <= 0) return A3D_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4,
+                       Ho, Wo);
+    return a3d_check_launch();
+}
+
+// ---- bilinear resize, align_corners=False (aten upsample_bilinear2d semantics) -------------------
+__device__ __forceinline__ void src_index(int o, float scale, int in_size, int &i0, int &i1, float &l1) {
+    float s = scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                              int H, int W, int C, int Ho, int Wo, float sh, float sw) {
+    const int CV = C / VEC;
+    const size_t total = (size_t)B * Ho * Wo * CV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        size_t p = i / CV;
+        const int ow = (int)(p % Wo);
+        p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(oh, sh, H, y0, y1, ly);
+        src_index(ow, sw, W, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float *base = x + (size_t)b * H * W * C + c;
+        for (int k = 0; k < VEC; ++k) {
+            const float v00 = base[((size_t)y0 * W + x0) * C + k], v01 = base[((size_t)y0 * W + x1) * C + k];
+            const float v10 = base[((size_t)y1 * W + x0) * C + k], v11 = base[((size_t)y1 * W + x1) * C + k];
+            y[i * VEC + k] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        }
+    }
+}
+
+extern "C" int a3d_resize_bilinear_nhwc(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo,
+                                        void *stream) {
+    if (!x || !y || B <= 0 || C <= 0) return A3D_ERR_ARG;
+    const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    if ((C & 3) == 0) {
+        const size_t total = (size_t)B * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL(resize_bilinear_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                           H, W, C, Ho, Wo, sh, sw);
+    } else {
+        const size_t total = (size_t)B * Ho * Wo * C;
+        hipLaunchKernelGGL(resize_bilinear_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                           H, W, C, Ho, Wo, sh, sw);
+    }
+    return a3d_check_launch();
+}
+
+// ---- 3x3 pad-1 conv to one channel: one wave per output pixel group --------------------------------
+// Each lane owns a float4 of channels (C = 64 -> 16 lanes per pixel, 4 pixels per wave); the 9 taps
+// are accumulated per lane, then reduced across the 16 lanes with DPP shuffles.
+__global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          float bias, float *__restrict__ y, int B, int H, int W,
+                                                          int C) {
+    const int lanes_per_pix = C >> 2;           // 16 for C=64
+    const int pix_per_blk = 256 / lanes_per_pix;
+    const int sub = threadIdx.x % lanes_per_pix;
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * pix_per_blk + threadIdx.x / lanes_per_pix; p < npix;
+         p += (size_t)gridDim.x * pix_per_blk) {
+        const int ow = (int)(p % W);
+        const size_t t = p / W;
+        const int oh = (int)(t % H);
+        const int b = (int)(t / H);
+        float acc = 0.f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh - 1 + dy;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow - 1 + dx;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * H + ih) * W + iw) * C + sub * 4);
+                const f32x4 k = *reinterpret_cast<const f32x4 *>(w + (dy * 3 + dx) * C + sub * 4);
+                acc += v[0] * k[0] + v[1] * k[1] + v[2] * k[2] + v[3] * k[3];
+            }
+        }
+        for (int off = lanes_per_pix >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (sub == 0) y[p] = acc + bias;
+    }
+}
+
+extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, float *y, int B, int H, int W, int C,
+                                    void *stream) {
+    if (!x || !w || !y || B <= 0) return A3D_ERR_ARG;
+    const int lpp = C >> 2;
+    if ((C & 3) || lpp > 64 || (lpp & (lpp - 1))) return A3D_ERR_UNSUPPORTED;
+    const size_t npix = (size_t)B * H * W;
+    const int ppb = 256 / lpp;
+    size_t blocks = (npix + ppb - 1) / ppb;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W,
+                       C);
+    return a3d_check_launch();
+}

@@ -1,0 +1,138 @@
+"""Parameter holders for the layers of the detection path.
+
+Each holder keeps its parameters under the SAME state_dict names as the detectron2 / reference modules
+(so `exps/model_final.pth`-style checkpoints load unchanged) and lowers itself
+once, lazily, to the packed layout of the HIP implicit-GEMM kernel (ops.PackedConv).  forward() works on
+fp32 NHWC device tensors and only launches kernels through `ops`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..ops import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
+
+
+def c2_msra_fill(weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    nn.init.kaiming_normal_(weight, mode="fan_out", nonlinearity="relu")
+    if bias is not None:
+        nn.init.constant_(bias, 0)
+
+
+def c2_xavier_fill(weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    nn.init.kaiming_uniform_(weight, a=1)
+    if bias is not None:
+        nn.init.constant_(bias, 0)
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped tensor -> contiguous NHWC.  Zero-copy when `t` is a channels-last view (what this
+    package's modules hand to each other)."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw_view(t: torch.Tensor) -> torch.Tensor:
+    """NHWC buffer -> NCHW-shaped view (channels_last strides), the shape the reference's callers see."""
+    return t.permute(0, 3, 1, 2)
+
+
+class _Packable(nn.Module):
+    """Caches the packed weights; re-packs when a parameter/buffer was modified or moved."""
+
+    def __init__(self):
+        super().__init__()
+        self._pack_cache = None
+        self._pack_key = None
+
+    def _key(self):
+        ts = list(self.parameters(recurse=True)) + list(self.buffers(recurse=True))
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
+
+    def packed(self) -> ops.PackedConv:
+        key = self._key()
+        if self._pack_cache is None or key != self._pack_key:
+            self._pack_cache = self._pack()
+            self._pack_key = key
+        return self._pack_cache
+
+    def _pack(self):
+        raise NotImplementedError
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Buffers of detectron2's FrozenBatchNorm2d (eps 1e-5); folded into the conv epilogue."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+
+class Conv2d(_Packable):
+    """conv (+ optional bias) (+ optional FrozenBN as `.norm`) (+ activation), NHWC in / NHWC out."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, norm=None, act=ACT_NONE):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.act = kernel_size, stride, padding, act
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.norm = norm
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def _pack(self):
+        bn = None
+        if self.norm is not None:
+            n = self.norm
+            bn = (n.weight, n.bias, n.running_mean, n.running_var, n.eps)
+        if self.in_channels == 3 and self.kernel_size == 7:
+            return ops.pack_stem(self.weight, bn, device=self.weight.device)
+        return ops.pack_conv(self.weight, self.bias, bn, self.stride, self.padding, self.act, device=self.weight.device)
+
+    def forward(self, x, **kw):
+        return ops.conv2d(x, self.packed(), **kw)
+
+
+class BNConv2d(_Packable):
+    """nn.Sequential(Conv2d, BatchNorm2d, act) of the depth head (depth_head.py:32-46): parameters live in
+    the parent under `<name>.0.*` / `<name>.1.*` (or `.1` / `.2` for the deconv form)."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int):
+        super().__init__()
+        self.conv, self.bn, self.act = conv, bn, act
+
+    def _key(self):
+        ts = list(self.conv.parameters()) + list(self.bn.parameters()) + list(self.bn.buffers())
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
+
+    def _pack(self):
+        bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps)
+        return ops.pack_conv(self.conv.weight, self.conv.bias, bn, 1, 1, self.act, device=self.conv.weight.device)
+
+
+class Linear(_Packable):
+    """nn.Linear holder.  `chw` = (C,H,W) of the flattened NCHW feature this layer consumes in the reference;
+    the packed copy is re-ordered for the NHWC activations used here."""
+
+    def __init__(self, in_features, out_features, chw=None, act=ACT_NONE):
+        super().__init__()
+        self.in_features, self.out_features, self.chw, self.act = in_features, out_features, chw, act
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def _pack(self):
+        return ops.pack_linear(self.weight, self.bias, self.chw, self.act, device=self.weight.device)
+
+    def forward(self, x, **kw):
+        return ops.linear(x, self.packed(), **kw)

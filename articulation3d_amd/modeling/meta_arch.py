@@ -1,0 +1,198 @@
+"""`PlaneRCNN` meta-architecture (META_ARCH_REGISTRY).
+
+Follows pkg/modeling/meta_arch/planercnn.py: constructor :26-58, `forward` :61-81 (eval),
+`inference` :125-146, `inference_single` :148-184, `preprocess_image` :188-196, `_postprocess` :203-219.
+
+Two entry points share the same kernels:
+  * `forward(list[dict])` -- the reference's signature and output format (list of
+    {"instances": Instances, "depth": Tensor});
+  * `inference_batched(frames_u8)` -- the MI355X throughput path: a uint8 [B,H,W,3] BGR batch stays on the
+    device end to end in fixed-size buffers (one small D2H read per batch), post-processing, mask paste and
+    the plane-offset least squares are fused, and the result is the packed detection records that the
+    frame-sharded all-gather ships to the host-side temporal optimiser.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..registry import META_ARCH_REGISTRY
+from ..structures import Boxes, ImageList, Instances
+from .backbone import build_backbone
+from .depth_head import build_depth_head
+from .layers import to_nchw_view
+from .postprocessing import detector_postprocess  # noqa: F401  (reference-compatible export)
+from .roi_heads.roi_heads import BatchedDetections, build_roi_heads
+from .rpn import build_proposal_generator
+
+__all__ = ["PlaneRCNN", "BatchedOutput", "build_model"]
+
+POST_SCORE_THRESH = 0.1  # planercnn.py:217
+
+
+@dataclass
+class BatchedOutput:
+    image_size: tuple
+    det: BatchedDetections  # raw fixed-size detections + per-ROI head outputs (compact rows)
+    depth: Optional[torch.Tensor]  # [B,H,W]
+    keep: torch.Tensor  # [B,R] survives detector_postprocess
+    boxes: torch.Tensor  # [B,R,4] clipped
+    planes: torch.Tensor  # [B,R,3] normal*offset (PlaneRCNN_Branch.process output)
+    area: torch.Tensor  # [B,R] pasted-mask pixel count
+    masks: Optional[torch.Tensor]  # [B,R,H,W] uint8 or None
+    records: torch.Tensor  # [B,R,798] packed detection records
+    rec_count: torch.Tensor  # [B]
+    proposals: Optional[tuple] = None
+
+
+@META_ARCH_REGISTRY.register()
+class PlaneRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape())
+        self.mask_threshold = cfg.MODEL.ROI_MASK_HEAD.MASK_THRESHOLD
+        self.nms = cfg.MODEL.ROI_MASK_HEAD.NMS
+        self.depth_head_on = cfg.MODEL.DEPTH_ON
+        self.refine_on = cfg.MODEL.REFINE_ON
+        self.axis_on = cfg.MODEL.AXIS_ON
+        if self.depth_head_on:
+            self.depth_head = build_depth_head(cfg)
+        assert not self.refine_on, "REFINE_ON is false in every reference config (refine head out of scope)"
+        self.vis_period = cfg.VIS_PERIOD
+        self.input_format = cfg.INPUT.FORMAT
+        assert len(cfg.MODEL.PIXEL_MEAN) == len(cfg.MODEL.PIXEL_STD) == 3
+        self.pixel_mean = tuple(float(v) for v in cfg.MODEL.PIXEL_MEAN)
+        self.pixel_std = tuple(float(v) for v in cfg.MODEL.PIXEL_STD)
+        self._eval_gt_box = cfg.TEST.EVAL_GT_BOX
+        self.to(self.device)
+        self._freeze = cfg.MODEL.FREEZE
+        for layers in self._freeze:
+            final = self
+            for l in layers.split("."):
+                final = getattr(final, l)
+            for params in final.parameters():
+                params.requires_grad = False
+
+    # ------------------------------------------------------------------ MI355X throughput path
+    @torch.no_grad()
+    def inference_batched(self, frames: torch.Tensor, want_masks: bool = False, given_boxes=None) -> BatchedOutput:
+        """frames: uint8 [B,H,W,3] BGR (device) or float32 [B,3,H,W] 0-255 BGR."""
+        assert not self.training
+        if frames.dtype == torch.uint8:
+            B, H, W, _ = frames.shape
+            x4 = ops.preprocess_u8hwc(frames.contiguous(), self.pixel_mean, self.pixel_std)
+        else:
+            B, _, H, W = frames.shape
+            x4 = ops.preprocess_f32chw(frames.contiguous().float(), self.pixel_mean, self.pixel_std)
+        assert H % self.backbone.size_divisibility == 0 and W % self.backbone.size_divisibility == 0, \
+            "batched path expects frames already a multiple of 32 (the reference feeds 480x640)"
+        hw = (H, W)
+        feats = self.backbone.forward_nhwc(x4)
+        proposals = None
+        if given_boxes is None:
+            pb, pl, plv, ppos, pc = self.proposal_generator.forward_batched(feats, hw)
+            proposals = (pb, pl, plv, ppos, pc)
+            det = self.roi_heads.box_batched(feats, pb, pc, hw)
+        else:  # forward_with_given_boxes entry (roi_heads.py:147): boxes [B,R,4], count [B]
+            gb, gc = given_boxes
+            det = BatchedDetections(gb, torch.ones(gb.shape[:2], device=gb.device), torch.zeros(gb.shape[:2], device=gb.device, dtype=torch.int32), gc, hw)
+        depth = self.depth_head.forward_nhwc(feats) if self.depth_head_on else None
+        det = self.roi_heads.given_boxes_batched(feats, det)
+        return self._post_batched(det, depth, hw, want_masks, proposals)
+
+    def _post_batched(self, det: BatchedDetections, depth, hw, want_masks, proposals) -> BatchedOutput:
+        B, R = det.boxes.shape[:2]
+        dev = det.boxes.device
+        if det.total and det.mask_prob is not None:
+            masks, planes, area, keep, boxes = ops.paste_lsq(
+                det.boxes, det.scores, det.count, det.row_offset, det.mask_prob, det.pred_plane, depth, hw,
+                post_score_thresh=POST_SCORE_THRESH, mask_thresh=self.mask_threshold, want_masks=want_masks)
+            records, rec_count = ops.detections_pack(boxes, det.scores, det.classes, det.count, det.row_offset, keep, planes,
+                                                     det.pred_rot_axis, det.pred_tran_axis, det.mask_prob, det.mask_prob.shape[-1])
+        else:
+            keep = torch.zeros((B, R), device=dev, dtype=torch.int32)
+            boxes = torch.zeros((B, R, 4), device=dev)
+            planes = torch.zeros((B, R, 3), device=dev)
+            area = torch.zeros((B, R), device=dev, dtype=torch.int32)
+            masks = torch.zeros((B, R, hw[0], hw[1]), device=dev, dtype=torch.uint8) if want_masks else None
+            records = torch.zeros((B, R, ops.record_floats(28)), device=dev)
+            rec_count = torch.zeros((B,), device=dev, dtype=torch.int32)
+        return BatchedOutput(hw, det, depth, keep, boxes, planes, area, masks, records, rec_count, proposals)
+
+    # ------------------------------------------------------------------ reference signatures
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        raise NotImplementedError("training forward (losses) is outside the inference hot path (SURVEY.md 8f-1)")
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        assert not self.training
+        assert detected_instances is None
+        pred_instances, pred_depth = self.inference_single(batched_inputs, do_postprocess)
+        for pre, d in zip(pred_instances, pred_depth):
+            pre.update({"depth": d})
+        return pred_instances
+
+    @torch.no_grad()
+    def inference_single(self, batched_inputs, do_postprocess=True):
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        if self._eval_gt_box:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            for inst in gt_instances:
+                inst.proposal_boxes = inst.gt_boxes
+                inst.objectness_logits = torch.ones(len(inst.gt_boxes), device=self.device)
+            proposals = gt_instances
+        elif self.proposal_generator is not None:
+            proposals, _ = self.proposal_generator(images, features, None)
+        else:
+            assert "proposals" in batched_inputs[0]
+            proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        pred_depth = [None] * len(proposals)
+        if self.depth_head_on:
+            pred_depth = self.depth_head(features, None)
+        results, _ = self.roi_heads(images, features, proposals, None)
+        return PlaneRCNN._postprocess(results, batched_inputs, images.image_sizes, mask_threshold=self.mask_threshold,
+                                      nms=self.nms), pred_depth
+
+    def preprocess_image(self, batched_inputs) -> ImageList:
+        """planercnn.py:188-196: to(device), (x - mean)/std, pad to a multiple of 32, batch.
+        The normalisation is the `a3d_preprocess_f32chw` kernel; `images.tensor` is an NCHW-shaped view of
+        its NHWC4 output (the buffer itself rides along so the backbone does not convert back)."""
+        imgs = [x["image"].to(self.device).float() for x in batched_inputs]
+        sizes = [(int(t.shape[-2]), int(t.shape[-1])) for t in imgs]
+        div = self.backbone.size_divisibility
+        H = (max(s[0] for s in sizes) + div - 1) // div * div
+        W = (max(s[1] for s in sizes) + div - 1) // div * div
+        if all(s == (H, W) for s in sizes):
+            x4 = ops.preprocess_f32chw(torch.stack(imgs).contiguous(), self.pixel_mean, self.pixel_std)
+        else:  # ImageList.from_tensors pads the NORMALISED images with zeros
+            x4 = torch.zeros((len(imgs), H, W, 4), device=self.device, dtype=torch.float32)
+            for i, t in enumerate(imgs):
+                x4[i, : t.shape[-2], : t.shape[-1]] = ops.preprocess_f32chw(t[None].contiguous(), self.pixel_mean, self.pixel_std)[0]
+        tensor = to_nchw_view(x4)[:, :3]
+        tensor._a3d_nhwc4 = x4
+        return ImageList(tensor, sizes)
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes, mask_threshold=0.5, nms=False):
+        processed_results = []
+        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            r = detector_postprocess(results_per_image, height, width, mask_threshold, box_score_threshold=POST_SCORE_THRESH, nms=nms)
+            processed_results.append({"instances": r})
+        return processed_results
+
+
+def build_model(cfg):
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

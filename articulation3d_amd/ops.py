@@ -1,0 +1,424 @@
+"""Thin host-side wrappers over the C-ABI kernels (include/a3d.h).
+
+torch is used for device memory and streams only: every function takes / returns torch CUDA tensors,
+hands their `data_ptr()` and the current HIP stream to liba3d_hip.so and does no arithmetic itself.
+All activations are fp32 NHWC.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
+
+GROUP_CAP = 1024
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("articulation3d_amd ops need CUDA/HIP tensors (there is no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"expected contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+# --------------------------------------------------------------------------------------------------
+# packed weights
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    w: torch.Tensor  # [cols, Kpad]
+    scale: Optional[torch.Tensor]
+    shift: Optional[torch.Tensor]
+    KH: int
+    KW: int
+    stride: int
+    pad: int
+    Cin: int  # total input channels (both sources)
+    cols: int  # GEMM columns (multiple of 4)
+    Kpad: int
+    act: int = ACT_NONE
+    pixshuf: bool = False
+    stem: bool = False
+
+    @property
+    def out_channels(self) -> int:
+        return self.cols // 4 if self.pixshuf else self.cols
+
+
+def _pad_rows(t: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    n = t.shape[0]
+    n_pad = (n + mult - 1) // mult * mult
+    if n_pad == n:
+        return t
+    out = t.new_zeros((n_pad,) + tuple(t.shape[1:]))
+    out[:n] = t
+    return out
+
+
+def fold_bn(weight, bias, mean, var, eps, conv_bias=None):
+    scale = weight * torch.rsqrt(var + eps)
+    shift = bias - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias * scale
+    return scale, shift
+
+
+def pack_conv(weight: torch.Tensor, bias=None, bn=None, stride=1, pad=0, act=ACT_NONE, device="cuda") -> PackedConv:
+    """weight [Cout, Cin, KH, KW] (torch layout) -> [Cout_pad4, KH*KW*Cin], k = (kh, kw, c)."""
+    Cout, Cin, KH, KW = weight.shape
+    if Cin % 32:
+        raise ValueError("generic conv path needs Cin % 32 == 0")
+    w = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = fold_bn(*[t.detach().float() for t in bn[:4]], bn[4], None if bias is None else bias.detach().float())
+    elif bias is not None:
+        shift = bias.detach().float()
+    w = _pad_rows(w)
+    cols = w.shape[0]
+    if scale is not None:
+        scale = _pad_rows(scale)
+    if shift is not None:
+        shift = _pad_rows(shift)
+    dev = lambda t: None if t is None else t.contiguous().to(device)
+    return PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act)
+
+
+def pack_stem(weight: torch.Tensor, bn, device="cuda") -> PackedConv:
+    """7x7 s2 p3 stem on NHWC4 input: [64,3,7,7] -> [64][7][8][4] (kw 7 and channel 3 are zero)."""
+    Cout = weight.shape[0]
+    w = weight.new_zeros(Cout, 7, 8, 4)
+    w[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
+    scale, shift = fold_bn(*[t.detach().float() for t in bn[:4]], bn[4])
+    return PackedConv(w.reshape(Cout, 224).contiguous().to(device), scale.contiguous().to(device),
+                      shift.contiguous().to(device), 7, 7, 2, 3, 4, Cout, 224, ACT_RELU, stem=True)
+
+
+def pack_linear(weight: torch.Tensor, bias=None, chw: Optional[Tuple[int, int, int]] = None, act=ACT_NONE,
+                device="cuda") -> PackedConv:
+    """nn.Linear weight [N, K].  chw=(C,H,W): the reference flattens NCHW (plane_head.py:76) while the
+    pooled / conv activations here are NHWC, so K is re-ordered (c,h,w) -> (h,w,c) once at load."""
+    N, K = weight.shape
+    w = weight.detach().float()
+    if chw is not None:
+        c, h, ww = chw
+        w = w.view(N, c, h, ww).permute(0, 2, 3, 1).reshape(N, K)
+    if K % 32:
+        raise ValueError("K % 32 != 0")
+    w = _pad_rows(w)
+    shift = None if bias is None else _pad_rows(bias.detach().float())
+    dev = lambda t: None if t is None else t.contiguous().to(device)
+    return PackedConv(dev(w), None, dev(shift), 1, 1, 1, 0, K, w.shape[0], K, act)
+
+
+def pack_deconv2x2(weight: torch.Tensor, bias, act=ACT_RELU, device="cuda") -> PackedConv:
+    """ConvTranspose2d(k=2, s=2) weight [Cin, Cout, 2, 2] -> GEMM columns (dy, dx, co)."""
+    Cin, Cout = weight.shape[:2]
+    w = weight.detach().float().permute(2, 3, 1, 0).reshape(4 * Cout, Cin)  # [(dy,dx,co), ci]
+    shift = bias.detach().float().repeat(4)
+    return PackedConv(w.contiguous().to(device), None, shift.contiguous().to(device), 1, 1, 1, 0, Cin, 4 * Cout, Cin,
+                      act, pixshuf=True)
+
+
+def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], device="cuda") -> PackedConv:
+    w = torch.cat([x.detach().float().reshape(x.shape[0], -1) for x in weights], 0)
+    b = torch.cat([x.detach().float() for x in biases], 0)
+    K = w.shape[1]
+    w = _pad_rows(w)
+    b = _pad_rows(b)
+    return PackedConv(w.contiguous().to(device), None, b.contiguous().to(device), 1, 1, 1, 0, K, w.shape[0], K, ACT_NONE)
+
+
+# --------------------------------------------------------------------------------------------------
+# kernels
+# --------------------------------------------------------------------------------------------------
+def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+           res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
+           m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
+    _req(x)
+    B, H, W, Cin = x.shape
+    Cin2 = 0
+    if x2 is not None:
+        _req(x2)
+        Cin2 = x2.shape[3]
+        assert x2.shape[:3] == x.shape[:3]
+    if not p.stem:
+        assert Cin + Cin2 == p.Cin, (Cin, Cin2, p.Cin)
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho = (Hl + 2 * p.pad - p.KH) // p.stride + 1
+    Wo = (Wl + 2 * p.pad - p.KW) // p.stride + 1
+    if out is None:
+        shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    d = _lib.ConvDesc()
+    d.x, d.x2, d.w, d.scale, d.shift, d.res, d.y = _p(x), _p(x2), _p(p.w), _p(p.scale), _p(p.shift), _p(res), _p(out)
+    d.B, d.H, d.W, d.Cin, d.Cin2 = B, H, W, Cin, Cin2
+    d.Ho, d.Wo, d.Cout = Ho, Wo, p.cols
+    d.KH, d.KW, d.stride, d.pad = p.KH, p.KW, p.stride, p.pad
+    d.Kpad, d.ups, d.act = p.Kpad, int(ups), p.act if act is None else act
+    d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), int(p.pixshuf), int(p.stem), int(splitk)
+    d.m_dev = _p(m_dev)
+    ws = None
+    if splitk > 1:
+        nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+        d.workspace = ws.data_ptr()
+    _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    return out
+
+
+def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk: int = 1,
+           m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, K] -> [M, cols]."""
+    M, K = x.shape
+    y = conv2d(x.view(M, 1, 1, K), p, act=act, splitk=splitk, m_dev=m_dev)
+    return y.view(M, p.cols)
+
+
+def choose_splitk(M: int, cols: int, K: int, target_blocks: int = 512) -> int:
+    tiles = max(1, math.ceil(M / 128)) * max(1, math.ceil(cols / 128))
+    chunks = K // 32
+    sk = max(1, min(target_blocks // tiles, chunks // 8))
+    return int(sk)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(t) for t in v])
+
+
+def preprocess_u8hwc(frames: torch.Tensor, mean, std) -> torch.Tensor:
+    _req(frames, torch.uint8)
+    B, H, W, _ = frames.shape
+    out = torch.empty((B, H, W, 4), device=frames.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_preprocess_u8hwc(frames.data_ptr(), out.data_ptr(), B, H, W, _f3(mean), _f3(std), _stream()),
+               "a3d_preprocess_u8hwc")
+    return out
+
+
+def preprocess_f32chw(images: torch.Tensor, mean, std) -> torch.Tensor:
+    _req(images)
+    B, _, H, W = images.shape
+    out = torch.empty((B, H, W, 4), device=images.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_preprocess_f32chw(images.data_ptr(), out.data_ptr(), B, H, W, _f3(mean), _f3(std), _stream()),
+               "a3d_preprocess_f32chw")
+    return out
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    _req(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_maxpool3x3s2_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, _stream()), "a3d_maxpool3x3s2_nhwc")
+    return out
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    _req(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_subsample2_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, _stream()), "a3d_subsample2_nhwc")
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
+    _req(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_resize_bilinear_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, Ho, Wo, _stream()),
+               "a3d_resize_bilinear_nhwc")
+    return out
+
+
+def conv3x3_to1(x: torch.Tensor, w: torch.Tensor, bias: float) -> torch.Tensor:
+    _req(x)
+    _req(w)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_conv3x3_to1_nhwc(x.data_ptr(), w.data_ptr(), float(bias), out.data_ptr(), B, H, W, Cc, _stream()),
+               "a3d_conv3x3_to1_nhwc")
+    return out
+
+
+def group_workspace(n_groups: int, device) -> torch.Tensor:
+    return torch.empty(_lib.lib().a3d_group_buffers_bytes(n_groups), device=device, dtype=torch.uint8)
+
+
+def rpn_proposals(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_anchors: torch.Tensor, img_hw, *,
+                  pre_topk: int, post_topk: int, nms_thresh: float, min_size: float, weights, scale_clamp: float):
+    """heads[l]: [B,Hf,Wf,CH] (objectness 0..A-1, deltas A..5A-1).  cell_anchors: CPU float32 [L,3,4].
+    -> boxes [B,post,4], logits [B,post], level [B,post] int32, pos [B,post] int32, count [B] int32."""
+    L = len(heads)
+    B = heads[0].shape[0]
+    dev = heads[0].device
+    d = _lib.RpnDesc()
+    for l, h in enumerate(heads):
+        _req(h)
+        d.head[l] = h.data_ptr()
+        d.Hf[l], d.Wf[l], d.stride[l] = h.shape[1], h.shape[2], int(strides[l])
+        for a in range(3):
+            for j in range(4):
+                d.cell_anchors[l][a][j] = float(cell_anchors[l, a, j])
+    d.B, d.L, d.A, d.CH = B, L, 3, heads[0].shape[3]
+    d.img_h, d.img_w = int(img_hw[0]), int(img_hw[1])
+    d.pre_topk, d.post_topk = int(pre_topk), int(post_topk)
+    d.nms_thresh, d.min_size = float(nms_thresh), float(min_size)
+    for j in range(4):
+        d.weights[j] = float(weights[j])
+    d.scale_clamp = float(scale_clamp)
+    ws = group_workspace(B * L, dev)
+    boxes = torch.empty((B, post_topk, 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((B, post_topk), device=dev, dtype=torch.float32)
+    level = torch.empty((B, post_topk), device=dev, dtype=torch.int32)
+    pos = torch.empty((B, post_topk), device=dev, dtype=torch.int32)
+    count = torch.empty((B,), device=dev, dtype=torch.int32)
+    d.workspace = ws.data_ptr()
+    d.out_boxes, d.out_scores, d.out_level, d.out_pos, d.out_count = (boxes.data_ptr(), scores.data_ptr(), level.data_ptr(),
+                                                                      pos.data_ptr(), count.data_ptr())
+    _lib.check(_lib.lib().a3d_rpn_proposals(C.byref(d), _stream()), "a3d_rpn_proposals")
+    return boxes, scores, level, pos, count
+
+
+def box_detections(pred: torch.Tensor, prop_boxes: torch.Tensor, prop_count: torch.Tensor, img_hw, *, num_classes: int,
+                   score_thresh: float, nms_thresh: float, topk: int, weights, scale_clamp: float):
+    """pred [B*R, CH] (cls logits 0..C, deltas C+1..), prop_boxes [B,R,4], prop_count [B] int32."""
+    _req(pred)
+    _req(prop_boxes)
+    _req(prop_count, torch.int32)
+    B, R, _ = prop_boxes.shape
+    dev = pred.device
+    d = _lib.BoxDetDesc()
+    d.pred, d.prop_boxes, d.prop_count = pred.data_ptr(), prop_boxes.data_ptr(), prop_count.data_ptr()
+    d.B, d.R, d.C, d.CH = B, R, int(num_classes), pred.shape[1]
+    d.img_h, d.img_w = int(img_hw[0]), int(img_hw[1])
+    d.score_thresh, d.nms_thresh, d.topk = float(score_thresh), float(nms_thresh), int(topk)
+    for j in range(4):
+        d.weights[j] = float(weights[j])
+    d.scale_clamp = float(scale_clamp)
+    ws = group_workspace(B * num_classes, dev)
+    boxes = torch.empty((B, topk, 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((B, topk), device=dev, dtype=torch.float32)
+    classes = torch.empty((B, topk), device=dev, dtype=torch.int32)
+    pos = torch.empty((B, topk), device=dev, dtype=torch.int32)
+    count = torch.empty((B,), device=dev, dtype=torch.int32)
+    d.workspace = ws.data_ptr()
+    d.out_boxes, d.out_scores, d.out_classes, d.out_pos, d.out_count = (boxes.data_ptr(), scores.data_ptr(),
+                                                                        classes.data_ptr(), pos.data_ptr(), count.data_ptr())
+    _lib.check(_lib.lib().a3d_box_detections(C.byref(d), _stream()), "a3d_box_detections")
+    return boxes, scores, classes, pos, count
+
+
+def group_nms(g_boxes: torch.Tensor, g_valid: torch.Tensor, g_n: torch.Tensor, thresh: float) -> torch.Tensor:
+    """g_boxes [G,1024,4] score-descending, g_valid [G,1024] int32, g_n [G] int32 -> keep [G,1024] int32."""
+    _req(g_boxes)
+    _req(g_valid, torch.int32)
+    _req(g_n, torch.int32)
+    G = g_boxes.shape[0]
+    assert g_boxes.shape[1] == GROUP_CAP
+    keep = torch.empty((G, GROUP_CAP), device=g_boxes.device, dtype=torch.int32)
+    _lib.check(_lib.lib().a3d_group_nms(g_boxes.data_ptr(), g_valid.data_ptr(), g_n.data_ptr(), keep.data_ptr(), G,
+                                        float(thresh), _stream()), "a3d_group_nms")
+    return keep
+
+
+def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor,
+                  count: Optional[torch.Tensor], P: int, sampling_ratio: int, aligned: bool, *,
+                  row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, want_level: bool = False):
+    """feats[l] NHWC [B,Hf,Wf,C]; boxes [B,R,4]; -> [rows, P, P, C] (rows = B*R unless compacted)."""
+    _req(boxes)
+    B, R, _ = boxes.shape
+    Cc = feats[0].shape[3]
+    dev = boxes.device
+    nrows = B * R if rows is None else rows
+    out = torch.zeros((nrows, P, P, Cc), device=dev, dtype=torch.float32)
+    lvl = torch.full((nrows,), -1, device=dev, dtype=torch.int32) if want_level else None
+    d = _lib.RoiAlignDesc()
+    for l, f in enumerate(feats):
+        _req(f)
+        d.feat[l] = f.data_ptr()
+        d.Hf[l], d.Wf[l] = f.shape[1], f.shape[2]
+        d.scale[l] = float(scales[l])
+    d.L, d.C = len(feats), Cc
+    d.boxes, d.count, d.row_offset = boxes.data_ptr(), _p(count), _p(row_offset)
+    d.B, d.R, d.P, d.sampling_ratio, d.aligned = B, R, int(P), int(sampling_ratio), int(bool(aligned))
+    d.out, d.out_level = out.data_ptr(), _p(lvl)
+    _lib.check(_lib.lib().a3d_roi_align_fpn(C.byref(d), _stream()), "a3d_roi_align_fpn")
+    return (out, lvl) if want_level else out
+
+
+def count_offsets(count: torch.Tensor, cap: int) -> torch.Tensor:
+    _req(count, torch.int32)
+    B = count.shape[0]
+    off = torch.empty((B + 1,), device=count.device, dtype=torch.int32)
+    _lib.check(_lib.lib().a3d_count_offsets(count.data_ptr(), off.data_ptr(), B, int(cap), _stream()), "a3d_count_offsets")
+    return off
+
+
+def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], norm_n: int = 0, sigmoid: bool = False,
+                 m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x)
+    _req(w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_linear_small(x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), M, _p(m_dev), K, N, int(norm_n),
+                                           int(sigmoid), _stream()), "a3d_linear_small")
+    return y
+
+
+def paste_lsq(boxes, scores, count, row_offset, mask_prob, normals, depth, img_hw, *, post_score_thresh=0.1,
+              mask_thresh=0.5, focal=571.623718, cx=319.5, cy=239.5, want_masks=True):
+    _req(boxes)
+    _req(scores)
+    B, R, _ = boxes.shape
+    H, W = int(img_hw[0]), int(img_hw[1])
+    dev = boxes.device
+    MS = mask_prob.shape[-1]
+    masks = torch.empty((B, R, H, W), device=dev, dtype=torch.uint8) if want_masks else None
+    planes = torch.empty((B, R, 3), device=dev, dtype=torch.float32)
+    area = torch.empty((B, R), device=dev, dtype=torch.int32)
+    keep = torch.empty((B, R), device=dev, dtype=torch.int32)
+    out_boxes = torch.empty((B, R, 4), device=dev, dtype=torch.float32)
+    d = _lib.PasteDesc()
+    d.boxes, d.scores, d.count, d.row_offset = boxes.data_ptr(), scores.data_ptr(), count.data_ptr(), row_offset.data_ptr()
+    d.mask_prob, d.normals, d.depth = mask_prob.data_ptr(), _p(normals), _p(depth)
+    d.B, d.R, d.MS, d.H, d.W = B, R, MS, H, W
+    d.post_score_thresh, d.mask_thresh = float(post_score_thresh), float(mask_thresh)
+    d.focal, d.cx, d.cy = float(focal), float(cx), float(cy)
+    d.masks, d.planes, d.area, d.keep, d.out_boxes = _p(masks), planes.data_ptr(), area.data_ptr(), keep.data_ptr(), out_boxes.data_ptr()
+    _lib.check(_lib.lib().a3d_paste_lsq(C.byref(d), _stream()), "a3d_paste_lsq")
+    return masks, planes, area, keep, out_boxes
+
+
+def record_floats(MS: int = 28) -> int:
+    return int(_lib.lib().a3d_record_floats(MS))
+
+
+def detections_pack(boxes, scores, classes, count, row_offset, keep, planes, rot_axis, tran_axis, mask_prob, MS=28):
+    B, R, _ = boxes.shape
+    dev = boxes.device
+    rec = record_floats(MS)
+    records = torch.empty((B, R, rec), device=dev, dtype=torch.float32)
+    rec_count = torch.empty((B,), device=dev, dtype=torch.int32)
+    d = _lib.PackDesc()
+    d.boxes, d.scores, d.classes, d.count = boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(), count.data_ptr()
+    d.row_offset, d.keep = row_offset.data_ptr(), keep.data_ptr()
+    d.planes, d.rot_axis, d.tran_axis, d.mask_prob = _p(planes), _p(rot_axis), _p(tran_axis), _p(mask_prob)
+    d.B, d.R, d.MS = B, R, MS
+    d.records, d.rec_count = records.data_ptr(), rec_count.data_ptr()
+    _lib.check(_lib.lib().a3d_detections_pack(C.byref(d), _stream()), "a3d_detections_pack")
+    return records, rec_count

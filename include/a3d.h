@@ -1,0 +1,241 @@
+/*
+ * a3d.h -- C ABI of liba3d_hip.so: the MI355X (gfx950) kernels of the PlaneRCNN per-frame
+ * detection path of Articulation3D.
+ *
+ * The reference is pure Python on top of detectron2 / torchvision / torch operators; it has no FFI
+ * of its own.  Each entry point below therefore names the reference call site (file:line under
+ * /root/reference/articulation3d/articulation3d/, "pkg/") whose operator it replaces.  A maintainer
+ * binds these with ctypes exactly as articulation3d_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host; no allocation inside; caller owns
+ *     all buffers, workspaces are sized by the *_workspace_bytes helpers;
+ *   - all activations are fp32 NHWC (channels innermost);
+ *   - stream-ordered on `stream` (a hipStream_t passed as void*), re-entrant, no global state;
+ *   - returns 0 (A3D_OK) or a negative error code; nothing is thrown.
+ */
+#ifndef A3D_H
+#define A3D_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3D_OK 0
+#define A3D_ERR_ARG (-1)
+#define A3D_ERR_LAUNCH (-2)
+#define A3D_ERR_UNSUPPORTED (-3)
+
+#define A3D_ACT_NONE 0
+#define A3D_ACT_RELU 1
+#define A3D_ACT_LEAKY 2 /* slope 0.01, pkg/modeling/depth_net/depth_head.py:36 */
+
+int a3d_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pre-processing.  Replaces PlaneRCNN.preprocess_image (pkg/modeling/meta_arch/planercnn.py:188-196)
+ * + the HWC->CHW float cast of PlaneRCNN_Branch.inference (pkg/utils/arti_vis.py:58).
+ * Output: [B,H,W,4] fp32, channel 3 = 0, value = (x - mean[c]) / std[c].
+ * ---------------------------------------------------------------------------------------------- */
+int a3d_preprocess_u8hwc(const uint8_t *frames /*[B,H,W,3]*/, float *out, int B, int H, int W,
+                         const float mean[3], const float std[3], void *stream);
+int a3d_preprocess_f32chw(const float *images /*[B,3,H,W]*/, float *out, int B, int H, int W,
+                          const float mean[3], const float std[3], void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused convolution / linear as an fp32-MFMA implicit GEMM.
+ * Replaces every Conv2d / Linear / ConvTranspose2d reached on the path:
+ *   backbone + FPN + RPN head (planercnn.py:150,168 -> detectron2), box head (roi_heads.py:186-187),
+ *   mask head (roi_heads.py:237), plane head (plane_head.py:71-80), axis head (axis_head.py:95-120),
+ *   depth head (depth_head.py:32-46,80-87).
+ *   y[m, n] = act( scale[n] * sum_k X[m, k] * w[n, k] + shift[n] + res[m, n] )
+ * m = (b, oh, ow); k = (kh, kw, c) with c running over source 0 then source 1 (channel concat).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_conv_desc {
+    const float *x;     /* source 0, NHWC [B,H,W,Cin]                                              */
+    const float *x2;    /* optional source 1 [B,H,W,Cin2] concatenated after source 0, or NULL     */
+    const float *w;     /* packed weights [Cout][Kpad], k = (kh*KW + kw)*(Cin+Cin2) + c            */
+    const float *scale; /* [Cout] or NULL (=1)   -- folded BatchNorm scale                         */
+    const float *shift; /* [Cout] or NULL (=0)   -- bias / folded BatchNorm shift                  */
+    const float *res;   /* residual [B,Ho,Wo,Cout] (or [B,Ho/2,Wo/2,Cout] when res_ups) or NULL    */
+    float *y;           /* [B,Ho,Wo,Cout]  (pixshuf: [B,2Ho,2Wo,Cout/4])                           */
+    float *workspace;   /* split-K partials, a3d_conv_workspace_bytes(); may be NULL if splitk==1  */
+    int B, H, W, Cin, Cin2;
+    int Ho, Wo, Cout; /* Cout % 4 == 0 */
+    int KH, KW, stride, pad;
+    int Kpad;    /* row length of w in floats, multiple of 32, >= KH*KW*(Cin+Cin2)                  */
+    int ups;     /* 1: the logical input is the nearest x2 upsampling of the sources (depth deconv) */
+    int act;     /* A3D_ACT_*                                                                       */
+    int res_ups; /* 1: residual is nearest x2 upsampled (FPN top-down add)                          */
+    int pixshuf; /* 1: ConvTranspose2d k2 s2 as GEMM with columns (dy,dx,co) scattered to 2x2 blocks */
+    int stem;    /* 1: x is [B,H,W,4] (a3d_preprocess_*), 7x7 s2 p3, w packed [Cout][7][8][4]        */
+    int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch            */
+    const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
+                         so ragged per-ROI batches need no host synchronisation                      */
+} a3d_conv_desc;
+
+size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
+int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
+
+/* Max-pool 3x3 stride 2 pad 1 (ResNet stem) and kernel-1 stride-2 pool (FPN LastLevelMaxPool = p6). */
+int a3d_maxpool3x3s2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);
+int a3d_subsample2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);
+
+/* Bilinear resize, align_corners=False (depth_head.py:82,88). */
+int a3d_resize_bilinear_nhwc(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, void *stream);
+
+/* 3x3 pad-1 convolution to ONE output channel (depth_head.py:68 depth_pred). w: [3][3][C], y: [B,H,W]. */
+int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, float *y, int B, int H, int W, int C,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RPN proposal selection.  Replaces detectron2 RPN.predict_proposals / find_top_rpn_proposals reached
+ * from planercnn.py:168 (anchor grid, Box2BoxTransform.apply_deltas, per-level top-k, clip, non-empty
+ * filter, batched_nms with level as category, first post_topk): SURVEY.md A.4-A.6.
+ * head[l]: [B, Hf, Wf, CH] fp32, channels [0,A) objectness logits, [A,5A) deltas (a*4+coord).
+ * Outputs are fixed-size: slots >= out_count[b] are zero boxes / level -1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_rpn_desc {
+    const float *head[5];
+    int Hf[5], Wf[5], stride[5];
+    float cell_anchors[5][3][4]; /* per level, per anchor: x1,y1,x2,y2 around (0,0) */
+    int B, L, A, CH;
+    int img_h, img_w;
+    int pre_topk, post_topk;
+    float nms_thresh, min_size;
+    float weights[4];
+    float scale_clamp;
+    void *workspace;    /* a3d_group_buffers_bytes(B*L) */
+    float *out_boxes;   /* [B, post_topk, 4] xyxy */
+    float *out_scores;  /* [B, post_topk] objectness logits */
+    int *out_level;     /* [B, post_topk] */
+    int *out_pos;       /* [B, post_topk] (level << 10) | rank-in-level : tie-break position */
+    int *out_count;     /* [B] */
+} a3d_rpn_desc;
+
+size_t a3d_group_buffers_bytes(int n_groups);
+int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fast R-CNN box inference.  Replaces FastRCNNOutputLayers.inference reached from
+ * pkg/modeling/roi_heads/roi_heads.py:206 (softmax, per-class apply_deltas, clip, score > thresh,
+ * batched_nms with class as category, first topk): SURVEY.md A.8.
+ * pred: [B*R, CH]: channels [0,C] class logits (C = background), [C+1, C+1+4C) per-class deltas.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_boxdet_desc {
+    const float *pred;
+    const float *prop_boxes; /* [B, R, 4] */
+    const int *prop_count;   /* [B] */
+    int B, R, C, CH;
+    int img_h, img_w;
+    float score_thresh, nms_thresh;
+    int topk;
+    float weights[4];
+    float scale_clamp;
+    void *workspace;   /* a3d_group_buffers_bytes(B*C) */
+    float *out_boxes;  /* [B, topk, 4] */
+    float *out_scores; /* [B, topk] */
+    int *out_classes;  /* [B, topk] (-1 in unused slots) */
+    int *out_pos;      /* [B, topk] proposal_row*C + class */
+    int *out_count;    /* [B] */
+} a3d_boxdet_desc;
+
+int a3d_box_detections(const a3d_boxdet_desc *d, void *stream);
+
+/* Greedy NMS over caller-sorted groups of <= 1024 boxes each (torchvision.ops.nms semantics, strict >).
+ * g_boxes [G,1024,4] score-descending, g_valid [G,1024], g_n [G] -> g_keep [G,1024]. */
+int a3d_group_nms(const float *g_boxes, const int *g_valid, const int *g_n, int *g_keep, int n_groups, float thresh,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ROIPooler: FPN level assignment + ROIAlign.  Replaces detectron2 ROIPooler / torchvision roi_align
+ * built at pkg/modeling/roi_heads/roi_heads.py:50-55,74-79 and called at :185,:236,:250,:268
+ * (SURVEY.md A.7).  feat[l]: NHWC [B,Hf,Wf,C]; boxes [B,R,4]; count[b] live boxes of image b (NULL = R).
+ * Output row of box (b, r) = (row_offset ? row_offset[b] : b*R) + r, layout [row, P, P, C].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_roialign_desc {
+    const float *feat[4];
+    int Hf[4], Wf[4];
+    float scale[4];
+    int L, C;
+    const float *boxes;
+    const int *count;
+    const int *row_offset;
+    int B, R;
+    int P, sampling_ratio, aligned;
+    float *out;
+    int *out_level; /* optional [rows] */
+} a3d_roialign_desc;
+
+int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);
+
+/* offsets[b] = sum_{i<b} min(count[i], cap); offsets[B] = total.  (compacts ragged per-image ROI lists) */
+int a3d_count_offsets(const int *count, int *offsets, int B, int cap, void *stream);
+
+/* Skinny output layer: y[m, 0:N] = x[m, :] . w[n, :] + bias[n], N <= 8, with the first norm_n outputs
+ * L2-normalised (F.normalize eps 1e-12) and/or sigmoid.  plane_head.py:80-82, axis_head.py:106-107,120,
+ * Mask R-CNN predictor + sigmoid (roi_heads.py:237). */
+int a3d_linear_small(const float *x, const float *w, const float *bias, float *y, int M, const int *m_dev, int K,
+                     int N, int norm_n, int sigmoid, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * detector_postprocess + paste_masks_in_image + override_depth fused.  Replaces
+ * pkg/modeling/postprocessing.py:47-69, pkg/layers/mask_ops.py:41-60,128-129 and
+ * pkg/utils/arti_vis.py:90-99,125-149.  One slot per (image b, detection r < R).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_paste_desc {
+    const float *boxes;      /* [B,R,4] pred_boxes */
+    const float *scores;     /* [B,R] */
+    const int *count;        /* [B] */
+    const int *row_offset;   /* [B] compact row of (b,0) in mask_prob / normals */
+    const float *mask_prob;  /* [rows, MS, MS] sigmoid mask probabilities */
+    const float *normals;    /* [rows, 3] pred_plane unit normals, or NULL */
+    const float *depth;      /* [B,H,W] or NULL */
+    int B, R, MS, H, W;
+    float post_score_thresh; /* 0.1, planercnn.py:217 */
+    float mask_thresh;       /* 0.5, MODEL.ROI_MASK_HEAD.MASK_THRESHOLD */
+    float focal, cx, cy;     /* 571.623718, 319.5, 239.5: arti_vis.py:101-104 */
+    unsigned char *masks;    /* [B,R,H,W] 0/1 or NULL (mask never materialised) */
+    float *planes;           /* [B,R,3] normal * offset (process()'s pred_plane) */
+    int *area;               /* [B,R] */
+    int *keep;               /* [B,R] survives score>=thresh and non-empty clip */
+    float *out_boxes;        /* [B,R,4] clipped */
+} a3d_paste_desc;
+
+int a3d_paste_lsq(const a3d_paste_desc *d, void *stream);
+
+/* Plane-offset least squares from dense masks of ONE image: PlaneRCNN_Branch.override_depth
+ * (pkg/utils/arti_vis.py:125-149).  depth [H,W], masks [D,H,W] (non-zero = inside), normals [D,3] -> out [D,3]. */
+int a3d_plane_offset_dense(const float *depth, const float *masks, const float *normals, float *out, int D, int H,
+                           int W, float focal, float cx, float cy, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fixed-size detection records = payload of the frame-sharded all-gather.  One record
+ * carries the fields create_instances() builds (pkg/utils/arti_vis.py:162-186):
+ *   [0:4] box xyxy  [4] score  [5] class  [6:9] plane normal*offset  [9:12] rot axis  [12:14] tran axis
+ *   [14:14+MS*MS] soft mask.   Kept detections of image b are compacted to records[b, 0:rec_count[b]].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct a3d_pack_desc {
+    const float *boxes;     /* [B,R,4] clipped boxes (a3d_paste_lsq out_boxes) */
+    const float *scores;    /* [B,R] */
+    const int *classes;     /* [B,R] */
+    const int *count;       /* [B] */
+    const int *row_offset;  /* [B] */
+    const int *keep;        /* [B,R] */
+    const float *planes;    /* [B,R,3] or NULL */
+    const float *rot_axis;  /* [rows,3] or NULL */
+    const float *tran_axis; /* [rows,2] or NULL */
+    const float *mask_prob; /* [rows,MS,MS] or NULL */
+    int B, R, MS;
+    float *records;         /* [B,R,a3d_record_floats(MS)] */
+    int *rec_count;         /* [B] */
+} a3d_pack_desc;
+
+int a3d_record_floats(int MS);
+int a3d_detections_pack(const a3d_pack_desc *d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
