@@ -83,10 +83,11 @@ class FastRCNNOutputLayers(nn.Module):
         """[rows, dim] -> [rows, 12]: class logits 0..2, per-class deltas 3..10, pad."""
         return ops.linear(x, self._fused.packed())
 
-    def inference_batched(self, pred, prop_boxes, prop_count, img_hw):
+    def inference_batched(self, pred, prop_boxes, prop_count, img_hw, return_groups=False):
         return ops.box_detections(pred, prop_boxes, prop_count, img_hw, num_classes=self.num_classes,
                                   score_thresh=self.test_score_thresh, nms_thresh=self.test_nms_thresh,
-                                  topk=self.test_topk_per_image, weights=self.box_weights, scale_clamp=SCALE_CLAMP)
+                                  topk=self.test_topk_per_image, weights=self.box_weights, scale_clamp=SCALE_CLAMP,
+                                  return_groups=return_groups)
 
 
 def build_box_head(cfg, input_shape):

@@ -100,13 +100,14 @@ class RPN(nn.Module):
         self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
         self.box_weights = tuple(cfg.MODEL.RPN.BBOX_REG_WEIGHTS)
 
-    def forward_batched(self, feats_nhwc: Dict[str, torch.Tensor], img_hw):
+    def forward_batched(self, feats_nhwc: Dict[str, torch.Tensor], img_hw, heads=None, return_groups=False):
         """Sync-free form: -> (boxes [B,K,4], logits [B,K], level, pos, count [B]) fixed-size device tensors."""
-        heads = self.rpn_head.forward_nhwc([feats_nhwc[f] for f in self.in_features])
+        if heads is None:
+            heads = self.rpn_head.forward_nhwc([feats_nhwc[f] for f in self.in_features])
         return ops.rpn_proposals(
             heads, self.strides, self.anchor_generator.cell_anchors, img_hw,
             pre_topk=self.pre_nms_topk[False], post_topk=self.post_nms_topk[False], nms_thresh=self.nms_thresh,
-            min_size=self.min_box_size, weights=self.box_weights, scale_clamp=SCALE_CLAMP)
+            min_size=self.min_box_size, weights=self.box_weights, scale_clamp=SCALE_CLAMP, return_groups=return_groups)
 
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances: Optional[list] = None):
         """Reference signature (planercnn.py:168): -> (list[Instances{proposal_boxes, objectness_logits}], {})."""

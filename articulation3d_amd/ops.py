@@ -258,8 +258,25 @@ def group_workspace(n_groups: int, device) -> torch.Tensor:
     return torch.empty(_lib.lib().a3d_group_buffers_bytes(n_groups), device=device, dtype=torch.uint8)
 
 
+def carve_group_workspace(ws: torch.Tensor, G: int) -> dict:
+    """Views of the selection workspace (layout of `carve()` in csrc/proposals.hip): per group the
+    score-sorted candidate boxes, scores, tie-break positions, validity and NMS keep flags.  Test hook."""
+    cap = GROUP_CAP
+    o = 0
+    out = {}
+    for name, width, dt in (("boxes", 16, torch.float32), ("scores", 4, torch.float32), ("pos", 4, torch.int32),
+                            ("valid", 4, torch.int32), ("keep", 4, torch.int32)):
+        nbytes = G * cap * width
+        t = ws[o:o + nbytes].view(dt)
+        out[name] = t.view(G, cap, 4) if name == "boxes" else t.view(G, cap)
+        o += nbytes
+    out["n"] = ws[o:o + G * 4].view(torch.int32)
+    return out
+
+
 def rpn_proposals(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_anchors: torch.Tensor, img_hw, *,
-                  pre_topk: int, post_topk: int, nms_thresh: float, min_size: float, weights, scale_clamp: float):
+                  pre_topk: int, post_topk: int, nms_thresh: float, min_size: float, weights, scale_clamp: float,
+                  return_groups: bool = False):
     """heads[l]: [B,Hf,Wf,CH] (objectness 0..A-1, deltas A..5A-1).  cell_anchors: CPU float32 [L,3,4].
     -> boxes [B,post,4], logits [B,post], level [B,post] int32, pos [B,post] int32, count [B] int32."""
     L = len(heads)
@@ -290,11 +307,14 @@ def rpn_proposals(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_an
     d.out_boxes, d.out_scores, d.out_level, d.out_pos, d.out_count = (boxes.data_ptr(), scores.data_ptr(), level.data_ptr(),
                                                                       pos.data_ptr(), count.data_ptr())
     _lib.check(_lib.lib().a3d_rpn_proposals(C.byref(d), _stream()), "a3d_rpn_proposals")
+    if return_groups:
+        return boxes, scores, level, pos, count, carve_group_workspace(ws, B * L)
     return boxes, scores, level, pos, count
 
 
 def box_detections(pred: torch.Tensor, prop_boxes: torch.Tensor, prop_count: torch.Tensor, img_hw, *, num_classes: int,
-                   score_thresh: float, nms_thresh: float, topk: int, weights, scale_clamp: float):
+                   score_thresh: float, nms_thresh: float, topk: int, weights, scale_clamp: float,
+                   return_groups: bool = False):
     """pred [B*R, CH] (cls logits 0..C, deltas C+1..), prop_boxes [B,R,4], prop_count [B] int32."""
     _req(pred)
     _req(prop_boxes)
@@ -319,6 +339,8 @@ def box_detections(pred: torch.Tensor, prop_boxes: torch.Tensor, prop_count: tor
     d.out_boxes, d.out_scores, d.out_classes, d.out_pos, d.out_count = (boxes.data_ptr(), scores.data_ptr(),
                                                                         classes.data_ptr(), pos.data_ptr(), count.data_ptr())
     _lib.check(_lib.lib().a3d_box_detections(C.byref(d), _stream()), "a3d_box_detections")
+    if return_groups:
+        return boxes, scores, classes, pos, count, carve_group_workspace(ws, B * num_classes)
     return boxes, scores, classes, pos, count
 
 

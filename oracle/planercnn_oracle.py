@@ -468,39 +468,46 @@ def clip_boxes(b, h, w):
     return b
 
 
+def rpn_select_level(logits_l, deltas_l, Hf, Wf, stride, size, cfg: OracleCfg, image_size):
+    """One (image, level): top-k (stable), decode, clip, validity.  logits_l [HWA], deltas_l [HWA,4].
+    -> idx [k] (anchor index), scores [k], boxes [k,4] clipped, valid [k] bool."""
+    anc = grid_anchors(Hf, Wf, stride, size, cfg.anchor_ratios)
+    k = min(cfg.rpn_pre_topk, logits_l.shape[0])
+    sc, idx = topk_stable(logits_l, k)
+    b = apply_deltas(deltas_l[idx], anc[idx], cfg.rpn_weights, cfg.scale_clamp)
+    fin = torch.isfinite(b).all(1) & torch.isfinite(sc)
+    bc = clip_boxes(b, image_size[0], image_size[1])
+    ne = ((bc[:, 2] - bc[:, 0]) > cfg.rpn_min_size) & ((bc[:, 3] - bc[:, 1]) > cfg.rpn_min_size)
+    return idx, sc, bc, fin & ne
+
+
+def rpn_select(logits, deltas, feat_hw, image_sizes, cfg: OracleCfg, return_groups=False):
+    """find_top_rpn_proposals (A.5) on given head outputs.  logits[l] [N,HWA], deltas[l] [N,HWA,4]."""
+    names = ("p2", "p3", "p4", "p5", "p6")
+    N = logits[0].shape[0]
+    out, groups = [], []
+    for n in range(N):
+        bs, ss, ls, gl = [], [], [], []
+        for li, name in enumerate(names[: len(logits)]):
+            Hf, Wf = feat_hw[li]
+            idx, sc, bc, valid = rpn_select_level(logits[li][n], deltas[li][n], Hf, Wf, FPN_STRIDES[name],
+                                                  cfg.anchor_sizes[li], cfg, image_sizes[n])
+            gl.append(dict(idx=idx, scores=sc, boxes=bc, valid=valid))
+            bs.append(bc[valid])
+            ss.append(sc[valid])
+            ls.append(torch.full((int(valid.sum()),), li, dtype=torch.int64))
+        b, s_, l = torch.cat(bs), torch.cat(ss), torch.cat(ls)
+        keep = batched_nms(b, s_, l, cfg.rpn_nms_thresh)[: cfg.rpn_post_topk]
+        out.append((b[keep], s_[keep]))
+        groups.append(gl)
+    return (out, groups) if return_groups else out
+
+
 def rpn_proposals(feats, P, image_sizes, cfg: OracleCfg):
     """-> list per image of (proposal_boxes Rx4, objectness_logits R)."""
     logits, deltas = rpn_head(feats, P)
     names = ("p2", "p3", "p4", "p5", "p6")
-    N = logits[0].shape[0]
-    top_boxes, top_scores, lvl_ids = [], [], []
-    for li, name in enumerate(names):
-        Hf, Wf = feats[name].shape[-2:]
-        anc = grid_anchors(Hf, Wf, FPN_STRIDES[name], cfg.anchor_sizes[li], cfg.anchor_ratios)
-        k = min(cfg.rpn_pre_topk, logits[li].shape[1])
-        sc, idx = topk_stable(logits[li], k)
-        props = []
-        for n in range(N):
-            d = deltas[li][n][idx[n]]
-            props.append(apply_deltas(d, anc[idx[n]], cfg.rpn_weights, cfg.scale_clamp))
-        top_boxes.append(torch.stack(props))
-        top_scores.append(sc)
-        lvl_ids.append(torch.full((k,), li, dtype=torch.int64))
-    top_boxes = torch.cat(top_boxes, 1)
-    top_scores = torch.cat(top_scores, 1)
-    lvl_ids = torch.cat(lvl_ids)
-    out = []
-    for n in range(N):
-        h, w = image_sizes[n]
-        b, s, l = top_boxes[n], top_scores[n], lvl_ids
-        valid = torch.isfinite(b).all(1) & torch.isfinite(s)
-        b, s, l = b[valid], s[valid], l[valid]
-        b = clip_boxes(b, h, w)
-        ne = ((b[:, 2] - b[:, 0]) > cfg.rpn_min_size) & ((b[:, 3] - b[:, 1]) > cfg.rpn_min_size)
-        b, s, l = b[ne], s[ne], l[ne]
-        keep = batched_nms(b, s, l, cfg.rpn_nms_thresh)[: cfg.rpn_post_topk]
-        out.append((b[keep], s[keep]))
-    return out
+    return rpn_select(logits, deltas, [tuple(feats[n].shape[-2:]) for n in names], image_sizes, cfg)
 
 
 # --------------------------------------------------------------------------------------

@@ -121,6 +121,20 @@ def stage_conv():
     return ok
 
 
+def _merge_expected(g, g0, ng, K):
+    """Expected merge_topk output from the group buffers (CPU): kept entries by (score desc, pos asc)."""
+    items = []
+    for gl in range(ng):
+        n = int(g["n"][g0 + gl])
+        keep = g["keep"][g0 + gl, :n].bool()
+        for r in keep.nonzero().squeeze(1).tolist():
+            items.append((-float(g["scores"][g0 + gl, r]), int(g["pos"][g0 + gl, r]), gl, r))
+    items.sort(key=lambda t: (t[0], t[1]))
+    items = items[:K]
+    boxes = torch.stack([g["boxes"][g0 + gl, r] for _, _, gl, r in items]) if items else torch.zeros(0, 4)
+    return boxes, [it[2] for it in items]
+
+
 def stage_model(nframes=2, thresh=0.0):
     from oracle import planercnn_oracle as O
     from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
@@ -138,60 +152,145 @@ def stage_model(nframes=2, thresh=0.0):
     assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
     frames = O.synthetic_frames(nframes)
     ocfg = O.OracleCfg(score_thresh=thresh)
-    t0 = time.time()
-    outs, aux = O.detect(O.frames_to_chw(frames), P, ocfg, return_aux=True)
-    print(f"oracle detect {time.time() - t0:.1f}s D={[len(o['scores']) for o in outs]}", flush=True)
-    fr = torch.from_numpy(frames).to(dev)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    out = model.inference_batched(fr, want_masks=True)
-    torch.cuda.synchronize()
-    print(f"hip detect (cold) {time.time() - t0:.2f}s", flush=True)
+    sizes = [(480, 640)] * nframes
     ok = True
-    # features
+    fr = torch.from_numpy(frames).to(dev)
+
+    # ---- S1 continuous: backbone / RPN head / depth, end to end vs the CPU oracle
+    x, _ = O.preprocess(O.frames_to_chw(frames), ocfg)
+    ofeats = O.backbone(x, P)
     x4 = ops.preprocess_u8hwc(fr, model.pixel_mean, model.pixel_std)
+    ok &= check("preprocess", x4[..., :3].permute(0, 3, 1, 2), x, 1e-7)
     feats = model.backbone.forward_nhwc(x4)
-    for k in ("p2", "p3", "p4", "p5", "p6"):
-        ok &= check(f"feat {k}", feats[k].permute(0, 3, 1, 2), aux["features"][k], 1e-4)
-    # proposals
-    pb, pl, plv, ppos, pc = out.proposals
+    names = ("p2", "p3", "p4", "p5", "p6")
+    for k in names:
+        ok &= check(f"feat {k}", feats[k].permute(0, 3, 1, 2), ofeats[k], 2e-4)
+    rpn = model.proposal_generator
+    heads = rpn.rpn_head.forward_nhwc([feats[f] for f in rpn.in_features])
+    ol, od = O.rpn_head(ofeats, P)
+    for l in range(5):
+        ok &= check(f"rpn logits L{l}", heads[l][..., :3].reshape(nframes, -1), ol[l], 2e-4)
+        ok &= check(f"rpn deltas L{l}", heads[l][..., 3:15].reshape(nframes, -1, 4), od[l], 2e-4)
+    depth = model.depth_head.forward_nhwc(feats)
+    ok &= check("depth e2e", depth, O.depth_head(ofeats, P), 5e-4)
+    gfeats = {k: feats[k].permute(0, 3, 1, 2).contiguous().cpu() for k in names}  # GPU features as oracle input
+    ok &= check("depth | same feats", depth, O.depth_head(gfeats, P), 2e-5)
+
+    # ---- S2 discrete: proposal selection on IDENTICAL head outputs
+    gl_ = [h[..., :3].reshape(nframes, -1).cpu() for h in heads]
+    gd_ = [h[..., 3:15].reshape(nframes, -1, 4).cpu() for h in heads]
+    feat_hw = [tuple(feats[k].shape[1:3]) for k in names]
+    oprops, ogroups = O.rpn_select(gl_, gd_, feat_hw, sizes, ocfg, return_groups=True)
+    pb, pl, plv, ppos, pc, g = rpn.forward_batched(feats, (480, 640), heads=heads, return_groups=True)
+    g = {k: v.cpu() for k, v in g.items()}
     for b in range(nframes):
-        ob, osc = aux["proposals"][b]
+        for l in range(5):
+            gi = b * 5 + l
+            og = ogroups[b][l]
+            k = len(og["scores"])
+            same = int(g["n"][gi]) == k and torch.equal(g["scores"][gi, :k], og["scores"])
+            eb = (g["boxes"][gi, :k] - og["boxes"]).abs().max().item()
+            sv = torch.equal(g["valid"][gi, :k].bool(), og["valid"])
+            v = g["valid"][gi, :k].bool()
+            okeep = torch.zeros(k, dtype=torch.bool)
+            okeep[v] = O.nms_sorted(g["boxes"][gi, :k][v], torch.zeros(int(v.sum()), dtype=torch.int64), ocfg.rpn_nms_thresh)
+            sk = torch.equal(g["keep"][gi, :k].bool(), okeep)
+            good = same and eb < 2e-3 and sv and sk
+            print(f"{'OK ' if good else 'BAD'} rpn group b{b} L{l}: k={k} topk_scores_bitexact={same} box_abs_err={eb:.2e} valid_eq={sv} keep_bitexact={sk} kept={int(okeep.sum())}", flush=True)
+            ok &= good
+        eb_, _ = _merge_expected(g, b * 5, 5, 1000)
         n = int(pc[b])
-        same_n = n == len(ob)
-        if same_n:
-            e = (pb[b, :n].cpu() - ob).abs().max().item()
-            es = (pl[b, :n].cpu() - osc).abs().max().item()
-        else:
-            e = es = float("nan")
-        print(f"{'OK ' if same_n and e < 1e-2 else 'BAD'} proposals[{b}] n={n} vs {len(ob)} box_abs_err={e:.3e} logit_err={es:.3e}")
-        ok &= same_n and e < 1e-2
-    # depth
-    ok &= check("depth", out.depth, torch.stack([o["depth"] for o in outs]), 1e-4)
-    # detections
-    det = out.det
-    for b in range(nframes):
-        o = outs[b]
-        n = int(det.count[b])
-        keep = out.keep[b, :n].bool().cpu()
-        nk = int(keep.sum())
-        good = nk == len(o["scores"])
-        msg = f"det[{b}] raw={n} kept={nk} vs oracle {len(o['scores'])}"
-        if good and nk:
-            idx = keep.nonzero().squeeze(1)
-            eb = (out.boxes[b, idx].cpu() - o["pred_boxes"]).abs().max().item()
-            es = (det.scores[b, idx].cpu() - o["scores"]).abs().max().item()
-            ec = (det.classes[b, idx].cpu().long() != o["pred_classes"]).sum().item()
-            rows = (det.row_offset[b].item() + idx)
-            epl = (det.pred_plane[rows].cpu() - o["pred_plane"]).abs().max().item()
-            era = (det.pred_rot_axis[rows].cpu() - o["pred_rot_axis"]).abs().max().item()
-            eta = (det.pred_tran_axis[rows].cpu() - o["pred_tran_axis"]).abs().max().item()
-            mm = (out.masks[b, idx].cpu().bool() != o["pred_masks"]).sum().item()
-            epo = ((out.planes[b, idx].cpu() - o["plane_offset"]).abs().max() / (o["plane_offset"].abs().max() + 1e-12)).item()
-            msg += f" box={eb:.2e} score={es:.2e} cls_mismatch={ec} plane={epl:.2e} rot={era:.2e} tran={eta:.2e} mask_px_mismatch={mm} plane_off_rel={epo:.2e}"
-            good = eb < 1e-2 and es < 1e-4 and ec == 0 and epl < 1e-4 and era < 1e-3 and eta < 1e-4 and epo < 1e-3
-        print(("OK  " if good else "BAD ") + msg, flush=True)
+        good = n == len(eb_) and torch.equal(pb[b, :n].cpu(), eb_)
+        ob = oprops[b][0]
+        loose = (n == len(ob)) and (pb[b, :n].cpu() - ob).abs().max().item()
+        print(f"{'OK ' if good else 'BAD'} rpn merge b{b}: n={n} exact_vs_expected={good}; vs full CPU selection: n_oracle={len(ob)} max_box_diff={loose}", flush=True)
         ok &= good
+
+    # ---- S3 box stage on IDENTICAL features + proposals
+    rh = model.roi_heads
+    lv = [feats[f] for f in rh.box_in_features]
+    pooled = rh.box_pooler.forward_batched(lv, pb, pc)
+    props_cpu = [pb[b, : int(pc[b])].cpu() for b in range(nframes)]
+    opooled = O.roi_pool_fpn(gfeats, props_cpu, *ocfg.box_pool)
+    R = pb.shape[1]
+    gp = torch.cat([pooled[b * R: b * R + int(pc[b])] for b in range(nframes)]).permute(0, 3, 1, 2)
+    ok &= check("box ROIAlign 7x7 | same feats", gp, opooled, 1e-5)
+    fc = rh.box_head(pooled)
+    pred = rh.box_predictor(fc)
+    ofc = O.box_head(opooled, P)
+    ocls, odl = O.box_predictor(ofc, P)
+    gpred = torch.cat([pred[b * R: b * R + int(pc[b])] for b in range(nframes)])
+    ok &= check("box cls logits", gpred[:, :3], ocls, 1e-4)
+    ok &= check("box deltas", gpred[:, 3:11], odl, 1e-4)
+    db, dsc, dcl, dpos, dcnt, g2 = rh.box_predictor.inference_batched(pred, pb, pc, (480, 640), return_groups=True)
+    g2 = {k: v.cpu() for k, v in g2.items()}
+    for b in range(nframes):
+        n = int(pc[b])
+        pr = pred[b * R: b * R + n].cpu()
+        dec = O.apply_deltas(pr[:, 3:11], props_cpu[b], ocfg.box_weights, ocfg.scale_clamp)
+        probs = F.softmax(pr[:, :3], dim=-1)
+        ob_, os_, oc_, _rows = O.fast_rcnn_inference_single(dec, probs, (480, 640), ocfg)
+        eb_, ecat = _merge_expected(g2, b * 2, 2, 100)
+        nd = int(dcnt[b])
+        exact = nd == len(eb_) and torch.equal(db[b, :nd].cpu(), eb_) and dcl[b, :nd].cpu().tolist() == ecat
+        same_n = nd == len(ob_)
+        ebx = (db[b, :nd].cpu() - ob_).abs().max().item() if same_n and nd else 0.0
+        esc = (dsc[b, :nd].cpu() - os_).abs().max().item() if same_n and nd else 0.0
+        ecl = (dcl[b, :nd].cpu().long() != oc_).sum().item() if same_n and nd else 0
+        good = exact and same_n and ebx < 2e-3 and esc < 1e-6 and ecl == 0
+        print(f"{'OK ' if good else 'BAD'} box det b{b}: D={nd} (oracle {len(ob_)}) merge_exact={exact} box_err={ebx:.2e} score_err={esc:.2e} class_mismatch={ecl}", flush=True)
+        ok &= good
+        for c in range(2):
+            gi = b * 2 + c
+            k = int(g2["n"][gi])
+            v = g2["valid"][gi, :k].bool()
+            okeep = torch.zeros(k, dtype=torch.bool)
+            okeep[v] = O.nms_sorted(g2["boxes"][gi, :k][v], torch.zeros(int(v.sum()), dtype=torch.int64), ocfg.nms_thresh)
+            sk = torch.equal(g2["keep"][gi, :k].bool(), okeep)
+            print(f"{'OK ' if sk else 'BAD'} box nms b{b} c{c}: n={k} keep_bitexact={sk} kept={int(okeep.sum())}", flush=True)
+            ok &= sk
+
+    # ---- S4 per-ROI heads on IDENTICAL features + detection boxes
+    from articulation3d_amd.modeling.roi_heads.roi_heads import BatchedDetections
+    det = BatchedDetections(db, dsc, dcl, dcnt, (480, 640))
+    det = rh.given_boxes_batched(feats, det)
+    dets_cpu = [db[b, : int(dcnt[b])].cpu() for b in range(nframes)]
+    if det.total:
+        om = O.mask_head(O.roi_pool_fpn(gfeats, dets_cpu, *ocfg.mask_pool), P)
+        ok &= check("mask probs", det.mask_prob[:, None], om, 1e-4)
+        opl = O.plane_head(O.roi_pool_fpn(gfeats, dets_cpu, *ocfg.plane_pool), P)
+        ok &= check("pred_plane", det.pred_plane, opl, 1e-4)
+        ora, ota = O.axis_head(O.roi_pool_fpn(gfeats, dets_cpu, *ocfg.axis_pool), P)
+        ok &= check("pred_rot_axis", det.pred_rot_axis, ora, 1e-4)
+        ok &= check("pred_tran_axis", det.pred_tran_axis, ota, 1e-4)
+    # ---- S5 post-process, paste, plane offset on IDENTICAL head outputs
+    out = model._post_batched(det, depth, (480, 640), True, None)
+    rays = O.k_inv_dot_xy1()
+    for b in range(nframes):
+        nd = int(dcnt[b])
+        if nd == 0:
+            print(f"OK  post b{b}: no detections")
+            continue
+        r0 = int(det.row_offset[b])
+        d = dict(pred_boxes=db[b, :nd].cpu(), scores=dsc[b, :nd].cpu(), pred_classes=dcl[b, :nd].cpu().long(),
+                 pred_masks=det.mask_prob[r0: r0 + nd, None].cpu(), pred_plane=det.pred_plane[r0: r0 + nd].cpu(), image_size=(480, 640))
+        o = O.detector_postprocess(d, 480, 640, ocfg)
+        keep = out.keep[b, :nd].bool().cpu()
+        idx = keep.nonzero().squeeze(1)
+        same = int(keep.sum()) == len(o["scores"])
+        mm = (out.masks[b, idx].cpu().bool() != o["pred_masks"]).sum().item() if same else -1
+        opo = O.override_depth(depth[b].cpu(), o["pred_masks"], o["pred_plane"], rays)
+        epo = ((out.planes[b, idx].cpu() - opo).abs().max() / (opo.abs().max() + 1e-12)).item() if same else -1
+        rc = int(out.rec_count[b])
+        good = same and mm == 0 and epo < 1e-4 and rc == len(idx)
+        print(f"{'OK ' if good else 'BAD'} post b{b}: kept={int(keep.sum())} (oracle {len(o['scores'])}) mask_px_mismatch={mm} of {len(idx) * 480 * 640} plane_offset_rel_err={epo:.2e} rec_count={rc}", flush=True)
+        ok &= good
+    # ---- whole path timing
+    torch.cuda.synchronize()
+    t0 = time.time()
+    model.inference_batched(fr)
+    torch.cuda.synchronize()
+    print(f"hip inference_batched B={nframes}: {1e3 * (time.time() - t0):.1f} ms", flush=True)
     return ok
 
 
