@@ -80,7 +80,7 @@ class PasteDesc(C.Structure):
         ("normals", fptr), ("depth", fptr),
         ("B", C.c_int), ("R", C.c_int), ("MS", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("post_score_thresh", C.c_float), ("mask_thresh", C.c_float),
-        ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("clip_boxes", C.c_int),
         ("masks", fptr), ("planes", fptr), ("area", fptr), ("keep", fptr), ("out_boxes", fptr),
     ]
 
@@ -130,6 +130,11 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP kernel library has not been built. "
                 "Run `python -m articulation3d_amd.build` (or __graft_entry__.build()). There is no CPU fallback."
             )
+        # torch ships its own ROCm runtime (torch/lib/libamdhip64.so).  It must be the HIP runtime of the process:
+        # if this library were loaded first it would pull in the system libamdhip64 and the two runtimes would not
+        # share streams / code objects (every launch then fails).  Import torch before dlopen.
+        import torch  # noqa: F401
+
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

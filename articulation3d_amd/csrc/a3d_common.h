@@ -13,6 +13,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hipGetLastError() is per-thread and also reports non-sticky codes left behind by OTHER users of the
+// runtime in this thread (e.g. hipErrorNotReady from an event query of the host framework).  Every entry
+// point therefore clears the slot before its first launch (a3d_begin) and reads it after its last.
+static inline void a3d_begin() { (void)hipGetLastError(); }
 static inline int a3d_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? A3D_OK : A3D_ERR_LAUNCH;

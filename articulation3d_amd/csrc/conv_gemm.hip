@@ -310,6 +310,7 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
     const int rc = conv_check(d);
     if (rc != A3D_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    a3d_begin();
     if (d->stem) return launch_cfg<4, 1, 2, 2, true>(d, s);
     if (d->Cout <= 32) return launch_cfg<4, 1, 1, 1, false>(d, s);
     if (d->Cout <= 64) return launch_cfg<4, 1, 2, 2, false>(d, s);

@@ -58,6 +58,7 @@ extern "C" int a3d_linear_small(const float *x, const float *w, const float *bia
     if (M == 0) return A3D_OK;
     int blocks = (M + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    a3d_begin();
     hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, m_dev, K,
                        N, norm_n, sigmoid ? 3 : 0);
     return a3d_check_launch();
@@ -77,6 +78,7 @@ struct PasteArgs {
     int B, R, MS, H, W;
     float post_score_thresh, mask_thresh;
     float fx, cx, cy;       // rays: ((x - cx)/fx, (y - cy)/fx, 1), arti_vis.py:101-123
+    int clip;
     unsigned char *masks;   // [B, R, H, W] or NULL
     float *planes;          // [B, R, 3]  normal * offset in the reference's output axes
     int *area;              // [B, R] mask pixel count
@@ -96,11 +98,14 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
     if (live) {
         const float *bx = a.boxes + (size_t)slot * 4;
         // output size == input size on this path (planercnn.py:213-214): scale 1, then clip
-        x0 = fminf(fmaxf(bx[0], 0.f), (float)a.W);
-        y0 = fminf(fmaxf(bx[1], 0.f), (float)a.H);
-        x1 = fminf(fmaxf(bx[2], 0.f), (float)a.W);
-        y1 = fminf(fmaxf(bx[3], 0.f), (float)a.H);
-        live = a.scores[slot] >= a.post_score_thresh && (x1 - x0) > 0.f && (y1 - y0) > 0.f;
+        x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+        if (a.clip) {
+            x0 = fminf(fmaxf(x0, 0.f), (float)a.W);
+            y0 = fminf(fmaxf(y0, 0.f), (float)a.H);
+            x1 = fminf(fmaxf(x1, 0.f), (float)a.W);
+            y1 = fminf(fmaxf(y1, 0.f), (float)a.H);
+            live = a.scores[slot] >= a.post_score_thresh && (x1 - x0) > 0.f && (y1 - y0) > 0.f;
+        }
     }
     if (threadIdx.x == 0) {
         a.keep[slot] = live ? 1 : 0;
@@ -258,11 +263,13 @@ extern "C" int a3d_paste_lsq(const a3d_paste_desc *d, void *stream) {
     a.fx = d->focal;
     a.cx = d->cx;
     a.cy = d->cy;
+    a.clip = d->clip_boxes;
     a.masks = d->masks;
     a.planes = d->planes;
     a.area = d->area;
     a.keep = d->keep;
     a.out_boxes = d->out_boxes;
+    a3d_begin();
     hipLaunchKernelGGL(paste_lsq_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
@@ -326,6 +333,7 @@ extern "C" int a3d_plane_offset_dense(const float *depth, const float *masks, co
                                       int H, int W, float focal, float cx, float cy, void *stream) {
     if (!depth || !masks || !normals || !out || D < 0) return A3D_ERR_ARG;
     if (D == 0) return A3D_OK;
+    a3d_begin();
     hipLaunchKernelGGL(plane_offset_dense_kernel, dim3(D), dim3(256), 0, (hipStream_t)stream, depth, masks, normals, out,
                        H, W, focal, cx, cy);
     return a3d_check_launch();

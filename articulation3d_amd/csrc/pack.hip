@@ -81,6 +81,7 @@ extern "C" int a3d_detections_pack(const a3d_pack_desc *d, void *stream) {
     a.MS = d->MS;
     a.records = d->records;
     a.rec_count = d->rec_count;
+    a3d_begin();
     hipLaunchKernelGGL(pack_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }

@@ -447,6 +447,7 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     a.g_pos = gb.pos;
     a.g_valid = gb.valid;
     a.g_n = gb.n;
+    a3d_begin();
     hipLaunchKernelGGL(rpn_select_kernel, dim3(d->L, d->B), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->L,
@@ -483,6 +484,7 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
     a.g_pos = gb.pos;
     a.g_valid = gb.valid;
     a.g_n = gb.n;
+    a3d_begin();
     hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
@@ -494,6 +496,7 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
 extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int *g_n, int *g_keep, int n_groups,
                              float thresh, void *stream) {
     if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
+    a3d_begin();
     hipLaunchKernelGGL(group_nms_kernel, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
                        g_keep, thresh);
     return a3d_check_launch();

@@ -115,6 +115,7 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     a.aligned = d->aligned;
     a.out = d->out;
     a.out_level = d->out_level;
+    a3d_begin();
     hipLaunchKernelGGL(roi_align_fpn_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
@@ -133,6 +134,7 @@ __global__ void count_offsets_kernel(const int *count, int *offsets, int B, int 
 
 extern "C" int a3d_count_offsets(const int *count, int *offsets, int B, int cap, void *stream) {
     if (!count || !offsets || B <= 0) return A3D_ERR_ARG;
+    a3d_begin();
     hipLaunchKernelGGL(count_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, offsets, B, cap);
     return a3d_check_launch();
 }

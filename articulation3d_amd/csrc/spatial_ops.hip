@@ -36,6 +36,7 @@ extern "C" int a3d_preprocess_u8hwc(const uint8_t *frames, float *out, int B, in
                                     const float std[3], void *stream) {
     if (!frames || !out || B <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
     const size_t npix = (size_t)B * H * W;
+    a3d_begin();
     hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, frames, out, npix,
                        mean[0], mean[1], mean[2], std[0], std[1], std[2]);
     return a3d_check_launch();
@@ -45,6 +46,7 @@ extern "C" int a3d_preprocess_f32chw(const float *images, float *out, int B, int
                                      const float std[3], void *stream) {
     if (!images || !out || B <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
     const size_t hw = (size_t)H * W;
+    a3d_begin();
     hipLaunchKernelGGL(preprocess_chw_kernel, dim3(grid_for(hw * B)), dim3(256), 0, (hipStream_t)stream, images, out, B,
                        hw, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
     return a3d_check_launch();
@@ -80,6 +82,7 @@ extern "C" int a3d_maxpool3x3s2_nhwc(const float *x, float *y, int B, int H, int
     if (!x || !y || (C & 3) || B <= 0) return A3D_ERR_ARG;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    a3d_begin();
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W,
                        C / 4, Ho, Wo);
     return a3d_check_launch();
@@ -105,6 +108,7 @@ extern "C" int a3d_subsample2_nhwc(const float *x, float *y, int B, int H, int W
     if (!x || !y || (C & 3) || B <= 0) return A3D_ERR_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    a3d_begin();
     hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4,
                        Ho, Wo);
     return a3d_check_launch();
@@ -150,6 +154,7 @@ extern "C" int a3d_resize_bilinear_nhwc(const float *x, float *y, int B, int H, 
                                         void *stream) {
     if (!x || !y || B <= 0 || C <= 0) return A3D_ERR_ARG;
     const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    a3d_begin();
     if ((C & 3) == 0) {
         const size_t total = (size_t)B * Ho * Wo * (C / 4);
         hipLaunchKernelGGL(resize_bilinear_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B,
@@ -204,6 +209,7 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
     const int ppb = 256 / lpp;
     size_t blocks = (npix + ppb - 1) / ppb;
     if (blocks > 8192) blocks = 8192;
+    a3d_begin();
     hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W,
                        C);
     return a3d_check_launch();

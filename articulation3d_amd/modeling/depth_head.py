@@ -67,8 +67,8 @@ class PlaneRCNNDepthHead(nn.Module):
 
     def forward_nhwc(self, feats):
         """feats: {p2..p6} NHWC -> depth [B, 2*H_p2*2, 2*W_p2*2] (480x640 for 480x640 frames)."""
-        C = lambda i, x: ops.conv2d(x, self._pk_conv[i - 1].packed())
-        D = lambda i, a, b=None: ops.conv2d(a, self._pk_deconv[i - 1].packed(), x2=b, ups=True)
+        C = lambda i, x: self._pk_conv[i - 1](x)
+        D = lambda i, a, b=None: self._pk_deconv[i - 1](a, x2=b, ups=True)
         x = D(1, C(1, feats["p6"]))
         p5 = feats["p5"]
         x = ops.resize_bilinear(x, p5.shape[1], p5.shape[2])  # depth_head.py:82

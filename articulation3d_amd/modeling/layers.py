@@ -40,6 +40,21 @@ def to_nchw_view(t: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 3, 1, 2)
 
 
+class _CalibrationState:
+    """While `active`, every conv that carries a (frozen / eval) batch-norm first measures the statistics
+    of its own un-normalised output on the batch flowing through and stores them in the norm's running
+    buffers (what a trained checkpoint holds).  Used once, offline, by utils.synthetic.calibrate_batchnorm to
+    give random-init weights well-conditioned activations; never active during inference."""
+
+    active = False
+
+
+def _calibrate_norm(norm, y_raw: torch.Tensor, eps_floor: float = 1e-6):
+    flat = y_raw.reshape(-1, y_raw.shape[-1])[:, : norm.running_mean.numel()]
+    norm.running_mean.copy_(flat.mean(0))
+    norm.running_var.copy_(flat.var(0, unbiased=False).clamp_min(eps_floor))
+
+
 class _Packable(nn.Module):
     """Caches the packed weights; re-packs when a parameter/buffer was modified or moved."""
 
@@ -98,6 +113,13 @@ class Conv2d(_Packable):
         return ops.pack_conv(self.weight, self.bias, bn, self.stride, self.padding, self.act, device=self.weight.device)
 
     def forward(self, x, **kw):
+        if _CalibrationState.active and self.norm is not None:
+            stem = self.in_channels == 3 and self.kernel_size == 7
+            ident = (torch.ones_like(self.norm.weight), torch.zeros_like(self.norm.bias), torch.zeros_like(self.norm.running_mean),
+                     torch.ones_like(self.norm.running_var) - self.norm.eps, self.norm.eps)
+            raw = ops.pack_stem(self.weight, ident, device=self.weight.device) if stem else \
+                ops.pack_conv(self.weight, self.bias, ident, self.stride, self.padding, ACT_NONE, device=self.weight.device)
+            _calibrate_norm(self.norm, ops.conv2d(x, raw, act=ACT_NONE, **{k: v for k, v in kw.items() if k in ("x2", "ups")}))
         return ops.conv2d(x, self.packed(), **kw)
 
 
@@ -116,6 +138,12 @@ class BNConv2d(_Packable):
     def _pack(self):
         bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps)
         return ops.pack_conv(self.conv.weight, self.conv.bias, bn, 1, 1, self.act, device=self.conv.weight.device)
+
+    def forward(self, x, **kw):
+        if _CalibrationState.active:
+            raw = ops.pack_conv(self.conv.weight, self.conv.bias, None, 1, 1, ACT_NONE, device=self.conv.weight.device)
+            _calibrate_norm(self.bn, ops.conv2d(x, raw, **kw))
+        return ops.conv2d(x, self.packed(), **kw)
 
 
 class Linear(_Packable):

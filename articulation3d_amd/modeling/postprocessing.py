@@ -27,7 +27,7 @@ def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5, nms=False):
     count = torch.tensor([N], device=dev, dtype=torch.int32)
     off = torch.zeros((2,), device=dev, dtype=torch.int32)
     m, _planes, _area, _keep, _ob = ops.paste_lsq(b, scores, count, off, masks.contiguous().float(), None, None, (h, w),
-                                                   post_score_thresh=-1.0, mask_thresh=threshold)
+                                                   post_score_thresh=-1.0, mask_thresh=threshold, clip_boxes=False)
     return m[0].to(torch.bool)
 
 

@@ -18,6 +18,22 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
 
 GROUP_CAP = 1024
 
+# Optional per-launch timing of the conv-GEMM kernel (bench.py's roofline leg): when a list is installed
+# here, conv2d() brackets its launch with HIP events on the launch stream and appends
+# (tile_config, algorithmic_flops, start_event, end_event).
+CONV_TIMING: Optional[list] = None
+
+
+def conv_tile_config(p: "PackedConv") -> str:
+    """Mirror of the dispatch in csrc/conv_gemm.hip:a3d_conv2d_nhwc_f32."""
+    if p.stem:
+        return "conv_gemm<4,1,2,2,stem> 256x64"
+    if p.cols <= 32:
+        return "conv_gemm<4,1,1,1> 128x32"
+    if p.cols <= 64:
+        return "conv_gemm<4,1,2,2> 256x64"
+    return "conv_gemm<2,2,2,2> 128x128"
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -178,6 +194,15 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         d.workspace = ws.data_ptr()
+    if CONV_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+        e1.record()
+        k_real = 147 if p.stem else p.KH * p.KW * p.Cin
+        CONV_TIMING.append((conv_tile_config(p), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1,
+                            f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"))
+        return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out
 
@@ -190,11 +215,12 @@ def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk:
     return y.view(M, p.cols)
 
 
-def choose_splitk(M: int, cols: int, K: int, target_blocks: int = 512) -> int:
-    tiles = max(1, math.ceil(M / 128)) * max(1, math.ceil(cols / 128))
-    chunks = K // 32
-    sk = max(1, min(target_blocks // tiles, chunks // 8))
-    return int(sk)
+def choose_splitk(M: int, cols: int, K: int) -> int:
+    """Split-K factor of a linear layer.  Depends on K ONLY: the summation order of every output element must
+    not change with the number of rows, otherwise a frame's result would depend on how frames were batched or
+    sharded across GPUs.  The 50176-deep head FCs are weight-bandwidth bound at realistic row counts: 32 K-slices
+    x 8 column tiles = 256 workgroups stream the 205 MB weight matrix once."""
+    return 32 if K >= 16384 else 1
 
 
 def _f3(v):
@@ -403,7 +429,7 @@ def linear_small(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
 
 
 def paste_lsq(boxes, scores, count, row_offset, mask_prob, normals, depth, img_hw, *, post_score_thresh=0.1,
-              mask_thresh=0.5, focal=571.623718, cx=319.5, cy=239.5, want_masks=True):
+              mask_thresh=0.5, focal=571.623718, cx=319.5, cy=239.5, want_masks=True, clip_boxes=True):
     _req(boxes)
     _req(scores)
     B, R, _ = boxes.shape
@@ -421,6 +447,7 @@ def paste_lsq(boxes, scores, count, row_offset, mask_prob, normals, depth, img_h
     d.B, d.R, d.MS, d.H, d.W = B, R, MS, H, W
     d.post_score_thresh, d.mask_thresh = float(post_score_thresh), float(mask_thresh)
     d.focal, d.cx, d.cy = float(focal), float(cx), float(cy)
+    d.clip_boxes = int(bool(clip_boxes))
     d.masks, d.planes, d.area, d.keep, d.out_boxes = _p(masks), planes.data_ptr(), area.data_ptr(), keep.data_ptr(), out_boxes.data_ptr()
     _lib.check(_lib.lib().a3d_paste_lsq(C.byref(d), _stream()), "a3d_paste_lsq")
     return masks, planes, area, keep, out_boxes

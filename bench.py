@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec through the PlaneRCNN detector at 480x640 on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of B=32 synthetic 480x640 uint8 BGR frames (resident in HBM) through the whole
+detector: normalise -> ResNet50-FPN -> RPN (top-k, NMS) -> ROIAlign -> box head -> detection NMS -> mask /
+plane / axis heads -> depth head -> fused post-process + mask paste + plane-offset LSQ -> packed detection
+records (+ an RCCL all-gather of the records when N > 1: frames are sharded across ranks, weak scaling).
+Weights: random init of the reference architecture with calibrated batch-norm statistics (no checkpoint is
+available offline); fp32 end to end.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
+
+
+def build_detector(score_thresh: float, device: str, seed: int = 2020):
+    from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
+    from articulation3d_amd.modeling import build_model
+    from articulation3d_amd.utils.synthetic import calibrate_batchnorm, synthetic_frames
+
+    cfg = get_cfg()
+    get_planercnn_cfg_defaults(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "planercnn_inference.yaml"))
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = score_thresh
+    cfg.MODEL.DEVICE = device
+    torch.manual_seed(seed)
+    model = build_model(cfg).eval()
+    calib = torch.from_numpy(synthetic_frames(2, seed + 1)).to(device)
+    calibrate_batchnorm(model, calib)
+    return model, cfg
+
+
+def cpu_baseline(model, frames_u8: np.ndarray, score_thresh: float, nframes: int):
+    """The CPU oracle (oracle/planercnn_oracle.py, a pure-PyTorch fp32 restatement of the same graph) timed on
+    this box's host cores, B=1 per call exactly as the reference's loop (tools/inference.py:215-219)."""
+    from oracle import planercnn_oracle as O
+
+    # threads = CPUs this process may run on (affinity mask, not the machine total), capped at 64: oneDNN convs at
+    # batch 1 do not scale past that and oversubscription makes the oracle pathologically slow
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, 64))
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ocfg = O.OracleCfg(score_thresh=score_thresh)
+    imgs = O.frames_to_chw(frames_u8[: nframes + 1])
+    O.detect(imgs[:1], P, ocfg)  # warm-up
+    ts, dets = [], []
+    for i in range(1, nframes + 1):
+        t0 = time.perf_counter()
+        out = O.detect(imgs[i:i + 1], P, ocfg)
+        ts.append(time.perf_counter() - t0)
+        dets.append(len(out[0]["scores"]))
+    med = float(np.median(ts))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{nframes} synthetic 480x640 frames, batch 1 per call, after 1 warm-up frame, median; "
+                      f"detections/frame={dets}; torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--score-thresh", type=float, default=0.5,
+                    help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
+                         "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP) device: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
+
+    from articulation3d_amd import ops
+    from articulation3d_amd.parallel import gather_records
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
+    model, cfg = build_detector(args.score_thresh, dev)
+    B = args.batch
+    # contiguous block of the synthetic clip per rank (temporal order is restored by rank order)
+    frames_np = synthetic_frames(B, seed=2020 + rank)
+    frames = torch.from_numpy(frames_np).to(dev)  # resident in HBM before the timed region
+
+    def step():
+        out = model.inference_batched(frames)
+        if world > 1:
+            return gather_records(out.records, out.rec_count), out
+        return (out.records, out.rec_count), out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.CONV_TIMING = []  # HIP events around every conv-GEMM launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing, ops.CONV_TIMING = ops.CONV_TIMING, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = B * world * args.steps
+    fps = total_frames / elapsed
+    dets = out.rec_count.float().mean().item()
+    raw = out.det.count.float().mean().item()
+
+    # roofline of the dominant kernel: per tile-config sums of algorithmic FLOPs and event durations
+    per = {}
+    for name, flops, e0, e1, _shape in timing:
+        d = per.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    dom = max(per.items(), key=lambda kv: kv[1][1])
+    dname, (dflops, dsec, dn) = dom
+    conv_sec = sum(v[1] for v in per.values())
+    achieved = dflops / dsec / 1e12
+    roofline = {
+        "kernel": dname, "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop": round(dflops / dn / 1e9, 3),
+        "share_of_step_time": round(dsec / elapsed, 3),
+        "all_conv_gemm": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "launches_per_step": v[2] // args.steps}
+                          for k, v in sorted(per.items())},
+        "conv_gemm_share_of_step_time": round(conv_sec / elapsed, 3),
+    }
+
+    result = {
+        "metric": "frames/sec through PlaneRCNN detector at 480x640",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: full PlaneRCNN detector (ResNet50-FPN + RPN + ROIAlign + box/mask/plane/axis heads "
+                               "+ depth head + NMS + mask paste + plane-offset LSQ + record pack), fp32, random-init weights with "
+                               "calibrated BN, synthetic 480x640 uint8 frames resident in HBM",
+                   "frames_per_step_per_gpu": B, "global_frames_per_step": B * world, "score_thresh_test": args.score_thresh,
+                   "raw_detections_per_frame": round(raw, 2), "kept_detections_per_frame": round(dets, 2),
+                   "proposals_per_frame": round(out.proposals[4].float().mean().item(), 1),
+                   "sharding": "contiguous frame blocks per rank" + (", RCCL all-gather of detection records per step" if world > 1 else "")},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(model, synthetic_frames(args.cpu_frames + 1, 2020), args.score_thresh, args.cpu_frames)
+        result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -196,6 +196,8 @@ typedef struct a3d_paste_desc {
     float post_score_thresh; /* 0.1, planercnn.py:217 */
     float mask_thresh;       /* 0.5, MODEL.ROI_MASK_HEAD.MASK_THRESHOLD */
     float focal, cx, cy;     /* 571.623718, 319.5, 239.5: arti_vis.py:101-104 */
+    int clip_boxes;          /* 1: Boxes.clip to the image first (detector_postprocess, postprocessing.py:58);
+                                0: paste with the boxes as given (bare paste_masks_in_image, mask_ops.py:68) */
     unsigned char *masks;    /* [B,R,H,W] 0/1 or NULL (mask never materialised) */
     float *planes;           /* [B,R,3] normal * offset (process()'s pred_plane) */
     int *area;               /* [B,R] */

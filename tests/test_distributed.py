@@ -1,0 +1,73 @@
+"""CPU suite, part 3: the N>1 path (frame sharding + all-gather of detection records) on gloo, world size 2."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from articulation3d_amd.parallel import gather_records, shard_range
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F_, R, REC = 10, 4, 798
+    lo, hi = shard_range(F_, rank, world)
+    B = hi - lo
+    rec = torch.zeros(B, R, REC)
+    cnt = torch.zeros(B, dtype=torch.int32)
+    for i, f in enumerate(range(lo, hi)):  # frame f carries f % 3 detections whose score encodes (frame, slot)
+        cnt[i] = f % 3
+        for r in range(int(cnt[i])):
+            rec[i, r, 4] = f + 0.1 * r
+    all_rec, all_cnt = gather_records(rec, cnt)
+    ok = all_rec.shape == (F_, R, REC) and all_cnt.tolist() == [f % 3 for f in range(F_)]
+    for f in range(F_):  # temporal order restored by rank order
+        for r in range(f % 3):
+            ok = ok and abs(float(all_rec[f, r, 4]) - (f + 0.1 * r)) < 1e-6
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from articulation3d_amd.parallel import shard_range
+
+    for F_, G in ((1024, 8), (10, 4), (3, 8), (64, 1)):
+        blocks = [shard_range(F_, r, G) for r in range(G)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == F_
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
+    assert shard_range(1024, 3, 8) == (384, 512)
+
+
+def test_gather_records_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_gather_records_single_process_is_identity():
+    from articulation3d_amd.parallel import gather_records
+
+    a, b = torch.zeros(2, 3, 798), torch.zeros(2, dtype=torch.int32)
+    x, y = gather_records(a, b)
+    assert x is a and y is b

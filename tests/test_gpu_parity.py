@@ -1,0 +1,548 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Methodology.  Continuous stages (convolutions, ROIAlign, heads, depth) are compared END TO END with the
+oracle at a stated fp32 tolerance.  Discrete stages (top-k, NMS keep masks, detection indices, pasted masks)
+are discontinuous in their inputs, so each is compared on IDENTICAL inputs -- the oracle stage is fed the
+very tensors the HIP stage consumed -- and must then agree BIT-EXACTLY.  Box coordinates that pass through
+`exp` are compared at 1e-3 px (device expf vs libm differ by an ulp).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import golden_inputs as G
+
+pytestmark = pytest.mark.gpu
+HW = (480, 640)
+NAMES = ("p2", "p3", "p4", "p5", "p6")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from articulation3d_amd import ops as o
+
+    return o
+
+
+# ------------------------------------------------------------------------------------------ conv-GEMM units
+CONV_CASES = [
+    dict(B=2, H=24, W=40, Cin=64, Cout=256, k=1, s=1, p=0),
+    dict(B=2, H=24, W=40, Cin=256, Cout=64, k=1, s=1, p=0),
+    dict(B=2, H=24, W=40, Cin=64, Cout=64, k=3, s=1, p=1),
+    dict(B=3, H=15, W=20, Cin=256, Cout=256, k=3, s=1, p=1),
+    dict(B=2, H=24, W=40, Cin=256, Cout=512, k=1, s=2, p=0),
+    dict(B=2, H=8, W=10, Cin=256, Cout=15, k=1, s=1, p=0),
+    dict(B=1, H=7, W=9, Cin=32, Cout=36, k=3, s=2, p=1),  # ragged M and N tiles, stride 2 with padding
+    dict(B=1, H=1, W=1, Cin=2048, Cout=512, k=1, s=1, p=0),  # single output row
+]
+
+
+@pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: f"{c['Cin']}to{c['Cout']}k{c['k']}s{c['s']}")
+def test_conv_gemm_vs_torch_fp32(ops, c):
+    torch.manual_seed(1)
+    x = torch.randn(c["B"], c["Cin"], c["H"], c["W"])
+    w = torch.randn(c["Cout"], c["Cin"], c["k"], c["k"]) / (c["Cin"] * c["k"] ** 2) ** 0.5
+    b = torch.randn(c["Cout"])
+    ref = F.relu(F.conv2d(x, w, b, stride=c["s"], padding=c["p"]))
+    p = ops.pack_conv(w, b, None, c["s"], c["p"], ops.ACT_RELU, device="cuda")
+    y = ops.conv2d(nhwc(x).cuda(), p)
+    assert rel(y[..., : c["Cout"]].permute(0, 3, 1, 2), ref) < 5e-6  # fp32 MFMA vs fp32 oneDNN
+
+
+def test_conv_fused_epilogues(ops):
+    torch.manual_seed(2)
+    x = torch.randn(2, 64, 24, 40)
+    w = torch.randn(256, 64, 1, 1) / 8
+    bn = (torch.rand(256) + 0.5, torch.randn(256) * 0.1, torch.randn(256) * 0.1, torch.rand(256) + 0.5, 1e-5)
+    r = torch.randn(2, 256, 24, 40)
+    ref = F.relu(F.batch_norm(F.conv2d(x, w), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5) + r)
+    y = ops.conv2d(nhwc(x).cuda(), ops.pack_conv(w, None, bn, 1, 0, ops.ACT_RELU), res=nhwc(r).cuda())
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    # FPN lateral: + nearest x2 upsampled coarser level
+    x = torch.randn(2, 512, 30, 40)
+    w = torch.randn(256, 512, 1, 1) / 22
+    b = torch.randn(256)
+    prev = torch.randn(2, 256, 15, 20)
+    ref = F.conv2d(x, w, b) + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+    y = ops.conv2d(nhwc(x).cuda(), ops.pack_conv(w, b), res=nhwc(prev).cuda(), res_ups=True)
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    # depth deconv: nearest x2 upsample of a channel concat, leaky / relu
+    a, c2 = torch.randn(2, 128, 15, 20), torch.randn(2, 128, 15, 20)
+    w = torch.randn(128, 256, 3, 3) / 48
+    ref = F.leaky_relu(F.conv2d(F.interpolate(torch.cat([a, c2], 1), scale_factor=2, mode="nearest"), w, b[:128], padding=1), 0.01)
+    y = ops.conv2d(nhwc(a).cuda(), ops.pack_conv(w, b[:128], None, 1, 1, ops.ACT_LEAKY), x2=nhwc(c2).cuda(), ups=True)
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    # transposed conv 2x2 s2 as a pixel-shuffled GEMM
+    x = torch.randn(5, 256, 14, 14)
+    w = torch.randn(256, 256, 2, 2) / 16
+    ref = F.relu(F.conv_transpose2d(x, w, b, stride=2))
+    y = ops.conv2d(nhwc(x).cuda(), ops.pack_deconv2x2(w, b))
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+
+
+def test_stem_pool_resize_small_ops(ops):
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, 96, 128) * 255 - 110
+    w = torch.randn(64, 3, 7, 7) / 12
+    bn = (torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(64) * 0.1, torch.rand(64) + 0.5, 1e-5)
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, None, 2, 3), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
+    y = ops.conv2d(ops.preprocess_f32chw(x.cuda(), (0, 0, 0), (1, 1, 1)), ops.pack_stem(w, bn))
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    assert rel(ops.maxpool3x3s2(y).permute(0, 3, 1, 2), F.max_pool2d(ref, 3, 2, 1)) < 5e-6
+    assert torch.equal(ops.subsample2(y).cpu(), y.cpu()[:, ::2, ::2])
+    u8 = torch.randint(0, 256, (2, 32, 64, 3), dtype=torch.uint8)
+    mean, std = (103.53, 116.28, 123.675), (1.0, 1.0, 1.0)
+    got = ops.preprocess_u8hwc(u8.cuda(), mean, std).cpu()
+    assert torch.equal(got[..., :3], u8.float() - torch.tensor(mean)) and float(got[..., 3].abs().sum()) == 0
+    x = torch.randn(2, 128, 16, 20)
+    assert rel(ops.resize_bilinear(nhwc(x).cuda(), 15, 20).permute(0, 3, 1, 2), F.interpolate(x, size=(15, 20), mode="bilinear", align_corners=False)) < 1e-6
+    x = torch.randn(2, 1, 24, 32)
+    assert rel(ops.resize_bilinear(nhwc(x).cuda(), 48, 64).permute(0, 3, 1, 2), F.interpolate(x, size=(48, 64), mode="bilinear", align_corners=False)) < 1e-6
+    x = torch.randn(2, 64, 24, 32)
+    w = torch.randn(1, 64, 3, 3) / 24
+    y = ops.conv3x3_to1(nhwc(x).cuda(), w[0].permute(1, 2, 0).contiguous().cuda(), 0.3)
+    assert rel(y[:, None], F.conv2d(x, w, torch.tensor([0.3]), padding=1)) < 5e-6
+
+
+@pytest.mark.parametrize("splitk", [1, 7, 64])
+def test_linear_splitk_chw_reorder(ops, splitk):
+    torch.manual_seed(4)
+    x = torch.randn(7, 256, 14, 14)
+    w = torch.randn(1024, 256 * 14 * 14) / 224
+    b = torch.randn(1024)
+    ref = F.relu(F.linear(x.flatten(1), w, b))
+    p = ops.pack_linear(w, b, chw=(256, 14, 14), act=ops.ACT_RELU)
+    y = ops.linear(nhwc(x).reshape(7, -1).cuda(), p, splitk=splitk)
+    assert rel(y, ref) < 1e-5
+    if splitk > 1:  # slabs are summed in slice order: bitwise reproducible
+        assert torch.equal(y, ops.linear(nhwc(x).reshape(7, -1).cuda(), p, splitk=splitk))
+
+
+def test_ragged_row_count_from_device(ops):
+    """m_dev: tiles past the live row count exit at once and leave the tail untouched."""
+    torch.manual_seed(5)
+    x = torch.randn(300, 64)
+    w = torch.randn(128, 64) / 8
+    p = ops.pack_linear(w, None)
+    live = torch.tensor([130], dtype=torch.int32).cuda()
+    out = torch.full((300, 1, 1, 128), -7.0).cuda()
+    ops.conv2d(x.view(300, 1, 1, 64).cuda(), p, m_dev=live, out=out)
+    y = out.view(300, 128).cpu()
+    assert rel(y[:130], F.linear(x[:130], w)) < 5e-6
+    assert bool((y[256:] == -7.0).all())  # whole tiles past the count were never written
+
+
+# ------------------------------------------------------------------------------------------ ROIAlign / NMS units
+@pytest.mark.parametrize("P,ratio,aligned", [(7, 0, True), (14, 2, False), (14, 0, False)])
+def test_roi_align_fpn_vs_oracle(ops, oracle, P, ratio, aligned):
+    torch.manual_seed(6)
+    B = 2
+    feats = {n: torch.randn(B, 256, 480 // s, 640 // s) for n, s in zip(NAMES[:4], (4, 8, 16, 32))}
+    rng = np.random.default_rng(P)
+    box_lists = []
+    for b in range(B):
+        n = 40 + 7 * b
+        side = np.exp(rng.uniform(np.log(4), np.log(600), n))  # covers all four pyramid levels
+        ar = np.exp(rng.uniform(-1, 1, n))
+        w_, h_ = side * np.sqrt(ar), side / np.sqrt(ar)
+        cx, cy = rng.uniform(0, 640, n), rng.uniform(0, 480, n)
+        bx = np.stack([cx - w_ / 2, cy - h_ / 2, cx + w_ / 2, cy + h_ / 2], 1)
+        bx[0] = [10, 10, 10, 10]  # zero-area box
+        bx[1] = [-50, -40, 700, 500]  # larger than the image
+        box_lists.append(torch.tensor(bx, dtype=torch.float32))
+    ref = oracle.roi_pool_fpn(feats, box_lists, P, ratio, aligned)
+    R = max(len(b) for b in box_lists)
+    boxes = torch.zeros(B, R, 4)
+    for i, bl in enumerate(box_lists):
+        boxes[i, : len(bl)] = bl
+    count = torch.tensor([len(b) for b in box_lists], dtype=torch.int32).cuda()
+    off = ops.count_offsets(count, R)
+    total = sum(len(b) for b in box_lists)
+    out, lvl = ops.roi_align_fpn([nhwc(feats[n]).cuda() for n in NAMES[:4]], [0.25, 0.125, 0.0625, 0.03125], boxes.cuda(), count,
+                                 P, ratio, aligned, row_offset=off, rows=total, want_level=True)
+    assert torch.equal(lvl.cpu().long(), oracle.assign_levels(torch.cat(box_lists)))  # level indices bit-exact
+    assert set(lvl.cpu().tolist()) == {0, 1, 2, 3}
+    assert rel(out.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def _nms_groups(seed, G_, n_max, dup=True):
+    rng = np.random.default_rng(seed)
+    boxes = torch.zeros(G_, 1024, 4)
+    valid = torch.zeros(G_, 1024, dtype=torch.int32)
+    ns = torch.zeros(G_, dtype=torch.int32)
+    for g in range(G_):
+        n = int(rng.integers(0, n_max + 1)) if g else n_max
+        cx, cy = rng.uniform(0, 640, n), rng.uniform(0, 480, n)
+        w_, h_ = rng.uniform(8, 200, n), rng.uniform(8, 200, n)
+        b = np.stack([cx - w_ / 2, cy - h_ / 2, cx + w_ / 2, cy + h_ / 2], 1).astype(np.float32)
+        if dup and n > 10:
+            b[5] = b[2]  # exact duplicate
+            b[7, :] = [100, 100, 100, 140]  # zero-area
+        boxes[g, :n] = torch.from_numpy(b)
+        v = rng.random(n) > 0.05
+        valid[g, :n] = torch.from_numpy(v.astype(np.int32))
+        ns[g] = n
+    return boxes, valid, ns
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.7])
+def test_group_nms_keep_masks_bit_exact(ops, oracle, thr):
+    boxes, valid, ns = _nms_groups(11, 12, 1000)
+    keep = ops.group_nms(boxes.cuda(), valid.cuda(), ns.cuda(), thr).cpu()
+    for g in range(boxes.shape[0]):
+        n = int(ns[g])
+        v = valid[g, :n].bool()
+        exp = torch.zeros(n, dtype=torch.bool)
+        exp[v] = oracle.nms_sorted(boxes[g, :n][v], torch.zeros(int(v.sum()), dtype=torch.int64), thr)
+        assert torch.equal(keep[g, :n].bool(), exp), f"group {g}"
+        assert int(keep[g, n:].sum()) == 0
+    # idempotence at full size: NMS of the kept boxes keeps all of them
+    g = 0
+    kept = boxes[g, : int(ns[g])][keep[g, : int(ns[g])].bool()]
+    b2 = torch.zeros(1, 1024, 4)
+    b2[0, : len(kept)] = kept
+    k2 = ops.group_nms(b2.cuda(), torch.ones(1, 1024, dtype=torch.int32).cuda(), torch.tensor([len(kept)], dtype=torch.int32).cuda(), thr).cpu()
+    assert int(k2[0, : len(kept)].sum()) == len(kept)
+
+
+def test_group_nms_edge_cases(ops):
+    boxes = torch.zeros(3, 1024, 4)
+    boxes[1, :3] = torch.tensor([[0.0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30]])
+    boxes[2, :2] = torch.tensor([[0.0, 0, 10, 10], [1, 1, 11, 11]])
+    valid = torch.ones(3, 1024, dtype=torch.int32)
+    valid[2, 0] = 0  # an invalid box neither survives nor suppresses
+    ns = torch.tensor([0, 3, 2], dtype=torch.int32)
+    keep = ops.group_nms(boxes.cuda(), valid.cuda(), ns.cuda(), 0.5).cpu()
+    assert int(keep[0].sum()) == 0
+    assert keep[1, :3].tolist() == [1, 0, 1]
+    assert keep[2, :2].tolist() == [0, 1]
+
+
+# ------------------------------------------------------------------------------------------ golden vectors (reference modules)
+def test_golden_paste_masks_through_hip(ops, golden_dir):
+    from articulation3d_amd.modeling.postprocessing import paste_masks_in_image
+
+    g = np.load(os.path.join(golden_dir, "paste_masks.npz"))
+    masks, boxes, hw = G.paste_case()
+    # the kernel vectorises 16 pixels: the 120x160 fixture image satisfies W % 16 == 0
+    out = paste_masks_in_image(masks.cuda(), boxes.cuda(), hw, threshold=0.5).cpu().numpy()
+    ref = np.unpackbits(g["packed"])[: int(np.prod(g["shape"]))].reshape(g["shape"]).astype(bool)
+    assert (out != ref).sum() == 0  # bit-exact against the REFERENCE's paste_masks_in_image
+
+
+def _close_to_truth(got, g, key, tol=1e-4):
+    """`got` vs the REFERENCE module evaluated in float64 (the fixture's *_f64 arrays).  North-star tolerance:
+    1e-4 relative to the magnitude of the quantity (unit vectors / O(1) offsets); and the HIP fp32 result may not
+    be more than a small factor further from the truth than the reference's own fp32 CPU result is."""
+    truth, ref32 = g[key + "_f64"], g[key]
+    scale = max(1.0, float(np.abs(truth).max()))
+    err = float(np.abs(got - truth).max())
+    ref_err = float(np.abs(ref32 - truth).max())
+    assert err < tol * scale, (key, err)
+    assert err < 8 * ref_err + 2e-6, (key, err, ref_err)
+
+
+def test_golden_plane_axis_heads_through_hip(ops, hip_model, golden_dir):
+    import copy
+
+    rh = hip_model.roi_heads
+    x = G.head_input()
+    xr = nhwc(x).cuda()
+    ph = copy.deepcopy(rh.plane_head)
+    ph.load_state_dict({k.replace("roi_heads.plane_head.", ""): v for k, v in G.head_params("plane").items()})
+    g = np.load(os.path.join(golden_dir, "plane_head.npz"))
+    _close_to_truth(ph.cuda().forward_rows(xr).cpu().numpy(), g, "pred_plane")
+    ah = copy.deepcopy(rh.axis_head)
+    ah.load_state_dict({k.replace("roi_heads.axis_head.", ""): v for k, v in G.head_params("axis").items()})
+    g = np.load(os.path.join(golden_dir, "axis_head.npz"))
+    rot, tran = ah.cuda().forward_rows(xr)
+    _close_to_truth(rot.cpu().numpy(), g, "pred_rot_axis")
+    _close_to_truth(tran.cpu().numpy(), g, "pred_tran_axis")
+
+
+def test_golden_depth_head_through_hip(ops, hip_model, golden_dir):
+    from articulation3d_amd.modeling.depth_head import PlaneRCNNDepthHead
+    from conftest import make_cfg
+
+    dh = PlaneRCNNDepthHead(make_cfg(0.7)).cuda().eval()
+    missing, unexpected = dh.load_state_dict({k.replace("depth_head.", ""): v for k, v in G.head_params("depth").items()}, strict=False)
+    assert not unexpected
+    g = np.load(os.path.join(golden_dir, "depth_head.npz"))
+    feats = {k: nhwc(v).cuda() for k, v in G.depth_features().items()}
+    d = dh.forward_nhwc(feats).cpu()
+    assert tuple(d.shape) == tuple(g["shape"])
+    _close_to_truth(d[:, ::16, ::16].numpy(), g, "depth_strided")
+    assert abs(float(d.double().sum()) - float(g["depth_sum"])) < 1e-4 * float(g["depth_abs_sum"])
+
+
+# ------------------------------------------------------------------------------------------ the whole path, stage-wise
+def _merge_expected(g, g0, ng, K):
+    items = []
+    for gl in range(ng):
+        n = int(g["n"][g0 + gl])
+        keep = g["keep"][g0 + gl, :n].bool()
+        for r in keep.nonzero().squeeze(1).tolist():
+            items.append((-float(g["scores"][g0 + gl, r]), int(g["pos"][g0 + gl, r]), gl, r))
+    items.sort(key=lambda t: (t[0], t[1]))
+    items = items[:K]
+    boxes = torch.stack([g["boxes"][g0 + gl, r] for _, _, gl, r in items]) if items else torch.zeros(0, 4)
+    return boxes, [it[2] for it in items]
+
+
+@pytest.fixture(scope="module")
+def staged(ops, hip_model, oracle, oracle_params):
+    """Runs the HIP path on two synthetic frames, keeping every intermediate."""
+    O, P, model = oracle, oracle_params, hip_model
+    nf = 2
+    frames = O.synthetic_frames(nf)
+    fr = torch.from_numpy(frames).cuda()
+    ocfg = O.OracleCfg(score_thresh=0.0)
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    x, _ = O.preprocess(O.frames_to_chw(frames), ocfg)
+    s = dict(nf=nf, frames=frames, fr=fr, ocfg=ocfg, ofeats=O.backbone(x, P), x=x)
+    s["x4"] = ops.preprocess_u8hwc(fr, model.pixel_mean, model.pixel_std)
+    s["feats"] = model.backbone.forward_nhwc(s["x4"])
+    rpn = model.proposal_generator
+    s["heads"] = rpn.rpn_head.forward_nhwc([s["feats"][f] for f in rpn.in_features])
+    s["depth"] = model.depth_head.forward_nhwc(s["feats"])
+    s["gfeats"] = {k: s["feats"][k].permute(0, 3, 1, 2).contiguous().cpu() for k in NAMES}
+    s["props"] = rpn.forward_batched(s["feats"], HW, heads=s["heads"], return_groups=True)
+    return s
+
+
+def test_stage_backbone_rpnhead_depth_end_to_end(staged, oracle, oracle_params):
+    s, O, P = staged, oracle, oracle_params
+    assert rel(s["x4"][..., :3].permute(0, 3, 1, 2), s["x"]) == 0.0
+    for k in NAMES:  # ~50 fp32 layers deep; both sides are fp32 with different summation orders
+        assert rel(s["feats"][k].permute(0, 3, 1, 2), s["ofeats"][k]) < 2e-4, k
+    ol, od = O.rpn_head(s["ofeats"], P)
+    for l in range(5):
+        assert rel(s["heads"][l][..., :3].reshape(s["nf"], -1), ol[l]) < 2e-4
+        assert rel(s["heads"][l][..., 3:15].reshape(s["nf"], -1, 4), od[l]) < 2e-4
+    assert rel(s["depth"], O.depth_head(s["ofeats"], P)) < 5e-4
+    assert rel(s["depth"], O.depth_head(s["gfeats"], P)) < 2e-5  # same features in: the depth head itself
+
+
+def test_stage_proposals_bit_exact_on_identical_heads(staged, oracle):
+    s, O = staged, oracle
+    nf, ocfg = s["nf"], s["ocfg"]
+    heads = s["heads"]
+    gl_ = [h[..., :3].reshape(nf, -1).cpu() for h in heads]
+    gd_ = [h[..., 3:15].reshape(nf, -1, 4).cpu() for h in heads]
+    feat_hw = [tuple(s["feats"][k].shape[1:3]) for k in NAMES]
+    oprops, ogroups = O.rpn_select(gl_, gd_, feat_hw, [HW] * nf, ocfg, return_groups=True)
+    pb, pl, plv, ppos, pc, g = s["props"]
+    g = {k: v.cpu() for k, v in g.items()}
+    for b in range(nf):
+        for l in range(5):
+            gi, og = b * 5 + l, ogroups[b][l]
+            k = len(og["scores"])
+            assert int(g["n"][gi]) == k
+            assert torch.equal(g["scores"][gi, :k], og["scores"])  # top-k selection + order, bit-exact
+            assert (g["boxes"][gi, :k] - og["boxes"]).abs().max() < 2e-3
+            assert torch.equal(g["valid"][gi, :k].bool(), og["valid"])
+            v = g["valid"][gi, :k].bool()
+            okeep = torch.zeros(k, dtype=torch.bool)
+            okeep[v] = O.nms_sorted(g["boxes"][gi, :k][v], torch.zeros(int(v.sum()), dtype=torch.int64), ocfg.rpn_nms_thresh)
+            assert torch.equal(g["keep"][gi, :k].bool(), okeep)  # NMS keep mask, bit-exact
+        exp_boxes, exp_lvl = _merge_expected(g, b * 5, 5, 1000)
+        n = int(pc[b])
+        assert n == len(exp_boxes) and torch.equal(pb[b, :n].cpu(), exp_boxes) and plv[b, :n].cpu().tolist() == exp_lvl
+        assert float(pb[b, n:].abs().sum()) == 0
+        sc = pl[b, :n].cpu()
+        assert bool((sc[:-1] >= sc[1:]).all())  # score-descending
+        ob = oprops[b][0]  # against the full CPU selection (differs only through exp ulps)
+        assert n == len(ob) and (pb[b, :n].cpu() - ob).abs().max() < 2e-3
+
+
+@pytest.fixture(scope="module")
+def staged_box(staged, hip_model, oracle, oracle_params):
+    s, O, P, model = staged, oracle, oracle_params, hip_model
+    rh = model.roi_heads
+    pb, _pl, _lv, _pos, pc, _g = s["props"]
+    lv = [s["feats"][f] for f in rh.box_in_features]
+    pooled = rh.box_pooler.forward_batched(lv, pb, pc)
+    pred = rh.box_predictor(rh.box_head(pooled))
+    rh.box_predictor.test_score_thresh = 0.0
+    det = rh.box_predictor.inference_batched(pred, pb, pc, HW, return_groups=True)
+    return dict(pooled=pooled, pred=pred, det=det, props_cpu=[pb[b, : int(pc[b])].cpu() for b in range(s["nf"])])
+
+
+def test_stage_box_head_and_detections(staged, staged_box, oracle, oracle_params):
+    s, sb, O, P = staged, staged_box, oracle, oracle_params
+    nf, ocfg = s["nf"], s["ocfg"]
+    pb, _pl, _lv, _pos, pc, _g = s["props"]
+    R = pb.shape[1]
+    opooled = O.roi_pool_fpn(s["gfeats"], sb["props_cpu"], *ocfg.box_pool)
+    gp = torch.cat([sb["pooled"][b * R: b * R + int(pc[b])] for b in range(nf)]).permute(0, 3, 1, 2)
+    assert rel(gp, opooled) < 1e-5
+    ocls, odl = O.box_predictor(O.box_head(opooled, P), P)
+    gpred = torch.cat([sb["pred"][b * R: b * R + int(pc[b])] for b in range(nf)])
+    assert rel(gpred[:, :3], ocls) < 1e-4 and rel(gpred[:, 3:11], odl) < 1e-4
+    db, dsc, dcl, dpos, dcnt, g2 = sb["det"]
+    g2 = {k: v.cpu() for k, v in g2.items()}
+    for b in range(nf):
+        n = int(pc[b])
+        pr = sb["pred"][b * R: b * R + n].cpu()
+        dec = O.apply_deltas(pr[:, 3:11], sb["props_cpu"][b], ocfg.box_weights, ocfg.scale_clamp)
+        ob_, os_, oc_, _rows = O.fast_rcnn_inference_single(dec, F.softmax(pr[:, :3], dim=-1), HW, ocfg)
+        exp_boxes, exp_cls = _merge_expected(g2, b * 2, 2, 100)
+        nd = int(dcnt[b])
+        assert nd == len(exp_boxes) == 100
+        assert torch.equal(db[b, :nd].cpu(), exp_boxes) and dcl[b, :nd].cpu().tolist() == exp_cls
+        assert nd == len(ob_) and (db[b, :nd].cpu() - ob_).abs().max() < 2e-3
+        assert (dsc[b, :nd].cpu() - os_).abs().max() < 1e-6
+        assert torch.equal(dcl[b, :nd].cpu().long(), oc_)  # class indices bit-exact
+        for c in range(2):
+            gi = b * 2 + c
+            k = int(g2["n"][gi])
+            v = g2["valid"][gi, :k].bool()
+            okeep = torch.zeros(k, dtype=torch.bool)
+            okeep[v] = O.nms_sorted(g2["boxes"][gi, :k][v], torch.zeros(int(v.sum()), dtype=torch.int64), ocfg.nms_thresh)
+            assert torch.equal(g2["keep"][gi, :k].bool(), okeep)
+
+
+def test_stage_roi_heads_paste_lsq_and_records(staged, staged_box, hip_model, oracle, oracle_params):
+    from articulation3d_amd.modeling.roi_heads.roi_heads import BatchedDetections
+
+    s, sb, O, P, model = staged, staged_box, oracle, oracle_params, hip_model
+    nf, ocfg = s["nf"], s["ocfg"]
+    db, dsc, dcl, _dpos, dcnt, _g2 = sb["det"]
+    det = model.roi_heads.given_boxes_batched(s["feats"], BatchedDetections(db, dsc, dcl, dcnt, HW))
+    dets_cpu = [db[b, : int(dcnt[b])].cpu() for b in range(nf)]
+    assert det.total == sum(len(d) for d in dets_cpu) == 200
+    om = O.mask_head(O.roi_pool_fpn(s["gfeats"], dets_cpu, *ocfg.mask_pool), P)
+    assert rel(det.mask_prob[:, None], om) < 1e-4
+    assert rel(det.pred_plane, O.plane_head(O.roi_pool_fpn(s["gfeats"], dets_cpu, *ocfg.plane_pool), P)) < 1e-4
+    ora, ota = O.axis_head(O.roi_pool_fpn(s["gfeats"], dets_cpu, *ocfg.axis_pool), P)
+    assert rel(det.pred_rot_axis, ora) < 1e-4 and rel(det.pred_tran_axis, ota) < 1e-4
+    out = model._post_batched(det, s["depth"], HW, True, None)
+    rays = O.k_inv_dot_xy1()
+    rec = out.records.cpu()
+    for b in range(nf):
+        nd = int(dcnt[b])
+        r0 = int(det.row_offset[b])
+        d = dict(pred_boxes=db[b, :nd].cpu(), scores=dsc[b, :nd].cpu(), pred_classes=dcl[b, :nd].cpu().long(),
+                 pred_masks=det.mask_prob[r0: r0 + nd, None].cpu(), pred_plane=det.pred_plane[r0: r0 + nd].cpu(), image_size=HW)
+        o = O.detector_postprocess(d, HW[0], HW[1], ocfg)
+        idx = out.keep[b, :nd].bool().cpu().nonzero().squeeze(1)
+        assert len(idx) == len(o["scores"])
+        assert (out.masks[b, idx].cpu().bool() != o["pred_masks"]).sum().item() == 0  # pasted masks bit-exact
+        assert torch.equal(out.area[b, idx].cpu().long(), o["pred_masks"].sum((1, 2)))
+        opo = O.override_depth(s["depth"][b].cpu(), o["pred_masks"], o["pred_plane"], rays)
+        assert ((out.planes[b, idx].cpu() - opo).abs().max() / opo.abs().max()).item() < 1e-4  # north_star tolerance
+        # packed records = the create_instances payload
+        n = int(out.rec_count[b])
+        assert n == len(idx)
+        assert torch.equal(rec[b, :n, 0:4], out.boxes[b, idx].cpu()) and torch.equal(rec[b, :n, 4], dsc[b, idx].cpu())
+        assert torch.equal(rec[b, :n, 5].long(), dcl[b, idx].cpu().long()) and torch.equal(rec[b, :n, 6:9], out.planes[b, idx].cpu())
+        assert torch.equal(rec[b, :n, 9:12], det.pred_rot_axis[r0 + idx].cpu()) and torch.equal(rec[b, :n, 14:], det.mask_prob[r0 + idx].reshape(n, -1).cpu())
+        assert float(rec[b, n:].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------ reference-signature path and edge cases
+def test_reference_api_matches_batched_path(hip_model, oracle):
+    from articulation3d_amd.utils.arti_vis import create_instances, PlaneRCNN_Branch
+
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    frames = oracle.synthetic_frames(2, seed=7)
+    out_b = model.inference_batched(torch.from_numpy(frames).cuda(), want_masks=True)
+    inputs = [{"image": torch.as_tensor(f.transpose(2, 0, 1).astype("float32"))} for f in frames]
+    outs = model(inputs)  # list[{"instances", "depth"}] as planercnn.py:143-146
+    assert len(outs) == 2
+    for b, o in enumerate(outs):
+        inst = o["instances"]
+        idx = out_b.keep[b, : int(out_b.det.count[b])].bool().nonzero().squeeze(1)
+        r0 = int(out_b.det.row_offset[b])
+        assert len(inst) == len(idx) > 0
+        assert torch.equal(inst.pred_boxes.tensor, out_b.boxes[b, idx]) and torch.equal(inst.scores, out_b.det.scores[b, idx])
+        assert inst.pred_classes.dtype == torch.int64 and inst.pred_masks.dtype == torch.bool
+        assert torch.equal(inst.pred_masks, out_b.masks[b, idx].bool())
+        assert torch.equal(inst.pred_plane, out_b.det.pred_plane[r0 + idx]) and torch.equal(inst.pred_rot_axis, out_b.det.pred_rot_axis[r0 + idx])
+        assert torch.equal(o["depth"], out_b.depth[b])
+    # PlaneRCNN_Branch.process: COCO records + plane offsets, then create_instances
+    branch = PlaneRCNN_Branch.__new__(PlaneRCNN_Branch)
+    branch._cpu_device, branch._refine_on = "cpu", False
+    pred = branch.process(outs[0])
+    idx = out_b.keep[0, : int(out_b.det.count[0])].bool().nonzero().squeeze(1)
+    assert ((pred["pred_plane"] - out_b.planes[0, idx].cpu()).abs().max() / out_b.planes[0, idx].abs().max()).item() < 1e-5
+    assert len(pred["instances"]) == len(idx) and set(pred["instances"][0]) == {"image_id", "category_id", "bbox", "score", "segmentation"}
+    ci = create_instances(pred["instances"], HW, pred_planes=pred["pred_plane"].numpy(), pred_rot_axis=pred["pred_rot_axis"],
+                          pred_tran_axis=pred["pred_tran_axis"], conf_threshold=0.3)
+    k = int((outs[0]["instances"].scores > 0.3).sum())
+    assert len(ci) == k and ci.pred_masks.shape == (k, 480, 640)
+    assert torch.equal(ci.pred_masks.bool(), outs[0]["instances"].pred_masks[outs[0]["instances"].scores > 0.3].cpu())
+
+
+def test_no_detections_at_reference_threshold(hip_model, oracle):
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.7  # the reference default: random-init scores stay below it
+    try:
+        frames = oracle.synthetic_frames(2, seed=9)
+        out = model.inference_batched(torch.from_numpy(frames).cuda(), want_masks=True)
+        assert out.det.total == 0 and int(out.rec_count.sum()) == 0 and float(out.records.abs().sum()) == 0
+        assert out.depth.shape == (2, 480, 640) and int(out.proposals[4].min()) > 100
+        outs = model([{"image": torch.as_tensor(f.transpose(2, 0, 1).astype("float32"))} for f in frames])
+        assert all(len(o["instances"]) == 0 for o in outs)
+        assert outs[0]["instances"].pred_masks.shape == (0, 480, 640)
+    finally:
+        model.roi_heads.box_predictor.test_score_thresh = 0.0
+
+
+def test_forward_with_given_boxes_ragged(hip_model, oracle, oracle_params, staged):
+    """forward_with_given_boxes entry (roi_heads.py:147) with a different number of boxes per image, incl. none."""
+    from articulation3d_amd.structures import Boxes, Instances
+
+    model, O, P = hip_model, oracle, oracle_params
+    feats = {k: v.permute(0, 3, 1, 2) for k, v in staged["feats"].items()}
+    boxes = [torch.tensor([[30.0, 40, 200, 300], [100, 100, 500, 400], [5, 5, 40, 30]]), torch.zeros(0, 4)]
+    insts = []
+    for b in boxes:
+        i = Instances(HW)
+        i.pred_boxes = Boxes(b.cuda())
+        i.pred_classes = torch.zeros(len(b), dtype=torch.int64).cuda()
+        insts.append(i)
+    out = model.roi_heads.forward_with_given_boxes(feats, insts)
+    assert out[0].pred_masks.shape == (3, 1, 28, 28) and out[1].pred_masks.shape == (0, 1, 28, 28)
+    ocfg = O.OracleCfg()
+    ref = O.plane_head(O.roi_pool_fpn(staged["gfeats"], boxes, *ocfg.plane_pool), P)
+    assert rel(out[0].pred_plane, ref) < 1e-4 and out[1].pred_plane.shape == (0, 3)
+    ora, ota = O.axis_head(O.roi_pool_fpn(staged["gfeats"], boxes, *ocfg.axis_pool), P)
+    assert rel(out[0].pred_rot_axis, ora) < 1e-4 and rel(out[0].pred_tran_axis, ota) < 1e-4
+
+
+def test_full_batch_properties(hip_model, oracle):
+    """BASELINE-size batch (32 frames): size-independent properties instead of an oracle run."""
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    frames = oracle.synthetic_frames(32, seed=21)
+    fr = torch.from_numpy(frames).cuda()
+    out = model.inference_batched(fr)
+    out2 = model.inference_batched(fr)
+    assert torch.equal(out.records, out2.records) and torch.equal(out.depth, out2.depth)  # deterministic
+    # batch-size independence: frame 5 alone == frame 5 in the batch (no cross-frame leakage)
+    one = model.inference_batched(fr[5:6].contiguous())
+    assert torch.equal(one.records[0], out.records[5]) and torch.equal(one.depth[0], out.depth[5])
+    pb, pl, _lv, _pos, pc = out.proposals
+    assert int(pc.min()) > 500 and int(pc.max()) <= 1000
+    assert bool((pl[:, :-1] >= pl[:, 1:]).all())  # sorted
+    assert bool(((pb[..., 0] >= 0) & (pb[..., 2] <= 640) & (pb[..., 1] >= 0) & (pb[..., 3] <= 480)).all())
+    n = torch.linalg.norm(out.det.pred_plane, dim=1)
+    assert float((n - 1).abs().max()) < 1e-5  # unit normals
+    assert float((torch.linalg.norm(out.det.pred_rot_axis[:, :2], dim=1) - 1).abs().max()) < 1e-5
+    assert int(out.rec_count.sum()) == int(out.keep.sum())

@@ -1,0 +1,137 @@
+"""CPU suite, part 1: the oracle against the golden vectors produced by the REFERENCE's own modules
+(oracle/make_golden.py) and against slow literal restatements of the third-party operators."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from oracle import golden_inputs as G
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_paste_masks_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "paste_masks.npz")
+    masks, boxes, hw = G.paste_case()
+    assert abs(float(masks.double().sum()) - float(g["masks_sum"])) < 1e-9, "seeded inputs drifted"
+    out = oracle.paste_masks(masks, boxes, hw[0], hw[1], 0.5)
+    ref = np.unpackbits(g["packed"])[: int(np.prod(g["shape"]))].reshape(g["shape"]).astype(bool)
+    assert out.shape == tuple(g["shape"])
+    assert (out.numpy() != ref).sum() == 0  # bit-exact bool masks
+
+
+def test_plane_head_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "plane_head.npz")
+    x = G.head_input()
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6
+    with torch.no_grad():
+        out = oracle.plane_head(x, G.head_params("plane"))
+    np.testing.assert_allclose(out.numpy(), g["pred_plane"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(out.numpy(), axis=1), 1.0, atol=1e-6)
+
+
+def test_axis_head_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "axis_head.npz")
+    with torch.no_grad():
+        rot, tran = oracle.axis_head(G.head_input(), G.head_params("axis"))
+    np.testing.assert_allclose(rot.numpy(), g["pred_rot_axis"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tran.numpy(), g["pred_tran_axis"], rtol=1e-5, atol=1e-6)
+
+
+def test_depth_head_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "depth_head.npz")
+    with torch.no_grad():
+        d = oracle.depth_head(G.depth_features(), G.head_params("depth"))
+    assert tuple(d.shape) == tuple(g["shape"])
+    np.testing.assert_allclose(d[:, ::16, ::16].numpy(), g["depth_strided"], rtol=1e-4, atol=1e-5)
+    assert abs(float(d.double().sum()) - float(g["depth_sum"])) < 1e-4 * float(g["depth_abs_sum"])
+
+
+# ---- third-party operators (parity unpinned): C kernels vs literal python statements of Appendix A ----
+def _rand_boxes(rng, n, w=160.0, h=120.0):
+    x1 = rng.uniform(-5, w, n)
+    y1 = rng.uniform(-5, h, n)
+    bw = rng.uniform(0.5, 80, n)
+    bh = rng.uniform(0.5, 60, n)
+    return torch.tensor(np.stack([x1, y1, x1 + bw, y1 + bh], 1), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("P,ratio,aligned", [(7, 0, True), (14, 2, False), (14, 0, False)])
+def test_roi_align_c_vs_python(oracle, P, ratio, aligned):
+    rng = np.random.default_rng(P + ratio)
+    feat = torch.randn(2, 3, 30, 40)
+    boxes = _rand_boxes(rng, 6) * 0.25
+    rois = torch.cat([torch.tensor([[0.], [1.], [0.], [1.], [0.], [1.]]), boxes * 4], 1)
+    a = oracle.roi_align(feat, rois, P, 0.25, ratio, aligned)
+    b = oracle.roi_align_py(feat, rois, P, 0.25, ratio, aligned)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_roi_align_constant_and_ramp(oracle):
+    # constant map -> constant; linear ramp in x -> bin centre value (sampling is symmetric about the centre)
+    feat = torch.full((1, 1, 32, 32), 3.25)
+    rois = torch.tensor([[0, 4.0, 4.0, 100.0, 90.0]])
+    out = oracle.roi_align(feat, rois, 7, 0.25, 0, True)
+    assert torch.allclose(out, torch.full_like(out, 3.25))
+    ramp = torch.arange(32, dtype=torch.float32).view(1, 1, 1, 32).expand(1, 1, 32, 32).contiguous()
+    out = oracle.roi_align(ramp, rois, 7, 0.25, 2, True)
+    x1, x2 = 4.0 * 0.25 - 0.5, 100.0 * 0.25 - 0.5
+    centres = x1 + (torch.arange(7) + 0.5) * (x2 - x1) / 7
+    np.testing.assert_allclose(out[0, 0, 0].numpy(), centres.numpy(), rtol=1e-5)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(0, 10_000), st.integers(1, 60))
+def test_nms_c_vs_python_and_properties(seed, n):
+    from oracle import planercnn_oracle as O
+
+    rng = np.random.default_rng(seed)
+    boxes = _rand_boxes(rng, n)
+    if n > 3:  # exact duplicates and ties
+        boxes[1] = boxes[0]
+    cats = torch.tensor(rng.integers(0, 2, n))
+    keep_c = O.nms_sorted(boxes, cats, 0.5)
+    keep_py = O.nms_sorted_py(boxes, cats, 0.5)
+    assert torch.equal(keep_c, keep_py)
+    assert keep_c[0]  # the top-scoring box always survives
+    # idempotence: NMS of the kept set keeps everything
+    again = O.nms_sorted(boxes[keep_c], cats[keep_c], 0.5)
+    assert bool(again.all())
+
+
+def test_topk_stable_ties(oracle):
+    s = torch.tensor([[0.5, 0.9, 0.5, 0.9, 0.1]])
+    v, i = oracle.topk_stable(s, 3)
+    assert i.tolist() == [[1, 3, 0]] and torch.equal(v, torch.tensor([[0.9, 0.9, 0.5]]))
+
+
+def test_batched_nms_categories_do_not_interact(oracle):
+    b = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 10], [0, 0, 10, 10]])
+    keep = oracle.batched_nms(b, torch.tensor([0.9, 0.8, 0.7]), torch.tensor([0, 1, 0]), 0.5)
+    assert keep.tolist() == [0, 1]
+
+
+def test_override_depth_empty_mask_and_axis_swap(oracle):
+    depth = torch.full((480, 640), 2.0)
+    rays = oracle.k_inv_dot_xy1()
+    masks = torch.zeros(2, 480, 640, dtype=torch.bool)
+    masks[1, 200:280, 300:340] = True
+    planes = torch.tensor([[0.0, 0.6, 0.8], [0.0, 0.0, 1.0]])
+    out = oracle.override_depth(depth, masks, planes, rays)
+    # empty mask keeps the plane (swap forth and back = identity)
+    np.testing.assert_allclose(out[0].numpy(), planes[0].numpy(), atol=1e-7)
+    # normal (0,0,1) -> swapped (0,-1,0): offset = mean(-Y) over the mask; rows 200..279 are above the principal point
+    ys = (np.arange(200, 280) - 239.5) / 571.623718 * 2.0
+    off = -ys.mean()
+    np.testing.assert_allclose(out[1].numpy(), [0.0, 0.0, off], rtol=1e-5, atol=1e-6)
+
+
+def test_detect_runs_and_filters(oracle, oracle_params):
+    frames = oracle.synthetic_frames(1)
+    outs = oracle.detect(oracle.frames_to_chw(frames), oracle_params, oracle.OracleCfg(score_thresh=0.7))
+    assert len(outs[0]["scores"]) == 0 and outs[0]["pred_masks"].shape == (0, 480, 640)
+    assert outs[0]["depth"].shape == (480, 640)
