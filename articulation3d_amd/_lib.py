@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("Kpad", C.c_int), ("ups", C.c_int), ("act", C.c_int), ("res_ups", C.c_int), ("pixshuf", C.c_int),
         ("stem", C.c_int), ("splitk", C.c_int),
         ("m_dev", fptr),
+        ("tune", C.c_int),
     ]
 
 

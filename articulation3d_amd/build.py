@@ -21,6 +21,7 @@ ARCH = "gfx950"
 # mul/add/div operators, hence -ffp-contract=off for those translation units.
 SOURCES = {
     "conv_gemm.hip": [],
+    "conv_gemm_v2.hip": [],
     "spatial_ops.hip": [],
     "roi_align.hip": ["-ffp-contract=off"],  # sample coordinates ~1e2 px: an FMA-rounded coordinate moves the bilinear weights by 1e-5
     "proposals.hip": ["-ffp-contract=off"],
@@ -39,7 +40,7 @@ def _hipcc() -> str:
 
 def _stamp(path: str, flags) -> str:
     h = hashlib.sha1()
-    for p in (path, os.path.join(CSRC, "a3d_common.h"), os.path.join(PKG_DIR, "..", "include", "a3d.h")):
+    for p in (path, os.path.join(CSRC, "a3d_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(PKG_DIR, "..", "include", "a3d.h")):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(COMMON + list(flags)).encode())

@@ -1,0 +1,314 @@
+// conv-GEMM v2: same math, tiling, LDS image and epilogue as conv_gemm.hip (see the header comment there),
+// re-built around what the v1 profile showed (MFMA pipe 76 % busy, the rest lost in a branchy 64-bit gather
+// that ran BEFORE the MFMA block and a write-back + barrier that ran AFTER it):
+//
+//  * gather through BUFFER loads: every operand is addressed as rsrc + 32-bit byte offset; a tap that falls
+//    into the zero padding (or a row past M / Cout) gets offset 0xFFFFFFFF, which the hardware range check
+//    turns into a zero result -- no exec-mask branches, no 64-bit address arithmetic.  Per-row validity of
+//    all KH*KW taps is one precomputed bitmask; per k-chunk the lane work is 1 add + 1 bit test + 1 select.
+//  * the main loop is ONE basic block: the LDS write-back of chunk t+1 (loaded during iteration t-1) and
+//    the global loads of chunk t+2 are issued in the shadow of the 64 MFMAs of chunk t (each fp32 32x32x2
+//    MFMA occupies the matrix pipe for 64 cycles but only a few issue cycles), fragments are double-buffered
+//    in registers, one barrier per chunk.
+#include "conv_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_GENERIC = 0, MODE_UPS = 1, MODE_STEM = 2 };
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// uniform (scalar) position of the current k-chunk inside the filter
+struct ChunkPos {
+    int kc;       // chunk index (k = 32*kc)
+    int c0;       // first channel of the chunk inside the concatenated input
+    int kh, kw;   // filter tap
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(const a3d_conv_desc d, const int Mmax,
+                                                                              const int ntiles, const int nblk,
+                                                                              const int kt_total, const int kt_per_split) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int RPP = NT / 8;  // tile rows covered by one pass of the workgroup (8 lanes x 16 B per 32-float row)
+    constexpr int XR = BM / RPP, WR = BN / RPP;
+    constexpr int BUF = (BM + BN) * LDK;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the loader pass");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int M = d.m_dev ? min(Mmax, *d.m_dev) : Mmax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    if (m0 >= M) return;
+    const int z = blockIdx.y;
+    const int kt_begin = z * kt_per_split;
+    const int kt_end = min(kt_total, kt_begin + kt_per_split);
+    const int nk = kt_end - kt_begin;
+
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const int CinT = (MODE == MODE_STEM) ? 32 : d.Cin + d.Cin2;
+    const int cs4 = (MODE == MODE_STEM) ? 16 : d.Cin * 4;  // bytes between consecutive pixels of a source
+    const unsigned xbytes = (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, xbytes);
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(d.x2 ? d.x2 : d.x, xbytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
+
+    // ---- per-row loop invariants ---------------------------------------------------------------
+    int rowoff[XR];      // GENERIC/STEM: byte offset of (b, ih0, iw0[+j], lc) -- may be "negative", used mod 2^32
+    unsigned vmask[XR];  // bit t set <=> filter tap t of this row reads inside the image
+    int uih0[XR], uiw0[XR], uboff[XR];  // UPS only
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = m0 + lr + RPP * i;
+        const bool rok = m < M;
+        const int mm = rok ? m : 0;
+        const int hw = d.Ho * d.Wo;
+        const int b = mm / hw;
+        const int r = mm - b * hw;
+        const int oh = r / d.Wo, ow = r - oh * d.Wo;
+        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        unsigned mask = 0;
+        if (MODE == MODE_STEM) {
+            const int j = tid & 7;
+            const bool jok = rok && j < 7 && (unsigned)(iw0 + j) < (unsigned)d.W;
+            for (int kh = 0; kh < 7; ++kh) mask |= (jok && (unsigned)(ih0 + kh) < (unsigned)d.H) ? (1u << kh) : 0u;
+            rowoff[i] = ((b * d.H + ih0) * d.W + iw0 + j) * 16;
+        } else {
+            const int Hl = (MODE == MODE_UPS) ? 2 * d.H : d.H, Wl = (MODE == MODE_UPS) ? 2 * d.W : d.W;
+            for (int kh = 0; kh < d.KH; ++kh)
+                for (int kw = 0; kw < d.KW; ++kw)
+                    mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)Hl && (unsigned)(iw0 + kw) < (unsigned)Wl) ? (1u << (kh * d.KW + kw)) : 0u;
+            rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        }
+        vmask[i] = mask;
+        uih0[i] = ih0;
+        uiw0[i] = iw0;
+        uboff[i] = b * d.H * d.W;
+    }
+    int woff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int n = n0 + lr + RPP * i;
+        woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
+    }
+
+    ChunkPos pos;
+    pos.kc = kt_begin;
+    if (MODE == MODE_STEM) {
+        pos.c0 = 0;
+        pos.kh = kt_begin;
+        pos.kw = 0;
+    } else {
+        const int kk = kt_begin * BK;
+        const int tap = kk / CinT;
+        pos.c0 = kk - tap * CinT;
+        pos.kh = tap / d.KW;
+        pos.kw = tap - pos.kh * d.KW;
+    }
+    auto advance = [&]() {
+        ++pos.kc;
+        if (MODE == MODE_STEM) {
+            ++pos.kh;
+        } else {
+            pos.c0 += BK;
+            if (pos.c0 >= CinT) {
+                pos.c0 = 0;
+                if (++pos.kw == d.KW) {
+                    pos.kw = 0;
+                    ++pos.kh;
+                }
+            }
+        }
+    };
+
+    f32x4 xs[XR], ws[WR];
+    // issue the global loads of the chunk at `pos` (all-zero when `live` is false: branch-free tail)
+    auto load_x = [&](bool live) {
+        const int tap = (MODE == MODE_STEM) ? pos.kh : pos.kh * d.KW + pos.kw;
+        const bool second = (MODE != MODE_STEM) && pos.c0 >= d.Cin;
+        const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
+        const unsigned livebit = (live && tap < 32) ? 1u : 0u;
+        if (MODE == MODE_UPS) {
+            const int ccb = (second ? pos.c0 - d.Cin : pos.c0) * 4 + lc * 4;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int ih = (uih0[i] + pos.kh) >> 1, iw = (uiw0[i] + pos.kw) >> 1;
+                const int off = (uboff[i] + ih * d.W + iw) * cs4 + ccb;
+                const bool ok = ((vmask[i] >> (tap & 31)) & livebit) != 0;
+                xs[i] = buf_load4(r, ok ? off : -1, 0);
+            }
+        } else {
+            const int tapoff = (MODE == MODE_STEM) ? pos.kh * d.W * 16
+                                                   : (pos.kh * d.W + pos.kw) * cs4 + (second ? pos.c0 - d.Cin : pos.c0) * 4;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const bool ok = ((vmask[i] >> (tap & 31)) & livebit) != 0;
+                xs[i] = buf_load4(r, ok ? rowoff[i] + tapoff : -1, 0);
+            }
+        }
+    };
+    auto load_w = [&](bool live) {
+        const int soff = pos.kc * (BK * 4);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ws[i] = buf_load4(rw, live ? woff[i] : -1, soff);
+    };
+    auto store_chunk = [&](int buf) {
+        float *X = lds + buf * BUF;
+        float *Wt = X + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) *reinterpret_cast<f32x4 *>(X + (lr + RPP * i) * LDK + lc) = xs[i];
+#pragma unroll
+        for (int i = 0; i < WR; ++i) *reinterpret_cast<f32x4 *>(Wt + (lr + RPP * i) * LDK + lc) = ws[i];
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- prologue: chunk 0 -> LDS[0]; chunk 1 -> registers -----------------------------------------
+    load_x(nk > 0);
+    load_w(nk > 0);
+    advance();
+    store_chunk(0);
+    load_x(nk > 1);
+    load_w(nk > 1);
+    advance();
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LDK + (lane >> 5) * 4;
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        const float *X = lds + cur * BUF + (wm * TM * 32) * LDK + frag_off;
+        const float *Wt = lds + cur * BUF + BM * LDK + (wn * TN * 32) * LDK + frag_off;
+        f32x4 fa[2][TN], fb[2][TM];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LDK);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) fb[0][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LDK);
+        // chunk it+1 (in registers since the previous iteration) -> the other LDS buffer.  Harmless when it is the
+        // tail (zeros into a buffer nobody reads again).
+        store_chunk(cur ^ 1);
+        const bool live2 = it + 2 < nk;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            const int fc = q & 1, fn = fc ^ 1;
+            if (q + 1 < BK / 8) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) fa[fn][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LDK + (q + 1) * 8);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) fb[fn][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LDK + (q + 1) * 8);
+            }
+            if (q == 1) load_x(live2);  // chunk it+2 -> registers (freed by store_chunk above)
+            if (q == 2) {
+                load_w(live2);
+                advance();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][mi][j], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to v1) ------------------------------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
+        if (m >= M) continue;
+        size_t res_row;
+        int b, oh, ow;
+        out_rows(d, m, res_row, b, oh, ow);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                if (n >= d.Cout) continue;
+                f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2],
+                           acc[ni][mi][rg * 4 + 3]};
+                if (d.splitk > 1) {
+                    *reinterpret_cast<f32x4 *>(d.workspace + ((size_t)z * Mmax + m) * d.Cout + n) = v;
+                } else {
+                    v = apply_epilogue(d, v, n, res_row);
+                    store_out(d, v, m, n, b, oh, ow);
+                }
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE>
+static void launch_v2(const a3d_conv_desc *d, hipStream_t s) {
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    const int nblk = mtiles * ntiles;
+    const int kt_total = d->Kpad / BK;
+    const int kps = (kt_total + d->splitk - 1) / d->splitk;
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<WAVES_M, WAVES_N, TM, TN, MODE>), dim3(nblk, d->splitk), dim3(WAVES_M * WAVES_N * 64), 0,
+                       s, *d, M, ntiles, nblk, kt_total, kps);
+}
+
+__global__ __launch_bounds__(256) void conv_splitk_reduce_v2_kernel(const a3d_conv_desc d, const int Mmax) {
+    const int M = d.m_dev ? min(Mmax, *d.m_dev) : Mmax;
+    const int n4 = d.Cout >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4);
+        const int n = (int)(i - (size_t)m * n4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < d.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(d.workspace + ((size_t)z * Mmax + m) * d.Cout + n);
+        size_t res_row;
+        int b, oh, ow;
+        out_rows(d, m, res_row, b, oh, ow);
+        v = apply_epilogue(d, v, n, res_row);
+        store_out(d, v, m, n, b, oh, ow);
+    }
+}
+
+int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
+    const size_t lim = (size_t)1 << 32;
+    const size_t cs = d->stem ? 4 : (size_t)d->Cin;
+    if ((size_t)d->B * d->H * d->W * cs * 4 >= lim || (size_t)d->Cout * d->Kpad * 4 >= lim) return A3D_ERR_UNSUPPORTED;
+    if (!d->stem) {
+        if (d->Cin2 && d->Cin2 != d->Cin) return A3D_ERR_UNSUPPORTED;
+        if (d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
+    }
+    if (d->stem) {
+        launch_v2<4, 1, 2, 2, MODE_STEM>(d, s);
+    } else if (d->ups) {
+        if (d->Cout <= 32) launch_v2<4, 1, 1, 1, MODE_UPS>(d, s);
+        else if (d->Cout <= 64) launch_v2<4, 1, 2, 2, MODE_UPS>(d, s);
+        else launch_v2<2, 2, 2, 2, MODE_UPS>(d, s);
+    } else {
+        if (d->Cout <= 32) launch_v2<4, 1, 1, 1, MODE_GENERIC>(d, s);
+        else if (d->Cout <= 64) launch_v2<4, 1, 2, 2, MODE_GENERIC>(d, s);
+        else launch_v2<2, 2, 2, 2, MODE_GENERIC>(d, s);
+    }
+    if (d->splitk > 1) {
+        const int M = d->B * d->Ho * d->Wo;
+        const size_t total = (size_t)M * (d->Cout >> 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv_splitk_reduce_v2_kernel, dim3(blocks), dim3(256), 0, s, *d, M);
+    }
+    return a3d_check_launch();
+}

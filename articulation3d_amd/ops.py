@@ -164,7 +164,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 # --------------------------------------------------------------------------------------------------
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
-           m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -189,6 +189,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     d.Kpad, d.ups, d.act = p.Kpad, int(ups), p.act if act is None else act
     d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), int(p.pixshuf), int(p.stem), int(splitk)
     d.m_dev = _p(m_dev)
+    d.tune = int(tune)
     ws = None
     if splitk > 1:
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))

@@ -73,6 +73,7 @@ typedef struct a3d_conv_desc {
     int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch            */
     const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
                          so ragged per-ROI batches need no host synchronisation                      */
+    int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel      */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
