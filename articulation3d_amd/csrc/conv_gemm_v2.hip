@@ -31,15 +31,18 @@ struct ChunkPos {
     int kh, kw;   // filter tap
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE, int PIPE, int BKT>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(const a3d_conv_desc d, const int Mmax,
                                                                               const int ntiles, const int nblk,
                                                                               const int kt_total, const int kt_per_split) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int RPP = NT / 8;  // tile rows covered by one pass of the workgroup (8 lanes x 16 B per 32-float row)
+    constexpr int LK = BKT + 4;   // padded LDS row (floats): 36 / 20 both tile the 64 banks exactly per b128 lane group
+    constexpr int TPR = BKT / 4;  // lanes (x 16 B) per tile row
+    constexpr int RPP = NT / TPR; // tile rows covered by one pass of the workgroup
+    static_assert(MODE != MODE_STEM || BKT == 32, "the stem packs one 7-tap filter row into a 32-float chunk");
     constexpr int XR = BM / RPP, WR = BN / RPP;
-    constexpr int BUF = (BM + BN) * LDK;
+    constexpr int BUF = (BM + BN) * LK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the loader pass");
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
     const int kt_end = min(kt_total, kt_begin + kt_per_split);
     const int nk = kt_end - kt_begin;
 
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
     const int CinT = (MODE == MODE_STEM) ? 32 : d.Cin + d.Cin2;
     const int cs4 = (MODE == MODE_STEM) ? 16 : d.Cin * 4;  // bytes between consecutive pixels of a source
     const unsigned xbytes = (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4);
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         pos.kh = kt_begin;
         pos.kw = 0;
     } else {
-        const int kk = kt_begin * BK;
+        const int kk = kt_begin * BKT;
         const int tap = kk / CinT;
         pos.c0 = kk - tap * CinT;
         pos.kh = tap / d.KW;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         if (MODE == MODE_STEM) {
             ++pos.kh;
         } else {
-            pos.c0 += BK;
+            pos.c0 += BKT;
             if (pos.c0 >= CinT) {
                 pos.c0 = 0;
                 if (++pos.kw == d.KW) {
@@ -158,17 +161,17 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         }
     };
     auto load_w = [&](bool live) {
-        const int soff = pos.kc * (BK * 4);
+        const int soff = pos.kc * (BKT * 4);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = buf_load4(rw, live ? woff[i] : -1, soff);
     };
     auto store_chunk = [&](int buf) {
         float *X = lds + buf * BUF;
-        float *Wt = X + BM * LDK;
+        float *Wt = X + BM * LK;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) *reinterpret_cast<f32x4 *>(X + (lr + RPP * i) * LDK + lc) = xs[i];
+        for (int i = 0; i < XR; ++i) *reinterpret_cast<f32x4 *>(X + (lr + RPP * i) * LK + lc) = xs[i];
 #pragma unroll
-        for (int i = 0; i < WR; ++i) *reinterpret_cast<f32x4 *>(Wt + (lr + RPP * i) * LDK + lc) = ws[i];
+        for (int i = 0; i < WR; ++i) *reinterpret_cast<f32x4 *>(Wt + (lr + RPP * i) * LK + lc) = ws[i];
     };
 
     f32x16 acc[TN][TM];
@@ -189,31 +192,31 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
     advance();
     __syncthreads();
 
-    const int frag_off = (lane & 31) * LDK + (lane >> 5) * 4;
+    const int frag_off = (lane & 31) * LK + (lane >> 5) * 4;
     for (int it = 0; it < nk; ++it) {
         const int cur = it & 1;
-        const float *X = lds + cur * BUF + (wm * TM * 32) * LDK + frag_off;
-        const float *Wt = lds + cur * BUF + BM * LDK + (wn * TN * 32) * LDK + frag_off;
+        const float *X = lds + cur * BUF + (wm * TM * 32) * LK + frag_off;
+        const float *Wt = lds + cur * BUF + BM * LK + (wn * TN * 32) * LK + frag_off;
         f32x4 fa[2][TN], fb[2][TM];
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LDK);
+        for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK);
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) fb[0][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LDK);
+        for (int mi = 0; mi < TM; ++mi) fb[0][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LK);
         // chunk it+1 (in registers since the previous iteration) -> the other LDS buffer.  Harmless when it is the
         // tail (zeros into a buffer nobody reads again).
         store_chunk(cur ^ 1);
         const bool live2 = it + 2 < nk;
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
+        for (int q = 0; q < BKT / 8; ++q) {
             const int fc = q & 1, fn = fc ^ 1;
-            if (q + 1 < BK / 8) {
+            if (q + 1 < BKT / 8) {
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) fa[fn][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LDK + (q + 1) * 8);
+                for (int ni = 0; ni < TN; ++ni) fa[fn][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK + (q + 1) * 8);
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) fb[fn][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LDK + (q + 1) * 8);
+                for (int mi = 0; mi < TM; ++mi) fb[fn][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LK + (q + 1) * 8);
             }
-            if (q == 1) load_x(live2);  // chunk it+2 -> registers (freed by store_chunk above)
-            if (q == 2) {
+            if (q == (PIPE ? 0 : 1)) load_x(live2);  // chunk it+2 -> registers (freed by store_chunk above)
+            if (q == (PIPE ? 1 : 2)) {
                 load_w(live2);
                 advance();
             }
@@ -255,15 +258,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE, int PIPE = 1, int BKT = 32>
 static void launch_v2(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
     const int nblk = mtiles * ntiles;
-    const int kt_total = d->Kpad / BK;
+    const int kt_total = d->Kpad / BKT;
     const int kps = (kt_total + d->splitk - 1) / d->splitk;
-    hipLaunchKernelGGL((conv_gemm_v2_kernel<WAVES_M, WAVES_N, TM, TN, MODE>), dim3(nblk, d->splitk), dim3(WAVES_M * WAVES_N * 64), 0,
+    hipLaunchKernelGGL((conv_gemm_v2_kernel<WAVES_M, WAVES_N, TM, TN, MODE, PIPE, BKT>), dim3(nblk, d->splitk), dim3(WAVES_M * WAVES_N * 64), 0,
                        s, *d, M, ntiles, nblk, kt_total, kps);
 }
 
@@ -292,19 +295,38 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
         if (d->Cin2 && d->Cin2 != d->Cin) return A3D_ERR_UNSUPPORTED;
         if (d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
     }
+    // ---- variant selection ---------------------------------------------------------------------------
+    // Tile shape never changes the summation order of an output element (k runs in chunk order inside one
+    // accumulator), so it may depend on the row count; measured on MI355X (tools/conv_bench.py, one process):
+    //   * BK=16 (LDS 40 KiB / 30 KiB per workgroup -> 3-5 workgroups per CU) beats BK=32 (2 per CU) by 3-25 %
+    //     everywhere except the very deep 1x1 GEMMs (box-head fc1, K=12544), where fewer barriers win;
+    //   * 128x64 tiles beat 128x128 whenever the 128x128 grid would be under ~4 rounds of the chip (res4/res5,
+    //     p4-p6 levels, per-ROI heads) or Cout <= 64.
+    const int M = d->B * d->Ho * d->Wo;
+    const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
+    int cfg = d->Cout <= 32 ? 2 : ((d->Cout <= 64 || n128 <= 1000) ? 1 : 0);  // 0: 128x128, 1: 128x64, 2: 128x32
+    int bk16 = !(d->KH * d->KW == 1 && d->Kpad >= 8192);
+    if (d->tune >= 100) {  // explicit variant for A/B measurements: 100 + 10*cfg + (bk16 ? 1 : 0)
+        cfg = (d->tune - 100) / 10;
+        bk16 = (d->tune - 100) % 10;
+        if (cfg > 2 || bk16 > 1) return A3D_ERR_ARG;
+    }
     if (d->stem) {
-        launch_v2<4, 1, 2, 2, MODE_STEM>(d, s);
+        launch_v2<4, 1, 2, 2, MODE_STEM, 1, 32>(d, s);
     } else if (d->ups) {
-        if (d->Cout <= 32) launch_v2<4, 1, 1, 1, MODE_UPS>(d, s);
-        else if (d->Cout <= 64) launch_v2<4, 1, 2, 2, MODE_UPS>(d, s);
-        else launch_v2<2, 2, 2, 2, MODE_UPS>(d, s);
+        if (cfg == 0) launch_v2<2, 2, 2, 2, MODE_UPS, 1, 16>(d, s);
+        else if (cfg == 1) launch_v2<2, 2, 2, 1, MODE_UPS, 1, 16>(d, s);
+        else launch_v2<4, 1, 1, 1, MODE_UPS, 1, 32>(d, s);
     } else {
-        if (d->Cout <= 32) launch_v2<4, 1, 1, 1, MODE_GENERIC>(d, s);
-        else if (d->Cout <= 64) launch_v2<4, 1, 2, 2, MODE_GENERIC>(d, s);
-        else launch_v2<2, 2, 2, 2, MODE_GENERIC>(d, s);
+        switch (cfg * 2 + bk16) {
+            case 0: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 32>(d, s); break;
+            case 1: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 16>(d, s); break;
+            case 2: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 32>(d, s); break;
+            case 3: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 16>(d, s); break;
+            default: launch_v2<4, 1, 1, 1, MODE_GENERIC, 1, 32>(d, s); break;  // 128x32 tile: BK=32 only
+        }
     }
     if (d->splitk > 1) {
-        const int M = d->B * d->Ho * d->Wo;
         const size_t total = (size_t)M * (d->Cout >> 2);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;

@@ -24,15 +24,15 @@ GROUP_CAP = 1024
 CONV_TIMING: Optional[list] = None
 
 
-def conv_tile_config(p: "PackedConv") -> str:
-    """Mirror of the dispatch in csrc/conv_gemm.hip:a3d_conv2d_nhwc_f32."""
+def conv_tile_config(p: "PackedConv", M: int, ups: bool = False) -> str:
+    """Mirror of the variant selection in csrc/conv_gemm_v2.hip:a3d_conv_launch_v2 (kernel template arguments
+    <WAVES_M,WAVES_N,TM,TN,MODE,PIPE,BK> as they appear in a rocprofv3 kernel trace)."""
     if p.stem:
-        return "conv_gemm<4,1,2,2,stem> 256x64"
-    if p.cols <= 32:
-        return "conv_gemm<4,1,1,1> 128x32"
-    if p.cols <= 64:
-        return "conv_gemm<4,1,2,2> 256x64"
-    return "conv_gemm<2,2,2,2> 128x128"
+        return "conv_gemm_v2<4,1,2,2,stem,bk32> 256x64"
+    n128 = ((M + 127) // 128) * ((p.cols + 127) // 128)
+    cfg = 2 if p.cols <= 32 else (1 if (p.cols <= 64 or n128 <= 1000) else 0)
+    bk = 32 if (p.KH * p.KW == 1 and p.Kpad >= 8192) or cfg == 2 else 16
+    return {0: "conv_gemm_v2<2,2,2,2> 128x128", 1: "conv_gemm_v2<2,2,2,1> 128x64", 2: "conv_gemm_v2<4,1,1,1> 128x32"}[cfg] + f" bk{bk}"
 
 
 def _stream() -> int:
@@ -201,7 +201,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
         k_real = 147 if p.stem else p.KH * p.KW * p.Cin
-        CONV_TIMING.append((conv_tile_config(p), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1,
+        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1,
                             f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")

@@ -28,31 +28,49 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride, ups
 
 
 def main():
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    """conv_bench.py [rounds] [filter] [tune,tune,...]: variants are interleaved round by round in ONE process
+    (cross-process / cross-device timings are not comparable); prints the median ms and TF/s per variant."""
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
-    tune = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    tunes = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
     torch.manual_seed(0)
-    tot_ms = tot_fl = 0.0
+    tot = {t: 0.0 for t in tunes}
+    tot_fl = 0.0
+    print(f"{'shape':28s} {'GFLOP':>8s} " + " ".join(f"{'t' + str(t):>16s}" for t in tunes))
     for name, B, H, W, Cin, Cout, k, s, ups in SHAPES:
         if filt not in name:
             continue
         x = torch.randn(B, H, W, Cin, device="cuda")
         w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
         p = ops.pack_conv(w, torch.randn(Cout), None, s, k // 2, ops.ACT_RELU)
-        y = ops.conv2d(x, p, ups=bool(ups), tune=tune)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.conv2d(x, p, ups=bool(ups), out=y, tune=tune)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        y = ops.conv2d(x, p, ups=bool(ups))
         fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k
-        tot_ms += ms
+        times = {t: [] for t in tunes}
+        ok = {t: True for t in tunes}
+        for r in range(rounds + 1):
+            for t in tunes:
+                try:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        ops.conv2d(x, p, ups=bool(ups), out=y, tune=t)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r:
+                        times[t].append(e0.elapsed_time(e1) / 3)
+                except RuntimeError:
+                    ok[t] = False
         tot_fl += fl
-        print(f"{name:28s} {fl / 1e9:9.1f} GFLOP {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF/s", flush=True)
-    print(f"{'TOTAL':28s} {tot_fl / 1e9:9.1f} GFLOP {tot_ms:8.3f} ms {tot_fl / tot_ms / 1e9:7.1f} TF/s")
+        cells = []
+        for t in tunes:
+            if ok[t] and times[t]:
+                ms = sorted(times[t])[len(times[t]) // 2]
+                tot[t] += ms
+                cells.append(f"{ms:7.3f}ms {fl / ms / 1e9:6.1f}")
+            else:
+                cells.append(f"{'n/a':>16s}")
+        print(f"{name:28s} {fl / 1e9:8.1f} " + " ".join(f"{c:>16s}" for c in cells), flush=True)
+    print(f"{'TOTAL':28s} {tot_fl / 1e9:8.1f} " + " ".join(f"{tot[t]:7.3f}ms {tot_fl / max(tot[t], 1e-9) / 1e9:6.1f}" for t in tunes))
 
 
 if __name__ == "__main__":
