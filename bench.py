@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of B=32 synthetic 480x640 uint8 BGR frames (resident in HBM) through the whole
+One "step" = one 64-frame clip (BASELINE configs[2]) of synthetic 480x640 uint8 BGR frames (resident in HBM) through the whole
 detector: normalise -> ResNet50-FPN -> RPN (top-k, NMS) -> ROIAlign -> box head -> detection NMS -> mask /
 plane / axis heads -> depth head -> fused post-process + mask paste + plane-offset LSQ -> packed detection
 records (+ an RCCL all-gather of the records when N > 1: frames are sharded across ranks, weak scaling).
@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (BASELINE configs[2]: a 64-frame clip)")
     ap.add_argument("--score-thresh", type=float, default=0.5,
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
