@@ -7,6 +7,11 @@
 // output bin, lane l owns channels 4l..4l+3 (C = 256 -> exactly one float4 per lane), so every corner
 // read and the bin store are 1 KiB coalesced accesses.  One workgroup (4 waves) owns one ROI and
 // walks its P*P bins; the ROI geometry is computed once per workgroup.
+//
+// Measured alternative (round 1, rejected): staging each ROI's cell window in LDS per 32-channel slice
+// (one workgroup per ROI x slice, then bins from LDS) ran the 7x7 box pooler in 3.07 ms per 32 frames
+// against 1.93 ms for this direct form: proposal windows are only ~100 cells, so the extra workgroups,
+// barrier and 12-wave occupancy cost more than the duplicate corner reads that L2 already absorbs.
 #include "a3d_common.h"
 #include "../../include/a3d.h"
 
