@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
         ("Kpad", C.c_int), ("ups", C.c_int), ("act", C.c_int), ("res_ups", C.c_int), ("pixshuf", C.c_int),
         ("stem", C.c_int), ("splitk", C.c_int),
         ("m_dev", fptr),
-        ("tune", C.c_int),
+        ("tune", C.c_int), ("phase", C.c_int),
+        ("w_wino", fptr),
     ]
 
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ f32x4 apply_epilogue(const a3d_conv_desc &d, f32x4 v,
 __device__ __forceinline__ void out_rows(const a3d_conv_desc &d, int m, size_t &res_row, int &b, int &oh, int &ow) {
     res_row = (size_t)m;
     b = oh = ow = 0;
-    if (d.res_ups || d.pixshuf) {
+    if (d.res_ups || d.pixshuf || d.phase) {
         const int hw = d.Ho * d.Wo;
         b = m / hw;
         const int r = m - b * hw;
@@ -49,7 +49,11 @@ __device__ __forceinline__ void out_rows(const a3d_conv_desc &d, int m, size_t &
 }
 
 __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m, int n, int b, int oh, int ow) {
-    if (d.pixshuf) {
+    if (d.phase) {
+        const int dy = (d.phase - 1) >> 1, dx = (d.phase - 1) & 1;
+        const size_t row = ((size_t)b * (2 * d.Ho) + (2 * oh + dy)) * (size_t)(2 * d.Wo) + (2 * ow + dx);
+        *reinterpret_cast<f32x4 *>(d.y + row * d.Cout + n) = v;
+    } else if (d.pixshuf) {
         const int co_n = d.Cout >> 2;  // real output channels
         const int q = n / co_n, co = n - q * co_n;
         const int dy = q >> 1, dx = q & 1;
@@ -64,3 +68,8 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
 // v2 kernel family (conv_gemm_v2.hip): buffer-addressed, branch-free gather + software-pipelined main loop.
 // Returns A3D_ERR_UNSUPPORTED when the descriptor needs the general kernel.
 int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
+
+// Winograd F(2x2,3x3) path (conv_wino.hip).  eligible() ignores the workspace pointer (used for sizing).
+int a3d_wino_eligible(const a3d_conv_desc *d);
+size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d);
+int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s);

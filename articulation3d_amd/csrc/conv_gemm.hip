@@ -218,13 +218,16 @@ static int conv_check(const a3d_conv_desc *d) {
         if (d->Kpad < d->KH * d->KW * (d->Cin + d->Cin2)) return A3D_ERR_ARG;
     }
     if (d->pixshuf && (d->Cout & 15)) return A3D_ERR_ARG;
+    if (d->phase < 0 || d->phase > 4) return A3D_ERR_ARG;
     if (d->splitk > 1 && !d->workspace) return A3D_ERR_ARG;
     if ((size_t)d->B * d->H * d->W >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
     return A3D_OK;
 }
 
 extern "C" size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d) {
-    if (!d || d->splitk <= 1) return 0;
+    if (!d) return 0;
+    if ((d->tune == 0 || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
+    if (d->splitk <= 1) return 0;
     return (size_t)d->splitk * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
@@ -253,10 +256,12 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
     if (rc != A3D_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     a3d_begin();
+    if ((d->tune == 0 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
     if (d->tune != 1) {  // tune == 1 forces the general kernel (A/B measurements, fallback)
         const int r2 = a3d_conv_launch_v2(d, s);
         if (r2 != A3D_ERR_UNSUPPORTED) return r2;
     }
+    if (d->phase) return A3D_ERR_UNSUPPORTED;  // the phase form only exists in the v2 family
     if (d->stem) return launch_cfg<4, 1, 2, 2, true>(d, s);
     if (d->Cout <= 32) return launch_cfg<4, 1, 1, 1, false>(d, s);
     if (d->Cout <= 64) return launch_cfg<4, 1, 2, 2, false>(d, s);

@@ -79,7 +79,11 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         const int b = mm / hw;
         const int r = mm - b * hw;
         const int oh = r / d.Wo, ow = r - oh * d.Wo;
-        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        if (d.phase) {  // 2x2 taps of output phase (dy,dx) on the source grid
+            ih0 = oh - 1 + ((d.phase - 1) >> 1);
+            iw0 = ow - 1 + ((d.phase - 1) & 1);
+        }
         unsigned mask = 0;
         if (MODE == MODE_STEM) {
             const int j = tid & 7;
@@ -291,6 +295,8 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
     const size_t lim = (size_t)1 << 32;
     const size_t cs = d->stem ? 4 : (size_t)d->Cin;
     if ((size_t)d->B * d->H * d->W * cs * 4 >= lim || (size_t)d->Cout * d->Kpad * 4 >= lim) return A3D_ERR_UNSUPPORTED;
+    if (d->phase && (d->stem || d->ups || d->KH != 2 || d->KW != 2 || d->stride != 1 || d->splitk != 1 || d->res || d->pixshuf))
+        return A3D_ERR_ARG;
     if (!d->stem) {
         if (d->Cin2 && d->Cin2 != d->Cin) return A3D_ERR_UNSUPPORTED;
         if (d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;

@@ -1,0 +1,300 @@
+// 3x3 stride-1 pad-1 convolutions as Winograd F(2x2, 3x3) on the fp32 MFMA pipe (gfx950).
+//
+// The direct implicit GEMM spends 9*C multiply-adds per output; F(2x2,3x3) needs 16*C per 2x2 output tile
+// = 4*C per output: 2.25x fewer MFMA cycles on layers that are MFMA-bound (3x3 convs are ~70 % of the
+// detector's FLOPs).  fp32 error vs float64 is ~2x the direct form's (6e-7 vs 3e-7 relative on a 256-channel
+// layer), well inside the path's tolerances.  Y = A^T [ (G g G^T) . (B^T d B) ] A with
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
+//
+// Two launches per layer:
+//  1. wino_input_kernel  (HBM-bound): d -> V[f][tile][c], f = 4u+v, 16 planes.  The nearest-x2 upsampling and the
+//     2-source channel concat of the depth decoder are folded into its gather, like in the direct kernel.
+//  2. wino_gemm_kernel   (MFMA-bound): per workgroup 64 tiles x (32*TN*2) channels; for each of the 16 frequency
+//     planes a plain GEMM over C (operands streamed with buffer loads through a double-buffered LDS image,
+//     same fragment layout / k-permutation / bank padding as conv_gemm_v2), whose accumulator M_f is folded into
+//     the four output accumulators Y_ij += A^T[i][u] A^T[j][v] M_f (coefficients 0/+-1) -- the 16 products are
+//     never written to memory.  Epilogue: folded BN scale/shift + activation, float4 NHWC stores.
+// Weights are transformed once on the host side at pack time (U = G g G^T, [16][Cout][Cin]).
+#include "conv_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wmake_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. input transform.  One thread = (tile, channel quad); 16 guarded float4 loads, 32+32 adds, 16 stores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                         float *__restrict__ V, int B, int H, int W, int Cin, int Cin2,
+                                                         int ups, int Ty, int Tx) {
+    const int C = Cin + Cin2, C4 = C >> 2;
+    const int Hl = ups ? 2 * H : H, Wl = ups ? 2 * W : W;
+    const size_t T = (size_t)B * Ty * Tx;
+    const size_t total = T * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const size_t t = i / C4;
+        const int tx = (int)(t % Tx);
+        const size_t r = t / Tx;
+        const int ty = (int)(r % Ty);
+        const int b = (int)(r / Ty);
+        const bool second = c >= Cin;
+        const float *src = second ? x2 : x;
+        const int cs = second ? Cin2 : Cin, cc = second ? c - Cin : c;
+        f32x4 d[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ly = 2 * ty - 1 + p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lx = 2 * tx - 1 + q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl) {
+                    const int sy = ups ? ly >> 1 : ly, sx = ups ? lx >> 1 : lx;
+                    v = *reinterpret_cast<const f32x4 *>(src + (((size_t)b * H + sy) * W + sx) * cs + cc);
+                }
+                d[p][q] = v;
+            }
+        }
+        f32x4 m[4][4];  // B^T d
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            m[0][q] = d[0][q] - d[2][q];
+            m[1][q] = d[1][q] + d[2][q];
+            m[2][q] = d[2][q] - d[1][q];
+            m[3][q] = d[1][q] - d[3][q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (B^T d) B
+            const f32x4 v0 = m[u][0] - m[u][2], v1 = m[u][1] + m[u][2], v2 = m[u][2] - m[u][1], v3 = m[u][1] - m[u][3];
+            float *o = V + ((size_t)(u * 4) * T + t) * C + c;
+            *reinterpret_cast<f32x4 *>(o) = v0;
+            *reinterpret_cast<f32x4 *>(o + T * C) = v1;
+            *reinterpret_cast<f32x4 *>(o + 2 * T * C) = v2;
+            *reinterpret_cast<f32x4 *>(o + 3 * T * C) = v3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. 16-plane GEMM with the output transform folded into the accumulators.
+// ------------------------------------------------------------------------------------------------
+struct WinoArgs {
+    const float *V;      // [16][T][C]
+    const float *U;      // [16][Cout][C]
+    const float *scale, *shift;
+    float *y;            // [B, Hl, Wl, Cout]
+    int T, C, Cout, B, Hl, Wl, Ty, Tx, act;
+};
+
+template <int TN, int BKT>
+__global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+    constexpr int BM = 64, BN = 2 * TN * 32;  // 64 Winograd tiles x BN channels; waves 2 (tiles) x 2 (channels)
+    constexpr int LK = BKT + 4, TPR = BKT / 4, RPP = 256 / TPR;
+    constexpr int XR = (BM + RPP - 1) / RPP, WR = BN / RPP;
+    constexpr int BUF = (BM + BN) * LK;
+    static_assert(BN % RPP == 0 && (BM % RPP == 0 || BM < RPP), "loader pass must tile the operand rows");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int t0 = mt * BM, n0 = nt * BN;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    const size_t vplane = (size_t)a.T * a.C, uplane = (size_t)a.Cout * a.C;
+    const unsigned vbytes = (unsigned)(vplane * 4), ubytes = (unsigned)(uplane * 4);
+    const int KC = a.C / BKT;      // k-chunks per frequency plane
+    const int NIT = 16 * KC;       // flat (f, kc) iteration space
+
+    // loop-invariant row offsets; rows past T / Cout (and loader lanes past the 64 tile rows) read as zero
+    int xoff[XR], woff[WR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int rrow = lr + RPP * i;
+        const int t = t0 + rrow;
+        xoff[i] = (rrow < BM && t < a.T) ? (t * a.C + lc) * 4 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int n = n0 + lr + RPP * i;
+        woff[i] = n < a.Cout ? (n * a.C + lc) * 4 : -1;
+    }
+    f32x4 xs[XR], ws[WR];
+    auto load_chunk = [&](int it, bool live) {
+        const int f = min(it / KC, 15), kc = it - (it / KC) * KC;  // (tail iterations are dead loads: keep the base in range)
+        const __amdgpu_buffer_rsrc_t rv = wmake_rsrc(a.V + (size_t)f * vplane, vbytes);
+        const __amdgpu_buffer_rsrc_t ru = wmake_rsrc(a.U + (size_t)f * uplane, ubytes);
+        const int soff = kc * BKT * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, live ? xoff[i] : -1, soff);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ws[i] = wbuf_load4(ru, live ? woff[i] : -1, soff);
+    };
+    auto store_chunk = [&](int buf) {
+        float *X = lds + buf * BUF;
+        float *Wt = X + BM * LK;
+#pragma unroll
+        for (int i = 0; i < XR; ++i)
+            if (BM >= RPP || lr < BM) *reinterpret_cast<f32x4 *>(X + (lr + RPP * i) * LK + lc) = xs[i];
+#pragma unroll
+        for (int i = 0; i < WR; ++i) *reinterpret_cast<f32x4 *>(Wt + (lr + RPP * i) * LK + lc) = ws[i];
+    };
+
+    f32x16 mf[TN];        // M_f of the current frequency plane
+    f32x16 yy[4][TN];     // the four outputs of each 2x2 tile: index 2*i + j
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mf[n][r] = 0.f;
+            yy[0][n][r] = yy[1][n][r] = yy[2][n][r] = yy[3][n][r] = 0.f;
+        }
+    }
+
+    load_chunk(0, true);
+    store_chunk(0);
+    load_chunk(1, NIT > 1);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LK + (lane >> 5) * 4;
+    for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1;
+        const float *X = lds + cur * BUF + (wm * 32) * LK + frag_off;
+        const float *Wt = lds + cur * BUF + BM * LK + (wn * TN * 32) * LK + frag_off;
+        f32x4 fa[2][TN], fb[2];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK);
+        fb[0] = *reinterpret_cast<const f32x4 *>(X);
+        store_chunk(cur ^ 1);
+#pragma unroll
+        for (int q = 0; q < BKT / 8; ++q) {
+            const int fc = q & 1, fn = fc ^ 1;
+            if (q + 1 < BKT / 8) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) fa[fn][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK + (q + 1) * 8);
+                fb[fn] = *reinterpret_cast<const f32x4 *>(X + (q + 1) * 8);
+            }
+            if (q == 0) load_chunk(it + 2, it + 2 < NIT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    mf[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], mf[ni], 0, 0, 0);
+        }
+        // end of a frequency plane: fold M_f into the outputs with the 0/+-1 coefficients of A^T (x) A^T
+        const int f = it / KC;
+        if (it - f * KC == KC - 1) {
+            const int u = f >> 2, v = f & 3;
+            const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
+            const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
+            const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                if (c00 != 0.f) yy[0][n] += c00 * mf[n];
+                if (c01 != 0.f) yy[1][n] += c01 * mf[n];
+                if (c10 != 0.f) yy[2][n] += c10 * mf[n];
+                if (c11 != 0.f) yy[3][n] += c11 * mf[n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mf[n][r] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns tile t, register quad = 4 consecutive channels -------------------------
+    const int t = t0 + wm * 32 + (lane & 31);
+    if (t >= a.T) return;
+    const int tx = t % a.Tx;
+    const int r = t / a.Tx;
+    const int ty = r % a.Ty, b = r / a.Ty;
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+        const int oy = 2 * ty + (ij >> 1), ox = 2 * tx + (ij & 1);
+        if (oy >= a.Hl || ox >= a.Wl) continue;
+        float *orow = a.y + (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                if (n >= a.Cout) continue;
+                f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
+                if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+                if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                if (a.act == A3D_ACT_RELU) {
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                } else if (a.act == A3D_ACT_LEAKY) {
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
+                }
+                *reinterpret_cast<f32x4 *>(orow + n) = v;
+            }
+        }
+    }
+}
+
+int a3d_wino_eligible(const a3d_conv_desc *d) {
+    if (!d->w_wino) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if (d->res || d->pixshuf || d->stem || d->splitk != 1 || d->m_dev) return 0;
+    if (((d->Cin + d->Cin2) & 15) || (d->Cin & 3) || (d->Cin2 & 3) || (d->Cout & 3)) return 0;
+    const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
+    const size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
+    const size_t C = (size_t)d->Cin + d->Cin2;
+    if (T * C * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * C * 4 >= ((size_t)1 << 32)) return 0;
+    return 1;
+}
+
+size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
+    const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
+    const size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
+    return 16 * T * ((size_t)d->Cin + d->Cin2) * sizeof(float);
+}
+
+int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
+    if (!a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_UNSUPPORTED;
+    const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
+    const int Ty = (Hl + 1) / 2, Tx = (Wl + 1) / 2;
+    const int C = d->Cin + d->Cin2;
+    const size_t T = (size_t)d->B * Ty * Tx;
+    const size_t total = T * (C / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, d->workspace, d->B, d->H, d->W,
+                       d->Cin, d->Cin2, d->ups, Ty, Tx);
+    WinoArgs a;
+    a.V = d->workspace;
+    a.U = d->w_wino;
+    a.scale = d->scale;
+    a.shift = d->shift;
+    a.y = d->y;
+    a.T = (int)T;
+    a.C = C;
+    a.Cout = d->Cout;
+    a.B = d->B;
+    a.Hl = Hl;
+    a.Wl = Wl;
+    a.Ty = Ty;
+    a.Tx = Tx;
+    a.act = d->act;
+    const int mtiles = (int)((T + 63) / 64);
+    // tune >= 200 selects an explicit GEMM variant for A/B measurements: 200 + 10*(TN-1) + (BK==32)
+    int tn = 1, bk32 = 1;  // measured best on every layer shape of the detector (64 tiles x 64 channels, 3 waves/SIMD)
+    if (d->tune >= 200) {
+        tn = (d->tune - 200) / 10 + 1;
+        bk32 = (d->tune - 200) % 10;
+    }
+    const int bn = tn * 64;
+    const int ntiles = (d->Cout + bn - 1) / bn;
+    const dim3 grid(mtiles * ntiles);
+    if (tn == 1 && !bk32) hipLaunchKernelGGL((wino_gemm_kernel<1, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
+    else if (tn == 1) hipLaunchKernelGGL((wino_gemm_kernel<1, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
+    else if (!bk32) hipLaunchKernelGGL((wino_gemm_kernel<2, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
+    else hipLaunchKernelGGL((wino_gemm_kernel<2, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
+    return a3d_check_launch();
+}

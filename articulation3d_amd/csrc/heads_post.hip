@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
         ty = ty / dyb;
         ty = ty * 2.f;
         ty = ty - 1.f;
-        const float iy = ((ty + 1.f) * MSf - 1.f) / 2.f;
+        // F.grid_sample (ATen CPU kernel, the oracle's reference) un-normalises with ONE fused multiply-add and sums the
+        // four taps as an FMA chain nw -> ne -> sw -> se; reproducing exactly that rounding keeps the thresholded mask
+        // bit-identical (checked against 2e5 random samples: 0 mismatches; the unfused form gives 19 % 1-ulp diffs).
+        const float iy = __fmaf_rn(ty + 1.f, MSf, -1.f) / 2.f;
         const float fy = floorf(iy);
         const int iyn = (int)fy;
         const float n = iy - fy, s = 1.f - n;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
                 tx = tx / dxb;
                 tx = tx * 2.f;
                 tx = tx - 1.f;
-                const float ix = ((tx + 1.f) * MSf - 1.f) / 2.f;
+                const float ix = __fmaf_rn(tx + 1.f, MSf, -1.f) / 2.f;
                 if (ix > -1.f && ix < MSf) {
                     const float fx = floorf(ix);
                     const int ixw = (int)fx;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
                     const float vne = (yn_ok && xe_ok) ? mp[iyn * a.MS + ixw + 1] : 0.f;
                     const float vsw = (ys_ok && xw_ok) ? mp[(iyn + 1) * a.MS + ixw] : 0.f;
                     const float vse = (ys_ok && xe_ok) ? mp[(iyn + 1) * a.MS + ixw + 1] : 0.f;
-                    const float val = vnw * nw + vne * ne + vsw * sw + vse * se;
+                    const float val = __fmaf_rn(vse, se, __fmaf_rn(vsw, sw, __fmaf_rn(vne, ne, vnw * nw)));
                     if (val >= a.mask_thresh) {
                         bit = 1;
                         ++cntpix;

@@ -48,7 +48,7 @@ class MaskRCNNConvUpsampleHead(nn.Module):
         """x: [rows,14,14,C] NHWC -> mask probabilities [rows, 28, 28]."""
         rows = x.shape[0]
         for conv in self.conv_norm_relus:
-            x = conv(x)
+            x = conv(x, wino=True)  # fixed algorithm choice: the ROI count must not change a ROI's result
         x = self.deconv(x)  # [rows,28,28,dim]
         S = x.shape[1]
         w = self.predictor.weight.reshape(1, -1).contiguous()

@@ -55,7 +55,7 @@ class PlaneRCNNConvFCHead(nn.Module):
 
     def _tower(self, x, convs, fcs):
         for layer in convs:
-            x = layer(x)
+            x = layer(x, wino=True)  # fixed algorithm choice: the ROI count must not change a ROI's result
         x = x.reshape(x.shape[0], -1)
         for fc in fcs:
             x = head_fc(x, fc)

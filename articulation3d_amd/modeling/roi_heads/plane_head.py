@@ -57,7 +57,7 @@ class PlaneRCNNConvFCHead(nn.Module):
     def forward_rows(self, x):
         """x: [rows,14,14,C] NHWC pooled features -> [rows, 3] unit normals."""
         for layer in self.conv_norm_relus:
-            x = layer(x)
+            x = layer(x, wino=True)  # fixed algorithm choice: the ROI count must not change a ROI's result
         x = x.reshape(x.shape[0], -1)
         for fc in self.fcs:
             x = head_fc(x, fc)

@@ -69,6 +69,8 @@ class PackedConv:
     act: int = ACT_NONE
     pixshuf: bool = False
     stem: bool = False
+    w_wino: Optional[torch.Tensor] = None  # [16, cols, Cin] Winograd-domain weights (3x3 s1 p1 convs)
+    phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
 
     @property
     def out_channels(self) -> int:
@@ -111,7 +113,50 @@ def pack_conv(weight: torch.Tensor, bias=None, bn=None, stride=1, pad=0, act=ACT
     if shift is not None:
         shift = _pad_rows(shift)
     dev = lambda t: None if t is None else t.contiguous().to(device)
-    return PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act)
+    pk = PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act)
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 16 == 0:
+        pk.w_wino = dev(winograd_weights(_pad_rows(weight.detach().float())))
+    return pk
+
+
+def pack_conv_ups_phases(weight: torch.Tensor, bias=None, bn=None, act=ACT_NONE, device="cuda") -> List[PackedConv]:
+    """3x3 pad-1 conv applied to a nearest-x2 upsampled input == four 2x2 convs on the source grid, one per output
+    phase (dy,dx), whose taps are sums of the original taps that land on the same source pixel:
+    dy=0: rows {kh0 | kh1+kh2}, dy=1: rows {kh0+kh1 | kh2}; same for columns.  4/9 of the FLOPs."""
+    Cout, Cin, KH, KW = weight.shape
+    assert KH == 3 and KW == 3 and Cin % 32 == 0
+    w = weight.detach().double()
+    groups = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    scale = shift = None
+    if bn is not None:
+        scale, shift = fold_bn(*[t.detach().float() for t in bn[:4]], bn[4], None if bias is None else bias.detach().float())
+    elif bias is not None:
+        shift = bias.detach().float()
+    dev = lambda t: None if t is None else t.contiguous().to(device)
+    scale_d, shift_d = dev(None if scale is None else _pad_rows(scale)), dev(None if shift is None else _pad_rows(shift))
+    out = []
+    for dy in (0, 1):
+        for dx in (0, 1):
+            wp = w.new_zeros(Cout, Cin, 2, 2)
+            for a, khs in enumerate(groups[dy]):
+                for b, kws in enumerate(groups[dx]):
+                    for kh in khs:
+                        for kw in kws:
+                            wp[:, :, a, b] += w[:, :, kh, kw]
+            wk = _pad_rows(wp.float().permute(0, 2, 3, 1).reshape(Cout, 4 * Cin))
+            out.append(PackedConv(dev(wk), scale_d, shift_d, 2, 2, 1, 0, Cin, wk.shape[0], 4 * Cin, act, phase=1 + dy * 2 + dx))
+    return out
+
+
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def winograd_weights(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> U = G g G^T as [16, Cout, Cin] (frequency f = 4u + v), the layout of a3d_conv_desc.w_wino.
+    Weight preparation only (once per layer at pack time)."""
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
+    U = torch.einsum("up,ncpq,vq->uvnc", G, weight.double(), G)
+    return U.reshape(16, weight.shape[0], weight.shape[1]).float().contiguous()
 
 
 def pack_stem(weight: torch.Tensor, bn, device="cuda") -> PackedConv:
@@ -164,7 +209,8 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 # --------------------------------------------------------------------------------------------------
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
-           m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0) -> torch.Tensor:
+           m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
+           wino: Optional[bool] = None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -178,6 +224,9 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
     Ho = (Hl + 2 * p.pad - p.KH) // p.stride + 1
     Wo = (Wl + 2 * p.pad - p.KW) // p.stride + 1
+    if p.phase:
+        assert not ups and out is not None, "phase convs run on the source grid and fill a shared [B,2H,2W,C] output"
+        Ho, Wo = H, W
     if out is None:
         shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
@@ -190,8 +239,16 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), int(p.pixshuf), int(p.stem), int(splitk)
     d.m_dev = _p(m_dev)
     d.tune = int(tune)
+    d.phase = int(p.phase)
+    # Winograd F(2x2,3x3) for 3x3 s1 p1 layers.  The choice must not depend on the batch / ROI count (a frame's
+    # result would otherwise depend on how it was batched): by default every layer whose per-image output is at
+    # least 600 pixels (p4 level and larger); callers with a variable row count (per-ROI heads) pass wino=True.
+    use_wino = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
+                and (wino if wino is not None else (Ho * Wo >= 600 and p.Cin >= 128)))
     ws = None
-    if splitk > 1:
+    if use_wino:
+        d.w_wino = p.w_wino.data_ptr()
+    if use_wino or splitk > 1:
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         d.workspace = ws.data_ptr()
@@ -201,10 +258,22 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
         k_real = 147 if p.stem else p.KH * p.KW * p.Cin
-        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1,
+        name = "wino_f2x2_3x3 (input transform + 16-plane gemm)" if use_wino else conv_tile_config(p, B * Ho * Wo, ups)
+        # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
+        fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
+        CONV_TIMING.append((name + (" ups-phase" if p.phase else ""), fl, e0, e1,
                             f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    return out
+
+
+def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 pad-1 conv over the nearest-x2 upsampling of (x || x2), as four source-grid 2x2 convs (pack_conv_ups_phases)."""
+    B, H, W, _ = x.shape
+    out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
+    for p in phases:
+        conv2d(x, p, x2=x2, out=out)
     return out
 
 

@@ -60,7 +60,8 @@ typedef struct a3d_conv_desc {
     const float *shift; /* [Cout] or NULL (=0)   -- bias / folded BatchNorm shift                  */
     const float *res;   /* residual [B,Ho,Wo,Cout] (or [B,Ho/2,Wo/2,Cout] when res_ups) or NULL    */
     float *y;           /* [B,Ho,Wo,Cout]  (pixshuf: [B,2Ho,2Wo,Cout/4])                           */
-    float *workspace;   /* split-K partials, a3d_conv_workspace_bytes(); may be NULL if splitk==1  */
+    float *workspace;   /* split-K partials or the Winograd-domain input, a3d_conv_workspace_bytes(); may be NULL
+                           if splitk == 1 and w_wino == NULL                                       */
     int B, H, W, Cin, Cin2;
     int Ho, Wo, Cout; /* Cout % 4 == 0 */
     int KH, KW, stride, pad;
@@ -73,7 +74,16 @@ typedef struct a3d_conv_desc {
     int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch            */
     const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
                          so ragged per-ROI batches need no host synchronisation                      */
-    int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel      */
+    int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel;
+                         2 = direct implicit GEMM even when w_wino is given; >= 100: explicit tile variant */
+    int phase;        /* 0, or 1..4 = output phase (dy,dx) = ((phase-1)>>1, (phase-1)&1) of a 3x3 pad-1 convolution over a
+                         nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
+                         taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
+                         phases write the interleaved pixels (2oh+dy, 2ow+dx) of y [B,2Ho,2Wo,Cout] -- 4/9 of the FLOPs
+                         of convolving the upsampled tensor (depth decoder, depth_head.py:40-46)                   */
+    const float *w_wino; /* optional Winograd-domain weights U = G g G^T, [16][Cout][Cin+Cin2] (3x3 s1 p1 only):
+                            when given (and workspace holds a3d_conv_workspace_bytes) the layer runs as
+                            F(2x2,3x3): 2.25x fewer MFMA cycles, same result within fp32 rounding           */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);

@@ -118,6 +118,48 @@ def test_stem_pool_resize_small_ops(ops):
     assert rel(y[:, None], F.conv2d(x, w, torch.tensor([0.3]), padding=1)) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 30, 40, 128, 256), (1, 15, 21, 64, 36), (3, 14, 14, 256, 256), (1, 2, 2, 32, 64)])
+def test_winograd_f2x2_3x3_vs_torch(ops, shape):
+    """3x3 s1 p1 layers run as Winograd F(2x2,3x3) (odd sizes = partial tiles, ragged channels)."""
+    B, H, W, Cin, Cout = shape
+    torch.manual_seed(8)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-3)
+    b = torch.randn(Cout)
+    ref = F.leaky_relu(F.batch_norm(F.conv2d(x, w, b, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-3), 0.01)
+    p = ops.pack_conv(w, b, bn, 1, 1, ops.ACT_LEAKY)
+    assert p.w_wino is not None and p.w_wino.shape == (16, p.cols, Cin)
+    yw = ops.conv2d(nhwc(x).cuda(), p, wino=True)
+    yd = ops.conv2d(nhwc(x).cuda(), p, wino=False)
+    assert rel(yw[..., :Cout].permute(0, 3, 1, 2), ref) < 1e-5 and rel(yd[..., :Cout].permute(0, 3, 1, 2), ref) < 5e-6
+    ref64 = F.leaky_relu(F.batch_norm(F.conv2d(x.double(), w.double(), b.double(), padding=1), bn[2].double(), bn[3].double(),
+                                      bn[0].double(), bn[1].double(), False, 0.0, 1e-3), 0.01)
+    # fp32 error budget against float64: Winograd stays within a small factor of the direct form
+    assert rel(yw[..., :Cout].permute(0, 3, 1, 2).double(), ref64) < 6 * rel(yd[..., :Cout].permute(0, 3, 1, 2).double(), ref64) + 1e-6
+
+
+def test_upsampled_conv_as_four_source_grid_phases(ops):
+    """conv3x3(pad 1) over nearest-x2 upsample(cat(a, b)) == four 2x2 convs with pre-summed taps (depth decoder)."""
+    torch.manual_seed(9)
+    a, c2 = torch.randn(2, 128, 15, 20), torch.randn(2, 128, 15, 20)
+    w = torch.randn(128, 256, 3, 3) / 48
+    b = torch.randn(128)
+    bn = (torch.rand(128) + 0.5, torch.randn(128) * 0.1, torch.randn(128) * 0.1, torch.rand(128) + 0.5, 1e-3)
+    ref = F.relu(F.batch_norm(F.conv2d(F.interpolate(torch.cat([a, c2], 1), scale_factor=2, mode="nearest"), w, b, padding=1),
+                              bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-3))
+    phases = ops.pack_conv_ups_phases(w, b, bn, ops.ACT_RELU)
+    assert [p.phase for p in phases] == [1, 2, 3, 4] and phases[0].Kpad == 4 * 256
+    y = ops.conv2d_ups(nhwc(a).cuda(), phases, x2=nhwc(c2).cuda())
+    assert y.shape == (2, 30, 40, 128) and rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    # single source, odd spatial size
+    a = torch.randn(1, 64, 7, 9)
+    w = torch.randn(64, 64, 3, 3) / 24
+    ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w, None, padding=1)
+    y = ops.conv2d_ups(nhwc(a).cuda(), ops.pack_conv_ups_phases(w))
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+
+
 @pytest.mark.parametrize("splitk", [1, 7, 64])
 def test_linear_splitk_chw_reorder(ops, splitk):
     torch.manual_seed(4)
