@@ -125,18 +125,26 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
         const int n = n0 + lr + RPP * i;
         woff[i] = n < a.Cout ? (n * a.C + lc) * 4 : -1;
     }
-    f32x4 xs[XR], ws[WR];
-    auto load_chunk = [&](int it, bool live) {
-        const int f = min(it / KC, 15), kc = it - (it / KC) * KC;  // (tail iterations are dead loads: keep the base in range)
+    // Two register staging sets: the loads of chunk c are issued at iteration c-3 into set (c & 1), written to LDS at
+    // iteration c-1 and multiplied at iteration c, so every buffer load has two full iterations (32 MFMAs) to land.
+    f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
+    int ld_f = 0, ld_kc = 0;  // (frequency plane, k-chunk) of the next chunk to load: incremental, no divisions
+    auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
+        const bool live = ld_f < 16;
+        const int f = min(ld_f, 15);  // (tail iterations issue dead loads: keep the base in range)
         const __amdgpu_buffer_rsrc_t rv = wmake_rsrc(a.V + (size_t)f * vplane, vbytes);
         const __amdgpu_buffer_rsrc_t ru = wmake_rsrc(a.U + (size_t)f * uplane, ubytes);
-        const int soff = kc * BKT * 4;
+        const int soff = ld_kc * BKT * 4;
 #pragma unroll
         for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, live ? xoff[i] : -1, soff);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = wbuf_load4(ru, live ? woff[i] : -1, soff);
+        if (++ld_kc == KC) {
+            ld_kc = 0;
+            ++ld_f;
+        }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[WR]) {
         float *X = lds + buf * BUF;
         float *Wt = X + BM * LK;
 #pragma unroll
@@ -157,21 +165,23 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
         }
     }
 
-    load_chunk(0, true);
-    store_chunk(0);
-    load_chunk(1, NIT > 1);
+    load_chunk(xsA, wsA);  // chunk 0
+    store_chunk(0, xsA, wsA);
+    load_chunk(xsB, wsB);  // chunk 1
+    load_chunk(xsA, wsA);  // chunk 2
     __syncthreads();
 
     const int frag_off = (lane & 31) * LK + (lane >> 5) * 4;
-    for (int it = 0; it < NIT; ++it) {
-        const int cur = it & 1;
+    int cf = 0, ckc = 0;  // (plane, chunk) being multiplied
+    // one iteration: multiply LDS[cur]; write the staged chunk it+1 to LDS[cur^1]; refill that set with chunk it+3
+    auto iteration = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         const float *X = lds + cur * BUF + (wm * 32) * LK + frag_off;
         const float *Wt = lds + cur * BUF + BM * LK + (wn * TN * 32) * LK + frag_off;
         f32x4 fa[2][TN], fb[2];
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK);
         fb[0] = *reinterpret_cast<const f32x4 *>(X);
-        store_chunk(cur ^ 1);
+        store_chunk(cur ^ 1, xs, ws);
 #pragma unroll
         for (int q = 0; q < BKT / 8; ++q) {
             const int fc = q & 1, fn = fc ^ 1;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
                 for (int ni = 0; ni < TN; ++ni) fa[fn][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK + (q + 1) * 8);
                 fb[fn] = *reinterpret_cast<const f32x4 *>(X + (q + 1) * 8);
             }
-            if (q == 0) load_chunk(it + 2, it + 2 < NIT);
+            if (q == 0) load_chunk(xs, ws);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -188,9 +198,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
                     mf[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], mf[ni], 0, 0, 0);
         }
         // end of a frequency plane: fold M_f into the outputs with the 0/+-1 coefficients of A^T (x) A^T
-        const int f = it / KC;
-        if (it - f * KC == KC - 1) {
-            const int u = f >> 2, v = f & 3;
+        if (++ckc == KC) {
+            ckc = 0;
+            const int u = cf >> 2, v = cf & 3;
+            ++cf;
             const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
             const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
             const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
@@ -205,6 +216,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
             }
         }
         __syncthreads();
+    };
+    for (int it = 0; it < NIT; it += 2) {  // NIT = 16*KC is even
+        iteration(0, xsB, wsB);  // chunk it   in LDS[0]; set B holds chunk it+1, is refilled with chunk it+3
+        iteration(1, xsA, wsA);  // chunk it+1 in LDS[1]; set A holds chunk it+2, is refilled with chunk it+4
     }
 
     // ---- epilogue: lane owns tile t, register quad = 4 consecutive channels -------------------------
