@@ -103,6 +103,8 @@ SIGNATURES = {
     "a3d_preprocess_f32chw": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_maxpool3x3s2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_subsample2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_resize_bilinear_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),

@@ -271,8 +271,7 @@ size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
     return 16 * T * ((size_t)d->Cin + d->Cin2) * sizeof(float);
 }
 
-int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
-    if (!a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_UNSUPPORTED;
+static int wino_launch_input(const a3d_conv_desc *d, hipStream_t s) {
     const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
     const int Ty = (Hl + 1) / 2, Tx = (Wl + 1) / 2;
     const int C = d->Cin + d->Cin2;
@@ -282,6 +281,13 @@ int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(wino_input_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, d->workspace, d->B, d->H, d->W,
                        d->Cin, d->Cin2, d->ups, Ty, Tx);
+    return A3D_OK;
+}
+
+static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
+    const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
+    const int Ty = (Hl + 1) / 2, Tx = (Wl + 1) / 2;
+    const size_t T = (size_t)d->B * Ty * Tx;
     WinoArgs a;
     a.V = d->workspace;
     a.U = d->w_wino;
@@ -289,7 +295,7 @@ int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
     a.shift = d->shift;
     a.y = d->y;
     a.T = (int)T;
-    a.C = C;
+    a.C = d->Cin + d->Cin2;
     a.Cout = d->Cout;
     a.B = d->B;
     a.Hl = Hl;
@@ -311,5 +317,26 @@ int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
     else if (tn == 1) hipLaunchKernelGGL((wino_gemm_kernel<1, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
     else if (!bk32) hipLaunchKernelGGL((wino_gemm_kernel<2, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
     else hipLaunchKernelGGL((wino_gemm_kernel<2, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
+    return A3D_OK;
+}
+
+int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
+    if (!a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_UNSUPPORTED;
+    wino_launch_input(d, s);
+    wino_launch_gemm(d, s);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream) {
+    if (!d || !d->x || !a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_ARG;
+    a3d_begin();
+    wino_launch_input(d, (hipStream_t)stream);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_wino_gemm(const a3d_conv_desc *d, void *stream) {
+    if (!d || !d->y || !a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_ARG;
+    a3d_begin();
+    wino_launch_gemm(d, (hipStream_t)stream);
     return a3d_check_launch();
 }

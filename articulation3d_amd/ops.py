@@ -253,16 +253,26 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
         d.workspace = ws.data_ptr()
     if CONV_TIMING is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k_real = 147 if p.stem else p.KH * p.KW * p.Cin
+        shape = f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+            e1.record()
+            _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
+            e2.record()
+            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape))
+            CONV_TIMING.append(("wino_gemm_kernel<1,32>", 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape))
+            return out
+        e0, e1 = ev(), ev()
         e0.record()
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
-        k_real = 147 if p.stem else p.KH * p.KW * p.Cin
-        name = "wino_f2x2_3x3 (input transform + 16-plane gemm)" if use_wino else conv_tile_config(p, B * Ho * Wo, ups)
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
-        CONV_TIMING.append((name + (" ups-phase" if p.phase else ""), fl, e0, e1,
-                            f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"))
+        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups) + (" ups-phase" if p.phase else ""), fl, e0, e1, shape))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

@@ -89,6 +89,11 @@ typedef struct a3d_conv_desc {
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
 int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
 
+/* The two launches of the Winograd form, individually (a3d_conv2d_nhwc_f32 issues both when d->w_wino is set):
+ * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */
+int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream);
+int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
+
 /* Max-pool 3x3 stride 2 pad 1 (ResNet stem) and kernel-1 stride-2 pool (FPN LastLevelMaxPool = p6). */
 int a3d_maxpool3x3s2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);
 int a3d_subsample2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);
