@@ -66,6 +66,19 @@ def _compile(src: str, flags) -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile + link (incremental).  Safe to call from several processes at once (one node, shared tree)."""
+    import fcntl
+
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     srcs = {k: v for k, v in SOURCES.items() if os.path.exists(os.path.join(CSRC, k))}
     if force:
         for k in srcs:

@@ -83,6 +83,7 @@ def main():
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--cpu-frames", type=int, default=4)
     args = ap.parse_args()
 
@@ -91,14 +92,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP) device: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    local_dev = local_rank % torch.cuda.device_count()  # == local_rank on a real N-GPU node
+    torch.cuda.set_device(local_dev)
+    dev = f"cuda:{local_dev}"
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from articulation3d_amd import ops
     from articulation3d_amd.parallel import gather_records
