@@ -115,8 +115,10 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
         a.out_boxes[slot * 4 + 3] = y1;
     }
     if (!live) {
-        if (mout)
+        if (mout && (npix & 15) == 0 && (((size_t)slot * npix) & 15) == 0)
             for (size_t i = threadIdx.x; i < npix / 16; i += blockDim.x) reinterpret_cast<uint4 *>(mout)[i] = uint4{0, 0, 0, 0};
+        else if (mout)
+            for (size_t i = threadIdx.x; i < npix; i += blockDim.x) mout[i] = 0;
         if (threadIdx.x == 0) {
             a.area[slot] = 0;
             a.planes[slot * 3 + 0] = a.planes[slot * 3 + 1] = a.planes[slot * 3 + 2] = 0.f;
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
     double sum = 0.0;
     int cntpix = 0;
     // 16 pixels per thread-iteration along x so the uint8 mask is stored as one 16-byte vector
-    const int groups_per_row = a.W / 16;
+    const int groups_per_row = (a.W + 15) / 16;
+    const bool vec_store = (a.W & 15) == 0;  // 16-byte mask stores need 16-pixel-aligned rows; other widths store bytes
     for (int gidx = threadIdx.x; gidx < a.H * groups_per_row; gidx += blockDim.x) {
         const int py = gidx / groups_per_row, gx = (gidx - py * groups_per_row) * 16;
         float ty = ((float)py + 0.5f) - y0;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             unsigned char bit = 0;
-            if (rowhit) {
+            if (rowhit && gx + j < a.W) {
                 const int px = gx + j;
                 float tx = ((float)px + 0.5f) - x0;
                 tx = tx / dxb;
@@ -198,7 +201,9 @@ __global__ __launch_bounds__(256) void paste_lsq_kernel(const PasteArgs a) {
             }
             bytes[j] = bit;
         }
-        if (mout) {
+        if (mout && !vec_store) {
+            for (int j = 0; j < 16 && gx + j < a.W; ++j) mout[(size_t)py * a.W + gx + j] = bytes[j];
+        } else if (mout) {
             uint4 pk;
             pk.x = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (bytes[3] << 24);
             pk.y = bytes[4] | (bytes[5] << 8) | (bytes[6] << 16) | (bytes[7] << 24);
@@ -247,7 +252,7 @@ extern "C" int a3d_paste_lsq(const a3d_paste_desc *d, void *stream) {
     if (!d || !d->boxes || !d->scores || !d->count || !d->row_offset || !d->mask_prob || !d->planes || !d->area ||
         !d->keep || !d->out_boxes)
         return A3D_ERR_ARG;
-    if (d->B <= 0 || d->R <= 0 || (d->W & 15) || d->MS <= 0) return A3D_ERR_ARG;
+    if (d->B <= 0 || d->R <= 0 || d->W <= 0 || d->H <= 0 || d->MS <= 0) return A3D_ERR_ARG;
     PasteArgs a;
     a.boxes = d->boxes;
     a.scores = d->scores;

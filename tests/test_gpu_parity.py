@@ -531,6 +531,46 @@ def test_reference_api_matches_batched_path(hip_model, oracle):
     assert torch.equal(ci.pred_masks.bool(), outs[0]["instances"].pred_masks[outs[0]["instances"].scores > 0.3].cpu())
 
 
+def test_reference_api_odd_image_size_is_padded(hip_model, oracle, oracle_params):
+    """A frame whose size is not a multiple of 32 goes through ImageList padding (planercnn.py:195) and comes back at
+    its own resolution; compared stage-wise with the oracle on the same frame."""
+    model, O, P = hip_model, oracle, oracle_params
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    H, W = 200, 300
+    frame = O.synthetic_frames(1, seed=31, h=H, w=W)[0]
+    img = torch.as_tensor(frame.transpose(2, 0, 1).astype("float32"))
+    out = model([{"image": img}])[0]
+    inst = out["instances"]
+    assert inst.image_size == (H, W) and inst.pred_masks.shape[1:] == (H, W) and len(inst) > 0
+    ocfg = O.OracleCfg(score_thresh=0.0)
+    x, sizes = O.preprocess([img], ocfg)
+    assert tuple(x.shape[-2:]) == (224, 320) and sizes == [(H, W)]
+    of = O.backbone(x, P)
+    images = model.preprocess_image([{"image": img}])
+    feats = model.backbone(images.tensor)
+    for k in ("p2", "p4", "p6"):
+        assert rel(feats[k], of[k]) < 2e-4
+    assert bool((inst.pred_boxes.tensor[:, 2] <= W).all()) and bool((inst.pred_boxes.tensor[:, 3] <= H).all())
+    # heads on the API's own boxes vs the oracle on the same (GPU) features
+    gfe = {k: v.contiguous().cpu() for k, v in feats.items()}
+    boxes = [inst.pred_boxes.tensor.cpu()]
+    ref_plane = O.plane_head(O.roi_pool_fpn(gfe, boxes, *ocfg.plane_pool), P)
+    assert rel(inst.pred_plane, ref_plane) < 1e-4
+    # pasted masks at the odd width (byte-store path of the paste kernel) vs the oracle paste on the same probabilities
+    raw = model.roi_heads.forward_with_given_boxes(feats, [_given(inst.pred_boxes.tensor, (H, W))])[0]
+    ref_masks = O.paste_masks(raw.pred_masks[:, 0].cpu(), boxes[0], H, W, 0.5)
+    assert (inst.pred_masks.cpu() != ref_masks).sum().item() == 0
+
+
+def _given(boxes, hw):
+    from articulation3d_amd.structures import Boxes, Instances
+
+    i = Instances(hw)
+    i.pred_boxes = Boxes(boxes)
+    i.pred_classes = torch.zeros(len(boxes), dtype=torch.int64, device=boxes.device)
+    return i
+
+
 def test_no_detections_at_reference_threshold(hip_model, oracle):
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.7  # the reference default: random-init scores stay below it
