@@ -628,3 +628,31 @@ def test_full_batch_properties(hip_model, oracle):
     assert float((n - 1).abs().max()) < 1e-5  # unit normals
     assert float((torch.linalg.norm(out.det.pred_rot_axis[:, :2], dim=1) - 1).abs().max()) < 1e-5
     assert int(out.rec_count.sum()) == int(out.keep.sum())
+
+
+def test_detect_clip_matches_reference_style_loop(hip_model, oracle):
+    """pipeline.detect_clip (batched + records + re-paste) == per-frame inference -> process -> create_instances."""
+    from articulation3d_amd.pipeline import detect_clip
+    from articulation3d_amd.utils.arti_vis import PlaneRCNN_Branch, create_instances
+    from articulation3d_amd.utils.opt_utils import track_planes
+
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    frames = oracle.synthetic_frames(5, seed=41)
+    preds = detect_clip(model, frames, batch=2, conf_threshold=0.35)
+    assert len(preds) == 5
+    branch = PlaneRCNN_Branch.__new__(PlaneRCNN_Branch)
+    branch._cpu_device, branch._refine_on = "cpu", False
+    for f, p in zip(frames, preds):
+        out = model([{"image": torch.as_tensor(f.transpose(2, 0, 1).astype("float32"))}])[0]
+        pd = branch.process(out)
+        ref = create_instances(pd["instances"], HW, pred_planes=pd["pred_plane"].numpy(), pred_rot_axis=pd["pred_rot_axis"],
+                               pred_tran_axis=pd["pred_tran_axis"], conf_threshold=0.35)
+        assert len(p) == len(ref) > 0
+        assert torch.equal(p.pred_boxes.tensor, ref.pred_boxes.tensor) and np.array_equal(p.pred_classes, ref.pred_classes)
+        np.testing.assert_allclose(p.scores, ref.scores, rtol=0, atol=0)
+        assert torch.equal(p.pred_rot_axis, ref.pred_rot_axis) and torch.equal(p.pred_tran_axis, ref.pred_tran_axis)
+        assert (p.pred_planes - ref.pred_planes).abs().max() <= 1e-5 * ref.pred_planes.abs().max()
+        assert torch.equal(p.pred_masks, ref.pred_masks)  # re-pasted on the receiving side == pasted by the sender
+    planes = track_planes(preds)  # runs on the rebuilt records (5 frames: every track is filtered as too short)
+    assert planes == {"rot": [], "trans": []}

@@ -217,3 +217,29 @@ def test_anchor_generator_and_create_instances():
                             pred_rot_axis=torch.ones(2, 3), pred_tran_axis=torch.ones(2, 2), conf_threshold=0.7)
     assert len(inst) == 1 and inst.pred_boxes.tensor.tolist() == [[30.0, 10.0, 50.0, 20.0]]
     assert inst.pred_masks.shape == (1, 480, 640) and float(inst.pred_masks.sum()) == 200 and inst.pred_planes.tolist() == [[1.0, 2.0, 3.0]]
+
+
+def test_track_planes_associates_by_iou_and_filters_short_tracks():
+    from articulation3d_amd.structures import Boxes, Instances
+    from articulation3d_amd.utils.opt_utils import track_planes
+
+    preds = []
+    for f in range(14):
+        inst = Instances((480, 640))
+        boxes, classes = [], []
+        if f != 6:  # a one-frame gap is bridged (gap <= 5)
+            boxes.append([100.0 + 3 * f, 100.0, 220.0 + 3 * f, 260.0])  # slowly drifting rotation plane
+            classes.append(0)
+        if f < 5:
+            boxes.append([400.0, 300.0, 500.0, 420.0])  # short-lived translation plane: filtered (< 10 frames)
+            classes.append(1)
+        inst.pred_boxes = Boxes(torch.tensor(boxes).reshape(-1, 4))
+        inst.pred_classes = np.asarray(classes, dtype=np.int64)
+        preds.append(inst)
+    planes = track_planes(preds)
+    assert len(planes["rot"]) == 1 and planes["trans"] == []
+    t = planes["rot"][0]
+    assert sorted(t["ids"]) == [f for f in range(14) if f != 6] and t["latest_frame"] == 13
+    # a jump breaks the association -> two short tracks, both filtered
+    preds[7].pred_boxes = Boxes(torch.tensor([[300.0, 300.0, 400.0, 400.0]]))
+    assert len(track_planes(preds[:9])["rot"]) == 0
