@@ -59,6 +59,64 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = a.C >> 2;
     float *orow = a.out + (size_t)row * a.P * a.P * a.C;
+
+    // Separable form.  The samples of a bin form a gh x gw lattice and a bilinear weight factorises into a y part and
+    // an x part, so  sum_samples sum_corners w*f  ==  sum_rows sum_cols WY[row] * WX[col] * f[row][col]  with
+    // WY[row] = sum over the bin's valid y-samples of (hy if yl == row) + (ly if yh == row), WX likewise.  A bin then reads
+    // (gh+1)(gw+1) cells instead of 4*gh*gw (gh, gw are 2-4 for typical proposals: ~2.2x fewer gathered bytes, which is
+    // what bounds this kernel).  Tables are built once per ROI: one thread per bin row / bin column.
+    constexpr int KMAX = 16, PMAX = 16;
+    __shared__ float WY[PMAX][KMAX], WX[PMAX][KMAX];
+    __shared__ int Y0[PMAX], NY[PMAX], X0[PMAX], NX[PMAX];
+    const bool separable = gh < KMAX && gw < KMAX && a.P <= PMAX;  // uniform per workgroup
+    if (separable) {
+        if (threadIdx.x < 2 * a.P) {
+            const bool isx = threadIdx.x >= a.P;
+            const int p = isx ? threadIdx.x - a.P : threadIdx.x;
+            const int g = isx ? gw : gh, L = isx ? W : H;
+            const float start = isx ? x1 : y1, bsz = isx ? bw : bh;
+            float *wt = isx ? WX[p] : WY[p];
+            for (int k = 0; k < KMAX; ++k) wt[k] = 0.f;
+            int base = -1, last = -1;
+            for (int i = 0; i < g; ++i) {
+                float v = start + (float)p * bsz + ((float)i + 0.5f) * bsz / (float)g;
+                if (v < -1.0f || v > (float)L) continue;
+                if (v <= 0.f) v = 0.f;
+                int lo = (int)v, hi;
+                if (lo >= L - 1) {
+                    hi = lo = L - 1;
+                    v = (float)lo;
+                } else
+                    hi = lo + 1;
+                const float l = v - (float)lo, h = 1.0f - l;
+                if (base < 0) base = lo;
+                wt[lo - base] += h;
+                wt[hi - base] += l;
+                last = hi;
+            }
+            (isx ? X0 : Y0)[p] = base < 0 ? 0 : base;
+            (isx ? NX : NY)[p] = base < 0 ? 0 : last - base + 1;
+        }
+        __syncthreads();
+        for (int bin = wave; bin < a.P * a.P; bin += 4) {
+            const int ph = bin / a.P, pw = bin - ph * a.P;
+            const int ry0 = Y0[ph], ny = NY[ph], rx0 = X0[pw], nx = NX[pw];
+            for (int c4 = lane; c4 < C4; c4 += 64) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int ky = 0; ky < ny; ++ky) {
+                    const float wy = WY[ph][ky];
+                    const float *frow = feat + ((size_t)(ry0 + ky) * W + rx0) * a.C + c4 * 4;
+                    for (int kx = 0; kx < nx; ++kx) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(frow + (size_t)kx * a.C);
+                        acc += (wy * WX[pw][kx]) * v;
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = acc / count;
+            }
+        }
+        return;
+    }
+    // general path (very large sampling grids): per-sample evaluation, as torchvision writes it
     for (int bin = wave; bin < a.P * a.P; bin += 4) {
         const int ph = bin / a.P, pw = bin - ph * a.P;
         for (int c4 = lane; c4 < C4; c4 += 64) {
