@@ -138,9 +138,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         }
     };
 
-    f32x4 xs[XR], ws[WR];
-    // issue the global loads of the chunk at `pos` (all-zero when `live` is false: branch-free tail)
-    auto load_x = [&](bool live) {
+    // PIPE == 1: two register staging sets -- the loads of chunk c are issued at iteration c-3 into set (c & 1), written to
+    // LDS at iteration c-1 and multiplied at iteration c (two full iterations in flight).  PIPE == 0: one set, one
+    // iteration in flight (fewer registers).
+    f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
+    int ld_idx = 0;  // index (relative to kt_begin) of the next chunk to load
+    // issue the global loads of the chunk at `pos` (all-zero past the last chunk: branch-free tail), then advance
+    auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
+        const bool live = ld_idx < nk;
+        ++ld_idx;
         const int tap = (MODE == MODE_STEM) ? pos.kh : pos.kh * d.KW + pos.kw;
         const bool second = (MODE != MODE_STEM) && pos.c0 >= d.Cin;
         const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
@@ -163,13 +169,12 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
                 xs[i] = buf_load4(r, ok ? rowoff[i] + tapoff : -1, 0);
             }
         }
-    };
-    auto load_w = [&](bool live) {
         const int soff = pos.kc * (BKT * 4);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = buf_load4(rw, live ? woff[i] : -1, soff);
+        advance();
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[WR]) {
         float *X = lds + buf * BUF;
         float *Wt = X + BM * LK;
 #pragma unroll
@@ -186,19 +191,16 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- prologue: chunk 0 -> LDS[0]; chunk 1 -> registers -----------------------------------------
-    load_x(nk > 0);
-    load_w(nk > 0);
-    advance();
-    store_chunk(0);
-    load_x(nk > 1);
-    load_w(nk > 1);
-    advance();
+    // ---- prologue: chunk 0 -> LDS[0]; chunk 1 (and, PIPE, chunk 2) -> registers ---------------------------
+    load_chunk(xsA, wsA);
+    store_chunk(0, xsA, wsA);
+    load_chunk(xsB, wsB);
+    if (PIPE) load_chunk(xsA, wsA);
     __syncthreads();
 
     const int frag_off = (lane & 31) * LK + (lane >> 5) * 4;
-    for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
+    // one iteration: multiply LDS[cur]; write the staged next chunk to LDS[cur^1]; refill that register set
+    auto iteration = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         const float *X = lds + cur * BUF + (wm * TM * 32) * LK + frag_off;
         const float *Wt = lds + cur * BUF + BM * LK + (wn * TN * 32) * LK + frag_off;
         f32x4 fa[2][TN], fb[2][TM];
@@ -206,10 +208,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         for (int ni = 0; ni < TN; ++ni) fa[0][ni] = *reinterpret_cast<const f32x4 *>(Wt + ni * 32 * LK);
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) fb[0][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LK);
-        // chunk it+1 (in registers since the previous iteration) -> the other LDS buffer.  Harmless when it is the
-        // tail (zeros into a buffer nobody reads again).
-        store_chunk(cur ^ 1);
-        const bool live2 = it + 2 < nk;
+        store_chunk(cur ^ 1, xs, ws);  // harmless at the tail (zeros into a buffer nobody reads again)
 #pragma unroll
         for (int q = 0; q < BKT / 8; ++q) {
             const int fc = q & 1, fn = fc ^ 1;
@@ -219,11 +218,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) fb[fn][mi] = *reinterpret_cast<const f32x4 *>(X + mi * 32 * LK + (q + 1) * 8);
             }
-            if (q == (PIPE ? 0 : 1)) load_x(live2);  // chunk it+2 -> registers (freed by store_chunk above)
-            if (q == (PIPE ? 1 : 2)) {
-                load_w(live2);
-                advance();
-            }
+            if (q == 0) load_chunk(xs, ws);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -233,6 +228,14 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][mi][j], acc[ni][mi], 0, 0, 0);
         }
         __syncthreads();
+    };
+    if (PIPE) {
+        for (int it = 0; it < nk; it += 2) {
+            iteration(0, xsB, wsB);                 // chunk it in LDS[0]; set B = chunk it+1, refilled with it+3
+            if (it + 1 < nk) iteration(1, xsA, wsA);  // chunk it+1 in LDS[1]; set A = chunk it+2, refilled with it+4
+        }
+    } else {
+        for (int it = 0; it < nk; ++it) iteration(it & 1, xsB, wsB);
     }
 
     // ---- epilogue (identical to v1) ------------------------------------------------------------------
@@ -312,24 +315,30 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
     const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
     int cfg = d->Cout <= 32 ? 2 : ((d->Cout <= 64 || n128 <= 1000) ? 1 : 0);  // 0: 128x128, 1: 128x64, 2: 128x32
     int bk16 = !(d->KH * d->KW == 1 && d->Kpad >= 8192);
-    if (d->tune >= 100) {  // explicit variant for A/B measurements: 100 + 10*cfg + (bk16 ? 1 : 0)
+    int pipe = 0;  // measured: the second staging set costs a wave per SIMD (146 vs 90 VGPRs) and loses 3-8 % on every shape
+    if (d->tune >= 100 && d->tune < 200) {  // explicit variant for A/B measurements: 100 + 10*cfg + (bk16 ? 1 : 0) + (single-set ? 5 : 0)
         cfg = (d->tune - 100) / 10;
-        bk16 = (d->tune - 100) % 10;
+        bk16 = (d->tune - 100) % 5;
+        pipe = ((d->tune - 100) % 10) >= 5 ? 0 : 1;
         if (cfg > 2 || bk16 > 1) return A3D_ERR_ARG;
     }
     if (d->stem) {
-        launch_v2<4, 1, 2, 2, MODE_STEM, 1, 32>(d, s);
+        launch_v2<4, 1, 2, 2, MODE_STEM, 0, 32>(d, s);
     } else if (d->ups) {
-        if (cfg == 0) launch_v2<2, 2, 2, 2, MODE_UPS, 1, 16>(d, s);
-        else if (cfg == 1) launch_v2<2, 2, 2, 1, MODE_UPS, 1, 16>(d, s);
-        else launch_v2<4, 1, 1, 1, MODE_UPS, 1, 32>(d, s);
+        if (cfg == 0) launch_v2<2, 2, 2, 2, MODE_UPS, 0, 16>(d, s);
+        else if (cfg == 1) launch_v2<2, 2, 2, 1, MODE_UPS, 0, 16>(d, s);
+        else launch_v2<4, 1, 1, 1, MODE_UPS, 0, 32>(d, s);
     } else {
-        switch (cfg * 2 + bk16) {
-            case 0: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 32>(d, s); break;
-            case 1: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 16>(d, s); break;
-            case 2: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 32>(d, s); break;
-            case 3: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 16>(d, s); break;
-            default: launch_v2<4, 1, 1, 1, MODE_GENERIC, 1, 32>(d, s); break;  // 128x32 tile: BK=32 only
+        switch ((cfg * 2 + bk16) * 2 + pipe) {
+            case 0: launch_v2<2, 2, 2, 2, MODE_GENERIC, 0, 32>(d, s); break;
+            case 1: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 32>(d, s); break;
+            case 2: launch_v2<2, 2, 2, 2, MODE_GENERIC, 0, 16>(d, s); break;
+            case 3: launch_v2<2, 2, 2, 2, MODE_GENERIC, 1, 16>(d, s); break;
+            case 4: launch_v2<2, 2, 2, 1, MODE_GENERIC, 0, 32>(d, s); break;
+            case 5: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 32>(d, s); break;
+            case 6: launch_v2<2, 2, 2, 1, MODE_GENERIC, 0, 16>(d, s); break;
+            case 7: launch_v2<2, 2, 2, 1, MODE_GENERIC, 1, 16>(d, s); break;
+            default: launch_v2<4, 1, 1, 1, MODE_GENERIC, 0, 32>(d, s); break;  // 128x32 tile: BK=32 only
         }
     }
     if (d->splitk > 1) {

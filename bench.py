@@ -84,7 +84,7 @@ def main():
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample (~10 s of host work)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
