@@ -25,7 +25,7 @@ def shard_range(num_frames: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_records(records: torch.Tensor, rec_count: torch.Tensor):
     """records [B,R,F] fp32, rec_count [B] int32 (this rank's block) -> ([G*B,R,F], [G*B]) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return records, rec_count
     G = dist.get_world_size()
     all_rec = torch.empty((G * records.shape[0],) + tuple(records.shape[1:]), device=records.device, dtype=records.dtype)

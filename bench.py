@@ -96,7 +96,8 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = f"cuda:{local_dev}"
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("A3D_BENCH_FORCE_DIST") == "1"  # (the env switch lets a 1-GPU box exercise RCCL)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -117,12 +118,12 @@ def main():
 
     def step():
         out = model.inference_batched(frames)
-        if world > 1:
+        if use_dist:
             return gather_records(out.records, out.rec_count), out
         return (out.records, out.rec_count), out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timing, ops.CONV_TIMING = ops.CONV_TIMING, None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -198,7 +199,7 @@ def main():
         result["gpu_over_cpu"] = round(fps / result["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
