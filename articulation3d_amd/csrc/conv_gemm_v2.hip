@@ -323,7 +323,8 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
         if (cfg > 2 || bk16 > 1) return A3D_ERR_ARG;
     }
     if (d->stem) {
-        launch_v2<4, 1, 2, 2, MODE_STEM, 0, 32>(d, s);
+        if (d->tune == 3) launch_v2<4, 1, 2, 2, MODE_STEM, 0, 32>(d, s);  // 256x64 tile, 1 workgroup / CU (A/B)
+        else launch_v2<2, 2, 2, 1, MODE_STEM, 0, 32>(d, s);              // 128x64 tile, 2 workgroups / CU
     } else if (d->ups) {
         if (cfg == 0) launch_v2<2, 2, 2, 2, MODE_UPS, 0, 16>(d, s);
         else if (cfg == 1) launch_v2<2, 2, 2, 1, MODE_UPS, 0, 16>(d, s);

@@ -28,7 +28,7 @@ def conv_tile_config(p: "PackedConv", M: int, ups: bool = False) -> str:
     """Mirror of the variant selection in csrc/conv_gemm_v2.hip:a3d_conv_launch_v2 (kernel template arguments
     <WAVES_M,WAVES_N,TM,TN,MODE,PIPE,BK> as they appear in a rocprofv3 kernel trace)."""
     if p.stem:
-        return "conv_gemm_v2<4,1,2,2,stem,bk32> 256x64"
+        return "conv_gemm_v2<2,2,2,1,stem,bk32> 128x64"
     n128 = ((M + 127) // 128) * ((p.cols + 127) // 128)
     cfg = 2 if p.cols <= 32 else (1 if (p.cols <= 64 or n128 <= 1000) else 0)
     bk = 32 if (p.KH * p.KW == 1 and p.Kpad >= 8192) or cfg == 2 else 16
