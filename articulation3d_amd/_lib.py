@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("m_dev", fptr),
         ("tune", C.c_int), ("phase", C.c_int),
         ("w_wino", fptr),
+        ("gate", fptr),
     ]
 
 
@@ -96,9 +97,61 @@ class PackDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", fptr), ("dy", fptr), ("scale", fptr), ("dw", fptr), ("workspace", fptr),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("splitk", C.c_int), ("accumulate", C.c_int),
+    ]
+
+
+class RoiAlignBwdDesc(C.Structure):
+    _fields_ = [
+        ("dfeat", fptr * 4),
+        ("Hf", C.c_int * 4), ("Wf", C.c_int * 4),
+        ("scale", C.c_float * 4),
+        ("L", C.c_int), ("C", C.c_int),
+        ("boxes", fptr), ("count", fptr), ("row_offset", fptr),
+        ("B", C.c_int), ("R", C.c_int), ("P", C.c_int), ("sampling_ratio", C.c_int), ("aligned", C.c_int),
+        ("dout", fptr),
+    ]
+
+
+class MatchDesc(C.Structure):
+    _fields_ = [
+        ("boxes", fptr), ("box_count", fptr), ("gt_boxes", fptr), ("gt_count", fptr),
+        ("B", C.c_int), ("N", C.c_int), ("Gmax", C.c_int), ("box_batch_stride", C.c_int),
+        ("thresholds", C.c_float * 2), ("labels", C.c_int * 3), ("n_thresholds", C.c_int), ("allow_low_quality", C.c_int),
+        ("gt_best", fptr), ("matched_idx", fptr), ("label", fptr), ("matched_iou", fptr),
+    ]
+
+
+class RpnLossDesc(C.Structure):
+    _fields_ = [
+        ("head", fptr * 5), ("dhead", fptr * 5),
+        ("Hf", C.c_int * 5), ("Wf", C.c_int * 5), ("stride", C.c_int * 5),
+        ("cell_anchors", ((C.c_float * 4) * 3) * 5),
+        ("B", C.c_int), ("L", C.c_int), ("A", C.c_int), ("CH", C.c_int), ("Atotal", C.c_int), ("Gmax", C.c_int),
+        ("labels", fptr), ("matched_idx", fptr), ("gt_boxes", fptr),
+        ("weights", C.c_float * 4), ("normalizer", C.c_float),
+        ("workspace", fptr), ("loss", fptr),
+    ]
+
+
+class BoxLossDesc(C.Structure):
+    _fields_ = [
+        ("pred", fptr), ("dpred", fptr), ("gt_classes", fptr), ("boxes", fptr), ("gt_boxes", fptr),
+        ("M", C.c_int), ("num_classes", C.c_int), ("pitch", C.c_int),
+        ("weights", C.c_float * 4),
+        ("workspace", fptr), ("loss", fptr),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/a3d.h declares
 SIGNATURES = {
     "a3d_version": (C.c_int, []),
+    "a3d_struct_size": (C.c_size_t, [C.c_int]),
     "a3d_preprocess_u8hwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_preprocess_f32chw": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
@@ -120,7 +173,25 @@ SIGNATURES = {
     "a3d_plane_offset_dense": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fptr]),
     "a3d_detections_pack": (C.c_int, [C.POINTER(PackDesc), fptr]),
     "a3d_record_floats": (C.c_int, [C.c_int]),
+    # training step
+    "a3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
+    "a3d_conv_wgrad_nhwc_f32": (C.c_int, [C.POINTER(WgradDesc), fptr]),
+    "a3d_weight_transpose": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_wino_weight_transform": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr]),
+    "a3d_zero_insert2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_sumpool2_add_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_roi_align_fpn_backward": (C.c_int, [C.POINTER(RoiAlignBwdDesc), fptr]),
+    "a3d_match_boxes": (C.c_int, [C.POINTER(MatchDesc), fptr]),
+    "a3d_loss_workspace_bytes": (C.c_size_t, []),
+    "a3d_rpn_loss": (C.c_int, [C.POINTER(RpnLossDesc), fptr]),
+    "a3d_box_loss": (C.c_int, [C.POINTER(BoxLossDesc), fptr]),
+    "a3d_sgd_momentum": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
 }
+
+STRUCT_IDS = {0: ConvDesc, 1: RpnDesc, 2: BoxDetDesc, 3: RoiAlignDesc, 4: PasteDesc, 5: PackDesc, 6: WgradDesc,
+              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc}
 
 _lib = None
 
@@ -144,6 +215,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for sid, cls in STRUCT_IDS.items():  # a layout mismatch would silently shift every field
+            if handle.a3d_struct_size(sid) != C.sizeof(cls):
+                raise RuntimeError(f"descriptor layout mismatch for {cls.__name__}: C {handle.a3d_struct_size(sid)} != ctypes {C.sizeof(cls)}")
         _lib = handle
     return _lib
 

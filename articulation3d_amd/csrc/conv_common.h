@@ -60,6 +60,10 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
         const size_t row = ((size_t)b * (2 * d.Ho) + (2 * oh + dy)) * (size_t)(2 * d.Wo) + (2 * ow + dx);
         *reinterpret_cast<f32x4 *>(d.y + row * co_n + co) = v;
     } else {
+        if (d.gate) {
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(d.gate + (size_t)m * d.Cout + n);
+            for (int i = 0; i < 4; ++i) v[i] = g[i] > 0.f ? v[i] : 0.f;
+        }
         *reinterpret_cast<f32x4 *>(d.y + (size_t)m * d.Cout + n) = v;
     }
 }

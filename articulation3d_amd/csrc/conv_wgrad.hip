@@ -1,0 +1,161 @@
+// Weight gradient of the fused convolution / linear layers (training step).
+//
+//   dw[co][kh][kw][ci] = scale[co] * sum_{b,oh,ow} dy[b,oh,ow,co] * x[b, oh*s + kh - pad, ow*s + kw - pad, ci]
+//
+// i.e. for every filter tap (kh,kw) a GEMM  dY^T [Cout x P] . X_tap [P x Cin]  whose reduction runs over the P = B*Ho*Wo
+// output pixels.  Both operands are NHWC, so the reduction index (pixel) is the SLOW index of both: a k-chunk of 16 pixels
+// is loaded as 16 rows of 128 consecutive channels (float4 per lane, fully coalesced) and kept in LDS as [k][channel].
+// In that layout the fp32 MFMA fragments (v_mfma_f32_32x32x2: lane l holds A[m = l%32][k = l/32], B[k = l/32][n = l%32])
+// are plain ds_read_b32 with consecutive lanes on consecutive words; the row pitch is 160 floats (= 32 mod 64 banks) so
+// the two 32-lane halves of a wave hit disjoint banks.  One ds_read per operand fragment feeds 2 MFMAs (64x64 wave
+// tile), i.e. 1 LDS word-read instruction per 64-cycle MFMA: far from the LDS limit.
+// Workgroup = 128 (co) x 128 (ci) x one tap x one pixel slice; 4 waves as 2x2, each 64x64 (4 accumulators).  Pixel
+// slices (split-K) write partials to the workspace; a second launch sums them in slice order (deterministic), applies
+// the folded-BN scale and stores or accumulates into dw, which has the packed forward layout [Cout][KH][KW][Cin].
+#include "a3d_common.h"
+#include "../../include/a3d.h"
+
+namespace {
+constexpr int WG_BK = 16;    // pixels per chunk
+constexpr int WG_LD = 160;   // LDS row pitch in floats
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const a3d_wgrad_desc d, const int P, const int mtiles, const int ntiles,
+                                                          const int chunk) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][WG_BK * WG_LD];  // [buffer][A|B][k][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    const int nt = t % ntiles;
+    t /= ntiles;
+    const int mt = t % mtiles;
+    const int tap = t / mtiles;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int co0 = mt * 128, ci0 = nt * 128;
+    const int p_begin = blockIdx.y * chunk, p_end = min(P, p_begin + chunk);
+
+    const int lrow = tid >> 5;          // 0..7 (+8 for the second row)
+    const int lcol = (tid & 31) * 4;    // channel offset inside the 128-wide tile
+    const bool a_ok = co0 + lcol < d.Cout, b_ok = ci0 + lcol < d.Cin;
+    const int HoWo = d.Ho * d.Wo;
+
+    f32x4 ra[2], rb[2];
+    auto load = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = p0 + lrow + 8 * i;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (p < p_end) {
+                if (a_ok) va = *reinterpret_cast<const f32x4 *>(d.dy + (size_t)p * d.Cout + co0 + lcol);
+                const int b = p / HoWo, r = p - b * HoWo;
+                const int oh = r / d.Wo, ow = r - oh * d.Wo;
+                const int iy = oh * d.stride + kh - d.pad, ix = ow * d.stride + kw - d.pad;
+                if (b_ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W)
+                    vb = *reinterpret_cast<const f32x4 *>(d.x + (((size_t)b * d.H + iy) * d.W + ix) * d.Cin + ci0 + lcol);
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4 *>(&lds[buf][0][(lrow + 8 * i) * WG_LD + lcol]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&lds[buf][1][(lrow + 8 * i) * WG_LD + lcol]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (p_end - p_begin + WG_BK - 1) / WG_BK;
+    if (nchunks > 0) {
+        load(p_begin);
+        store(0);
+        __syncthreads();
+    }
+    const int foff = (lane >> 5) * WG_LD + (lane & 31);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) load(p_begin + (c + 1) * WG_BK);
+        const float *A = &lds[cur][0][foff + wm * 64];
+        const float *Bm = &lds[cur][1][foff + wn * 64];
+#pragma unroll
+        for (int k = 0; k < WG_BK; k += 2) {
+            const float a0 = A[k * WG_LD], a1 = A[k * WG_LD + 32];
+            const float b0 = Bm[k * WG_LD], b1 = Bm[k * WG_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial[slice][co][tap][ci]; accumulator register r of lane l = row (r/4)*8 + (l/32)*4 + r%4, column l%32
+    float *out = d.workspace + (size_t)blockIdx.y * d.Cout * d.KH * d.KW * d.Cin;
+    const int taps = d.KH * d.KW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+            if (ci >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                if (co < d.Cout) out[((size_t)co * taps + tap) * d.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const a3d_wgrad_desc d, const int slices) {
+    const size_t row = (size_t)d.KH * d.KW * d.Cin;  // floats per output channel
+    const size_t total4 = (size_t)d.Cout * row / 4;
+    const size_t plane = (size_t)d.Cout * row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < slices; ++k) s += *reinterpret_cast<const f32x4 *>(d.workspace + (size_t)k * plane + i * 4);
+        if (d.scale) s *= d.scale[(i * 4) / row];
+        f32x4 *o = reinterpret_cast<f32x4 *>(d.dw + i * 4);
+        *o = d.accumulate ? *o + s : s;
+    }
+}
+
+int wgrad_check(const a3d_wgrad_desc *d) {
+    if (!d || !d->x || !d->dy || !d->dw) return A3D_ERR_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cin <= 0 || d->Cout <= 0) return A3D_ERR_ARG;
+    if ((d->Cin & 3) || (d->Cout & 3) || d->KH < 1 || d->KW < 1 || d->stride < 1 || d->splitk < 1) return A3D_ERR_ARG;
+    if ((size_t)d->B * d->Ho * d->Wo >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    return A3D_OK;
+}
+}  // namespace
+
+extern "C" size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d) {
+    if (!d || d->splitk < 1) return 0;
+    return (size_t)d->splitk * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
+    const int rc = wgrad_check(d);
+    if (rc != A3D_OK) return rc;
+    if (!d->workspace) return A3D_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = d->B * d->Ho * d->Wo;
+    const int mtiles = (d->Cout + 127) / 128, ntiles = (d->Cin + 127) / 128;
+    int chunk = (P + d->splitk - 1) / d->splitk;
+    chunk = (chunk + WG_BK - 1) / WG_BK * WG_BK;
+    a3d_begin();
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles,
+                       chunk);
+    const size_t total4 = (size_t)d->Cout * d->KH * d->KW * d->Cin / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, *d, d->splitk);
+    return a3d_check_launch();
+}

@@ -88,6 +88,7 @@ struct WinoArgs {
     const float *V;      // [16][T][C]
     const float *U;      // [16][Cout][C]
     const float *scale, *shift;
+    const float *gate;   // optional [B, Hl, Wl, Cout]: zero the output where gate <= 0
     float *y;            // [B, Hl, Wl, Cout]
     int T, C, Cout, B, Hl, Wl, Ty, Tx, act;
 };
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
     for (int ij = 0; ij < 4; ++ij) {
         const int oy = 2 * ty + (ij >> 1), ox = 2 * tx + (ij & 1);
         if (oy >= a.Hl || ox >= a.Wl) continue;
-        float *orow = a.y + (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
+        const size_t ooff = (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
+        float *orow = a.y + ooff;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -246,6 +248,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
                 } else if (a.act == A3D_ACT_LEAKY) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
+                }
+                if (a.gate) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
+                    for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
                 }
                 *reinterpret_cast<f32x4 *>(orow + n) = v;
             }
@@ -293,6 +299,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.U = d->w_wino;
     a.scale = d->scale;
     a.shift = d->shift;
+    a.gate = d->gate;
     a.y = d->y;
     a.T = (int)T;
     a.C = d->Cin + d->Cin2;

@@ -85,3 +85,21 @@ extern "C" int a3d_detections_pack(const a3d_pack_desc *d, void *stream) {
     hipLaunchKernelGGL(pack_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
+
+// sizeof() of every descriptor struct, so a binding can verify its mirror of the layouts (ids in include/a3d.h).
+extern "C" size_t a3d_struct_size(int id) {
+    switch (id) {
+        case 0: return sizeof(a3d_conv_desc);
+        case 1: return sizeof(a3d_rpn_desc);
+        case 2: return sizeof(a3d_boxdet_desc);
+        case 3: return sizeof(a3d_roialign_desc);
+        case 4: return sizeof(a3d_paste_desc);
+        case 5: return sizeof(a3d_pack_desc);
+        case 6: return sizeof(a3d_wgrad_desc);
+        case 7: return sizeof(a3d_roialign_bwd_desc);
+        case 8: return sizeof(a3d_match_desc);
+        case 9: return sizeof(a3d_rpn_loss_desc);
+        case 10: return sizeof(a3d_box_loss_desc);
+        default: return 0;
+    }
+}

@@ -201,3 +201,140 @@ extern "C" int a3d_count_offsets(const int *count, int *offsets, int B, int cap,
     hipLaunchKernelGGL(count_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, offsets, B, cap);
     return a3d_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the pooler (training step): dfeat[level] += scatter(dout).  Same geometry and the same
+// separable weight tables as the forward kernel; one wave owns one bin, lane l owns channels 4l..4l+3 and issues
+// float atomics (hardware red.add in L2) on the (gh+1)(gw+1) cells of the bin.  The summation order across ROIs is not
+// fixed, so results are reproducible to fp32 rounding only (documented tolerance in the parity test).
+// ------------------------------------------------------------------------------------------------
+struct RoiBwdArgs {
+    float *dfeat[4];
+    int Hf[4], Wf[4];
+    float scale[4];
+    int L, C;
+    const float *boxes;
+    const int *count;
+    const int *row_offset;
+    int R, P, ratio, aligned;
+    const float *dout;
+};
+
+__global__ __launch_bounds__(256) void roi_align_fpn_backward_kernel(const RoiBwdArgs a) {
+    const int slot = blockIdx.x;
+    const int b = slot / a.R, r = slot - b * a.R;
+    const int cnt = a.count ? a.count[b] : a.R;
+    if (r >= cnt) return;
+    const int row = (a.row_offset ? a.row_offset[b] : b * a.R) + r;
+    const float *bx = a.boxes + (size_t)slot * 4;
+    const float bx1 = bx[0], by1 = bx[1], bx2 = bx[2], by2 = bx[3];
+    const float size = sqrtf((bx2 - bx1) * (by2 - by1));
+    float lvf = floorf(4.0f + log2f(size / 224.0f + 1e-8f));
+    lvf = fminf(fmaxf(lvf, 2.0f), (float)(2 + a.L - 1));
+    const int lv = (int)lvf - 2;
+    float *feat = a.dfeat[lv] + (size_t)b * a.Hf[lv] * a.Wf[lv] * a.C;
+    const int H = a.Hf[lv], W = a.Wf[lv];
+    const float s = a.scale[lv];
+    const float off = a.aligned ? 0.5f : 0.0f;
+    const float x1 = bx1 * s - off, y1 = by1 * s - off, x2 = bx2 * s - off, y2 = by2 * s - off;
+    float rw = x2 - x1, rh = y2 - y1;
+    if (!a.aligned) {
+        rw = fmaxf(rw, 1.0f);
+        rh = fmaxf(rh, 1.0f);
+    }
+    const float bh = rh / (float)a.P, bw = rw / (float)a.P;
+    const int gh = a.ratio > 0 ? a.ratio : (int)ceilf(rh / (float)a.P);
+    const int gw = a.ratio > 0 ? a.ratio : (int)ceilf(rw / (float)a.P);
+    const float count = (float)max(gh * gw, 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C4 = a.C >> 2;
+    const float *orow = a.dout + (size_t)row * a.P * a.P * a.C;
+
+    // weight tables per bin row / bin column: up to KMAX cells each; longer sampling lattices are walked in windows
+    constexpr int KMAX = 16, PMAX = 16;
+    __shared__ float WY[PMAX][KMAX], WX[PMAX][KMAX];
+    __shared__ int Y0[PMAX], NY[PMAX], X0[PMAX], NX[PMAX];
+    if (a.P > PMAX) return;  // refused on the host side
+    // sample lattices longer than KMAX-1 are processed in passes of (KMAX-1) samples per axis
+    const int passes_y = (gh + KMAX - 2) / (KMAX - 1), passes_x = (gw + KMAX - 2) / (KMAX - 1);
+    for (int py = 0; py < passes_y; ++py)
+        for (int px = 0; px < passes_x; ++px) {
+            __syncthreads();
+            if (threadIdx.x < 2 * a.P) {
+                const bool isx = threadIdx.x >= a.P;
+                const int p = isx ? threadIdx.x - a.P : threadIdx.x;
+                const int g = isx ? gw : gh, L = isx ? W : H;
+                const int i0 = (isx ? px : py) * (KMAX - 1), i1 = min(g, i0 + KMAX - 1);
+                const float start = isx ? x1 : y1, bsz = isx ? bw : bh;
+                float *wt = isx ? WX[p] : WY[p];
+                for (int k = 0; k < KMAX; ++k) wt[k] = 0.f;
+                int base = -1, last = -1;
+                for (int i = i0; i < i1; ++i) {
+                    float v = start + (float)p * bsz + ((float)i + 0.5f) * bsz / (float)g;
+                    if (v < -1.0f || v > (float)L) continue;
+                    if (v <= 0.f) v = 0.f;
+                    int lo = (int)v, hi;
+                    if (lo >= L - 1) {
+                        hi = lo = L - 1;
+                        v = (float)lo;
+                    } else
+                        hi = lo + 1;
+                    const float l = v - (float)lo, h = 1.0f - l;
+                    if (base < 0) base = lo;
+                    wt[lo - base] += h;
+                    wt[hi - base] += l;
+                    last = hi;
+                }
+                (isx ? X0 : Y0)[p] = base < 0 ? 0 : base;
+                (isx ? NX : NY)[p] = base < 0 ? 0 : last - base + 1;
+            }
+            __syncthreads();
+            for (int bin = wave; bin < a.P * a.P; bin += 4) {
+                const int ph = bin / a.P, pw = bin - ph * a.P;
+                const int ry0 = Y0[ph], ny = NY[ph], rx0 = X0[pw], nx = NX[pw];
+                for (int c4 = lane; c4 < C4; c4 += 64) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) / count;
+                    for (int ky = 0; ky < ny; ++ky) {
+                        const float wy = WY[ph][ky];
+                        float *frow = feat + ((size_t)(ry0 + ky) * W + rx0) * a.C + c4 * 4;
+                        for (int kx = 0; kx < nx; ++kx) {
+                            const float w = wy * WX[pw][kx];
+                            if (w == 0.f) continue;
+                            float *dst = frow + (size_t)kx * a.C;
+                            unsafeAtomicAdd(dst + 0, w * g[0]);
+                            unsafeAtomicAdd(dst + 1, w * g[1]);
+                            unsafeAtomicAdd(dst + 2, w * g[2]);
+                            unsafeAtomicAdd(dst + 3, w * g[3]);
+                        }
+                    }
+                }
+            }
+        }
+}
+
+extern "C" int a3d_roi_align_fpn_backward(const a3d_roialign_bwd_desc *d, void *stream) {
+    if (!d || !d->boxes || !d->dout || d->L < 1 || d->L > 4 || (d->C & 3) || d->B <= 0 || d->R <= 0 || d->P <= 0 || d->P > 16)
+        return A3D_ERR_ARG;
+    if (d->sampling_ratio > 0) return A3D_ERR_UNSUPPORTED;  // adaptive lattices only (samples <= 1 cell apart): the box pooler
+    RoiBwdArgs a;
+    for (int l = 0; l < 4; ++l) {
+        a.dfeat[l] = l < d->L ? d->dfeat[l] : nullptr;
+        a.Hf[l] = d->Hf[l];
+        a.Wf[l] = d->Wf[l];
+        a.scale[l] = d->scale[l];
+        if (l < d->L && !d->dfeat[l]) return A3D_ERR_ARG;
+    }
+    a.L = d->L;
+    a.C = d->C;
+    a.boxes = d->boxes;
+    a.count = d->count;
+    a.row_offset = d->row_offset;
+    a.R = d->R;
+    a.P = d->P;
+    a.ratio = d->sampling_ratio;
+    a.aligned = d->aligned;
+    a.dout = d->dout;
+    a3d_begin();
+    hipLaunchKernelGGL(roi_align_fpn_backward_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    return a3d_check_launch();
+}

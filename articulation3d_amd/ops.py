@@ -210,7 +210,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -238,6 +238,9 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     d.Kpad, d.ups, d.act = p.Kpad, int(ups), p.act if act is None else act
     d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), int(p.pixshuf), int(p.stem), int(splitk)
     d.m_dev = _p(m_dev)
+    if gate is not None:
+        assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
+        d.gate = gate.data_ptr()
     d.tune = int(tune)
     d.phase = int(p.phase)
     # Winograd F(2x2,3x3) for 3x3 s1 p1 layers.  The choice must not depend on the batch / ROI count (a frame's

@@ -1,0 +1,167 @@
+"""Host-side wrappers over the training-step kernels of include/a3d.h.  Like ops.py: torch tensors
+carry device memory only, all arithmetic happens in liba3d_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from .ops import _p, _req, _stream
+
+
+def choose_wgrad_slices(P: int, tiles: int) -> int:
+    """Pixel slices of a weight-gradient GEMM: enough workgroups to fill 256 CUs x 4, each slice >= 64 pixels.
+    Depends on the layer shape only (deterministic summation order for a given batch size)."""
+    want = max(1, 1024 // max(tiles, 1))
+    return int(max(1, min(want, P // 64 if P >= 64 else 1, 256)))
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int, pad: int,
+               scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None) -> torch.Tensor:
+    """dw [Cout, KH*KW*Cin] (=/+=) weight gradient of y = conv(x) given dy (NHWC tensors)."""
+    _req(x), _req(dy), _req(dw)
+    B, H, W, Cin = x.shape
+    B2, Ho, Wo, Cout = dy.shape
+    assert B == B2 and dw.numel() == Cout * KH * KW * Cin, (x.shape, dy.shape, dw.shape)
+    d = _lib.WgradDesc()
+    d.x, d.dy, d.scale, d.dw = _p(x), _p(dy), _p(scale), _p(dw)
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * KH * KW
+    d.splitk = int(splitk) if splitk else choose_wgrad_slices(B * Ho * Wo, tiles)
+    d.accumulate = int(accumulate)
+    ws = torch.empty(_lib.lib().a3d_wgrad_workspace_bytes(C.byref(d)) // 4, device=x.device, dtype=torch.float32)
+    d.workspace = ws.data_ptr()
+    _lib.check(_lib.lib().a3d_conv_wgrad_nhwc_f32(C.byref(d), _stream()), "a3d_conv_wgrad_nhwc_f32")
+    return dw
+
+
+def weight_transpose(w: torch.Tensor, out: torch.Tensor, Cout: int, KH: int, KW: int, Cin: int,
+                     scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert _req(w).numel() == Cout * KH * KW * Cin == _req(out).numel()
+    _lib.check(_lib.lib().a3d_weight_transpose(_p(w), _p(scale), _p(out), Cout, KH, KW, Cin, _stream()), "a3d_weight_transpose")
+    return out
+
+
+def wino_weight_transform(w: torch.Tensor, out: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    assert _req(w).numel() == Cout * 9 * Cin and _req(out).numel() == 16 * Cout * Cin
+    _lib.check(_lib.lib().a3d_wino_weight_transform(_p(w), _p(out), Cout, Cin, _stream()), "a3d_wino_weight_transform")
+    return out
+
+
+def zero_insert2(x: torch.Tensor, Ho: int, Wo: int, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    B, H, W, Cc = _req(x).shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_zero_insert2_nhwc(_p(x), _p(out), B, H, W, Cc, Ho, Wo, int(accumulate), _stream()), "a3d_zero_insert2_nhwc")
+    return out
+
+
+def sumpool2_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc = _req(y).shape
+    assert tuple(_req(x).shape) == (B, 2 * H, 2 * W, Cc)
+    _lib.check(_lib.lib().a3d_sumpool2_add_nhwc(_p(x), _p(y), B, H, W, Cc, _stream()), "a3d_sumpool2_add_nhwc")
+    return y
+
+
+def colsum(dy: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    Cc = dy.shape[-1]
+    M = dy.numel() // Cc
+    assert _req(out).numel() >= Cc
+    ws = torch.empty(_lib.lib().a3d_colsum_workspace_bytes(Cc) // 4, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_colsum(_p(_req(dy)), _p(out), _p(ws), M, Cc, int(accumulate), _stream()), "a3d_colsum")
+    return out
+
+
+def roi_align_fpn_backward(dfeats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, dout: torch.Tensor, *,
+                           P: int, sampling_ratio: int, aligned: bool, count: Optional[torch.Tensor] = None,
+                           row_offset: Optional[torch.Tensor] = None) -> None:
+    """dfeats[l] [B,Hf,Wf,C] += gradient of roi_align_fpn with respect to level l.  boxes [B,R,4], dout [rows,P,P,C]."""
+    d = _lib.RoiAlignBwdDesc()
+    for l, f in enumerate(dfeats):
+        _req(f)
+        d.dfeat[l], d.Hf[l], d.Wf[l], d.scale[l] = f.data_ptr(), f.shape[1], f.shape[2], float(scales[l])
+    d.L, d.C = len(dfeats), dfeats[0].shape[3]
+    d.boxes, d.count, d.row_offset = _p(_req(boxes)), _p(count), _p(row_offset)
+    d.B, d.R, d.P, d.sampling_ratio, d.aligned = boxes.shape[0], boxes.shape[1], P, sampling_ratio, int(aligned)
+    d.dout = _p(_req(dout))
+    _lib.check(_lib.lib().a3d_roi_align_fpn_backward(C.byref(d), _stream()), "a3d_roi_align_fpn_backward")
+
+
+def match_boxes(boxes: torch.Tensor, gt_boxes: torch.Tensor, gt_count: torch.Tensor, *, thresholds, labels, allow_low_quality: bool,
+                shared: bool = False, box_count: Optional[torch.Tensor] = None, return_iou: bool = False):
+    """boxes [N,4] (shared=True: the same anchors for every image) or [B,N,4]; gt_boxes [B,Gmax,4]; gt_count [B] int32.
+    -> matched_idx int32 [B,N], label int8 [B,N] (, iou [B,N])."""
+    _req(boxes), _req(gt_boxes), _req(gt_count, torch.int32)
+    B, Gmax = gt_boxes.shape[:2]
+    N = boxes.shape[-2]
+    d = _lib.MatchDesc()
+    d.boxes, d.box_count, d.gt_boxes, d.gt_count = _p(boxes), _p(box_count), _p(gt_boxes), _p(gt_count)
+    d.B, d.N, d.Gmax, d.box_batch_stride = B, N, Gmax, 0 if shared else N
+    for i, t in enumerate(thresholds):
+        d.thresholds[i] = float(t)
+    for i, l in enumerate(labels):
+        d.labels[i] = int(l)
+    d.n_thresholds, d.allow_low_quality = len(thresholds), int(allow_low_quality)
+    best = torch.empty((B, Gmax), device=boxes.device, dtype=torch.int32) if allow_low_quality else None
+    midx = torch.zeros((B, N), device=boxes.device, dtype=torch.int32)
+    lab = torch.full((B, N), -1, device=boxes.device, dtype=torch.int8)
+    iou = torch.zeros((B, N), device=boxes.device, dtype=torch.float32) if return_iou else None
+    d.gt_best, d.matched_idx, d.label, d.matched_iou = _p(best), _p(midx), _p(lab), _p(iou)
+    _lib.check(_lib.lib().a3d_match_boxes(C.byref(d), _stream()), "a3d_match_boxes")
+    return (midx, lab, iou) if return_iou else (midx, lab)
+
+
+def rpn_loss(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_anchors: torch.Tensor, labels: torch.Tensor,
+             matched_idx: torch.Tensor, gt_boxes: torch.Tensor, *, A: int, weights, normalizer: float):
+    """heads[l] [B,Hf,Wf,CH] -> (loss [2] = (loss_rpn_cls, loss_rpn_loc), dheads list of the same shapes)."""
+    d = _lib.RpnLossDesc()
+    dheads = []
+    ca = cell_anchors.detach().cpu().float()
+    for l, h in enumerate(heads):
+        _req(h)
+        g = torch.empty_like(h)
+        dheads.append(g)
+        d.head[l], d.dhead[l], d.Hf[l], d.Wf[l], d.stride[l] = h.data_ptr(), g.data_ptr(), h.shape[1], h.shape[2], int(strides[l])
+        for a in range(A):
+            for k in range(4):
+                d.cell_anchors[l][a][k] = float(ca[l, a, k])
+    d.B, d.L, d.A, d.CH = heads[0].shape[0], len(heads), A, heads[0].shape[3]
+    d.Atotal, d.Gmax = labels.shape[1], gt_boxes.shape[1]
+    d.labels, d.matched_idx, d.gt_boxes = _p(_req(labels, torch.int8)), _p(_req(matched_idx, torch.int32)), _p(_req(gt_boxes))
+    for k in range(4):
+        d.weights[k] = float(weights[k])
+    d.normalizer = float(normalizer)
+    ws = torch.empty(_lib.lib().a3d_loss_workspace_bytes() // 4, device=labels.device, dtype=torch.float32)
+    loss = torch.empty(2, device=labels.device, dtype=torch.float32)
+    d.workspace, d.loss = ws.data_ptr(), loss.data_ptr()
+    _lib.check(_lib.lib().a3d_rpn_loss(C.byref(d), _stream()), "a3d_rpn_loss")
+    return loss, dheads
+
+
+def box_loss(pred: torch.Tensor, gt_classes: torch.Tensor, boxes: torch.Tensor, gt_boxes: torch.Tensor, *, num_classes: int, weights):
+    """pred [M,pitch] fused predictor rows -> (loss [2] = (loss_cls, loss_box_reg), dpred [M,pitch])."""
+    M, pitch = _req(pred).shape
+    d = _lib.BoxLossDesc()
+    dpred = torch.empty_like(pred)
+    d.pred, d.dpred = pred.data_ptr(), dpred.data_ptr()
+    d.gt_classes, d.boxes, d.gt_boxes = _p(_req(gt_classes, torch.int32)), _p(_req(boxes)), _p(_req(gt_boxes))
+    d.M, d.num_classes, d.pitch = M, num_classes, pitch
+    for k in range(4):
+        d.weights[k] = float(weights[k])
+    ws = torch.empty(_lib.lib().a3d_loss_workspace_bytes() // 4, device=pred.device, dtype=torch.float32)
+    loss = torch.empty(2, device=pred.device, dtype=torch.float32)
+    d.workspace, d.loss = ws.data_ptr(), loss.data_ptr()
+    _lib.check(_lib.lib().a3d_box_loss(C.byref(d), _stream()), "a3d_box_loss")
+    return loss, dpred
+
+
+def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, *, lr: float, momentum: float, weight_decay: float,
+                 grad_scale: float = 1.0, first: bool = False) -> None:
+    n = _req(p).numel()
+    assert _req(g).numel() == n == _req(buf).numel()
+    _lib.check(_lib.lib().a3d_sgd_momentum(_p(p), _p(g), _p(buf), n, lr, momentum, weight_decay, grad_scale, int(first), _stream()),
+               "a3d_sgd_momentum")

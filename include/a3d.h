@@ -32,6 +32,10 @@ extern "C" {
 #define A3D_ACT_LEAKY 2 /* slope 0.01, pkg/modeling/depth_net/depth_head.py:36 */
 
 int a3d_version(void);
+/* sizeof() of a descriptor struct, for bindings to verify their mirror of the layout.  id: 0 a3d_conv_desc, 1 a3d_rpn_desc,
+ * 2 a3d_boxdet_desc, 3 a3d_roialign_desc, 4 a3d_paste_desc, 5 a3d_pack_desc, 6 a3d_wgrad_desc, 7 a3d_roialign_bwd_desc,
+ * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc; 0 for an unknown id. */
+size_t a3d_struct_size(int id);
 
 /* ------------------------------------------------------------------------------------------------
  * Pre-processing.  Replaces PlaneRCNN.preprocess_image (pkg/modeling/meta_arch/planercnn.py:188-196)
@@ -84,6 +88,9 @@ typedef struct a3d_conv_desc {
     const float *w_wino; /* optional Winograd-domain weights U = G g G^T, [16][Cout][Cin+Cin2] (3x3 s1 p1 only):
                             when given (and workspace holds a3d_conv_workspace_bytes) the layer runs as
                             F(2x2,3x3): 2.25x fewer MFMA cycles, same result within fp32 rounding           */
+    const float *gate;   /* optional [B,Ho,Wo,Cout]: outputs are zeroed where gate <= 0 -- the ReLU backward of the
+                            training step (section "Training step" below): y = dgrad(...) * (forward activation > 0).
+                            Plain output layout only (no pixshuf / phase)                                     */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -252,6 +259,120 @@ typedef struct a3d_pack_desc {
 
 int a3d_record_floats(int MS);
 int a3d_detections_pack(const a3d_pack_desc *d, void *stream);
+
+/* ================================================================================================
+ * Training step (BASELINE configs[4]: config/step1_bbox.yaml).
+ * Replaces, under autograd, the training branch of PlaneRCNN.forward (pkg/modeling/meta_arch/planercnn.py:83-123),
+ * the box branch of PlaneRCNNROIHeads.forward (pkg/modeling/roi_heads/roi_heads.py:93-117,190-204) and the SGD step
+ * of the detectron2 trainer behind tools/train_net.py:84-117.  Data gradients of convolutions reuse
+ * a3d_conv2d_nhwc_f32 with a3d_weight_transpose'd filters and the `gate` epilogue (ReLU backward).
+ * ============================================================================================== */
+
+/* dw[co][kh][kw][ci] (=/+=) scale[co] * sum_pixels dy[b,oh,ow,co] * x[b, oh*stride+kh-pad, ow*stride+kw-pad, ci]
+ * (autograd's weight gradient of every Conv2d / Linear on the trainable path; dw has the packed forward layout). */
+typedef struct a3d_wgrad_desc {
+    const float *x;     /* forward input NHWC [B,H,W,Cin]                    */
+    const float *dy;    /* gradient of the layer output [B,Ho,Wo,Cout]       */
+    const float *scale; /* optional [Cout]: folded FrozenBN scale that followed the conv in the forward pass */
+    float *dw;          /* [Cout][KH][KW][Cin]                               */
+    float *workspace;   /* a3d_wgrad_workspace_bytes()                       */
+    int B, H, W, Cin, Ho, Wo, Cout; /* Cin % 4 == 0, Cout % 4 == 0           */
+    int KH, KW, stride, pad;
+    int splitk;         /* >= 1 pixel slices (summed in slice order: deterministic) */
+    int accumulate;     /* 1: dw += (weights shared by several call sites, e.g. the RPN head over 5 levels) */
+} a3d_wgrad_desc;
+size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
+int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);
+
+/* wt[ci][KH-1-kh][KW-1-kw][co] = scale[co] * w[co][kh][kw][ci]: the filter of the data gradient. */
+int a3d_weight_transpose(const float *w, const float *scale, float *wt, int Cout, int KH, int KW, int Cin, void *stream);
+/* U = G g G^T of a packed 3x3 filter [Cout][3][3][Cin] -> [16][Cout][Cin] (a3d_conv_desc.w_wino), on the device. */
+int a3d_wino_weight_transform(const float *w, float *U, int Cout, int Cin, void *stream);
+
+/* y [B,Ho,Wo,C] (=/+=) x [B,ceil(Ho/2),ceil(Wo/2),C] at even pixels, 0 elsewhere (backward of a3d_subsample2_nhwc and
+ * of the input sub-sampling of a stride-2 1x1 convolution). */
+int a3d_zero_insert2_nhwc(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, int accumulate, void *stream);
+/* y [B,H,W,C] += 2x2 block sums of x [B,2H,2W,C] (backward of the nearest-x2 upsampling of the FPN top-down path). */
+int a3d_sumpool2_add_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);
+/* out[c] (=/+=) sum_m dy[m,c]  (bias gradients). */
+size_t a3d_colsum_workspace_bytes(int C);
+int a3d_colsum(const float *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream);
+
+/* Gradient of a3d_roi_align_fpn with respect to the pyramid: dfeat[level] += scatter(dout).  dfeat must hold the
+ * gradient accumulated so far (or zeros).  Adaptive sampling (sampling_ratio 0) only: the box pooler. */
+typedef struct a3d_roialign_bwd_desc {
+    float *dfeat[4];
+    int Hf[4], Wf[4];
+    float scale[4];
+    int L, C;
+    const float *boxes;    /* [B,R,4] */
+    const int *count;      /* [B] or NULL */
+    const int *row_offset; /* [B] or NULL */
+    int B, R, P, sampling_ratio, aligned;
+    const float *dout;     /* [rows,P,P,C] */
+} a3d_roialign_bwd_desc;
+int a3d_roi_align_fpn_backward(const a3d_roialign_bwd_desc *d, void *stream);
+
+/* detectron2 Matcher over pairwise_iou(gt, boxes) (RPN.label_and_sample_anchors, ROIHeads.label_and_sample_proposals):
+ * matched_idx[b,i] = argmax_g IoU (first maximum), label[b,i] = labels[k] for IoU in [thresholds[k-1], thresholds[k]),
+ * and with allow_low_quality every box attaining some gt's best IoU gets label 1.  Images without gt: labels[0]. */
+typedef struct a3d_match_desc {
+    const float *boxes;     /* [*, N, 4]; image b reads boxes + b*box_batch_stride*4 (stride 0: shared anchors) */
+    const int *box_count;   /* [B] live boxes per image or NULL (= N) */
+    const float *gt_boxes;  /* [B, Gmax, 4] */
+    const int *gt_count;    /* [B] */
+    int B, N, Gmax, box_batch_stride;
+    float thresholds[2];
+    int labels[3];
+    int n_thresholds;       /* 1 or 2 */
+    int allow_low_quality;
+    unsigned int *gt_best;  /* scratch [B, Gmax] (allow_low_quality only) */
+    int *matched_idx;       /* [B, N] */
+    signed char *label;     /* [B, N] */
+    float *matched_iou;     /* [B, N] or NULL */
+} a3d_match_desc;
+int a3d_match_boxes(const a3d_match_desc *d, void *stream);
+
+/* RPN.losses + its gradient with respect to the head outputs (layout of a3d_rpn_desc.head).  loss[0] = loss_rpn_cls,
+ * loss[1] = loss_rpn_loc.  labels: -1 ignore, 0 negative, 1 positive AFTER sub-sampling; anchor order: level-major,
+ * then (y, x, a). */
+typedef struct a3d_rpn_loss_desc {
+    const float *head[5];
+    float *dhead[5];
+    int Hf[5], Wf[5], stride[5];
+    float cell_anchors[5][3][4];
+    int B, L, A, CH, Atotal, Gmax;
+    const signed char *labels; /* [B, Atotal] */
+    const int *matched_idx;    /* [B, Atotal] */
+    const float *gt_boxes;     /* [B, Gmax, 4] */
+    float weights[4];          /* Box2BoxTransform weights (1,1,1,1) */
+    float normalizer;          /* RPN.BATCH_SIZE_PER_IMAGE * images */
+    float *workspace;          /* a3d_loss_workspace_bytes() */
+    float *loss;               /* [2] */
+} a3d_rpn_loss_desc;
+size_t a3d_loss_workspace_bytes(void);
+int a3d_rpn_loss(const a3d_rpn_loss_desc *d, void *stream);
+
+/* FastRCNNOutputLayers.losses + gradient with respect to the fused predictor output rows:
+ * pred[r] = [K+1 class scores (K = background) | 4K deltas, class-major | padding up to pitch].
+ * loss[0] = loss_cls (mean cross entropy), loss[1] = loss_box_reg (L1 on foreground rows / M). */
+typedef struct a3d_box_loss_desc {
+    const float *pred;     /* [M, pitch] */
+    float *dpred;          /* [M, pitch] */
+    const int *gt_classes; /* [M] in [0, K] */
+    const float *boxes;    /* [M,4] sampled proposal boxes */
+    const float *gt_boxes; /* [M,4] matched ground truth (unused for background rows) */
+    int M, num_classes, pitch;
+    float weights[4];      /* (10,10,5,5) */
+    float *workspace;      /* a3d_loss_workspace_bytes() */
+    float *loss;           /* [2] */
+} a3d_box_loss_desc;
+int a3d_box_loss(const a3d_box_loss_desc *d, void *stream);
+
+/* torch.optim.SGD (momentum, weight decay) over a flat buffer; n % 4 == 0.
+ * d = grad_scale*g + wd*p;  buf = first ? d : momentum*buf + d;  p -= lr*buf */
+int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
+                     int first, void *stream);
 
 #ifdef __cplusplus
 }

@@ -96,3 +96,55 @@ void orc_nms_sorted(const float *boxes, const int32_t *cat, int n, float thr, ui
     }
     free(sup);
 }
+
+/*
+ * Gradient of orc_roi_align_nchw with respect to feat (torchvision roi_align_backward as published:
+ * every sample scatters grad_bin / count times its four bilinear weights).  dfeat must be zeroed by the
+ * caller; accumulation is double precision per element so the oracle's value does not depend on the
+ * scatter order.  Used by oracle/train_oracle.py (the box branch of the training step,
+ * reference call site pkg/modeling/roi_heads/roi_heads.py:185 under autograd).
+ */
+void orc_roi_align_backward_nchw(const float *dout, int N, int C, int H, int W, const float *rois, int K,
+                                 int P, float scale, int sampling_ratio, int aligned, double *dfeat) {
+    (void)N;
+    for (int k = 0; k < K; ++k) {
+        const float *r = rois + (size_t)k * 5;
+        int b = (int)r[0];
+        float off = aligned ? 0.5f : 0.0f;
+        float x1 = r[1] * scale - off, y1 = r[2] * scale - off;
+        float x2 = r[3] * scale - off, y2 = r[4] * scale - off;
+        float rw = x2 - x1, rh = y2 - y1;
+        if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+        float bh = rh / (float)P, bw = rw / (float)P;
+        int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
+        int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
+        float count = (float)(gh * gw > 1 ? gh * gw : 1);
+        for (int ph = 0; ph < P; ++ph)
+            for (int pw = 0; pw < P; ++pw)
+                for (int iy = 0; iy < gh; ++iy) {
+                    float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                    if (y < -1.0f || y > (float)H) continue;
+                    if (y <= 0.0f) y = 0.0f;
+                    int yl = (int)y, yh;
+                    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                    float ly = y - (float)yl, hy = 1.0f - ly;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                        if (x < -1.0f || x > (float)W) continue;
+                        if (x <= 0.0f) x = 0.0f;
+                        int xl = (int)x, xh;
+                        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                        float lx = x - (float)xl, hx = 1.0f - lx;
+                        float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                        for (int c = 0; c < C; ++c) {
+                            double g = (double)dout[(((size_t)k * C + c) * P + ph) * P + pw] / (double)count;
+                            double *plane = dfeat + ((size_t)b * C + c) * H * W;
+                            plane[yl * W + xl] += g * w1;
+                            plane[yl * W + xh] += g * w2;
+                            plane[yh * W + xl] += g * w3;
+                            plane[yh * W + xh] += g * w4;
+                        }
+                    }
+                }
+    }
+}

@@ -1,0 +1,270 @@
+"""GPU suite (-m gpu) for the training step: every backward / loss / optimiser kernel through the
+C ABI against torch autograd on the CPU (floating-point kernels) or the CPU oracle (oracle/train_oracle.py), then the
+whole step against the oracle's loss_and_grads on identical sampled index sets.
+
+Tolerances (fp32): gradients are long sums, compared by relative L2 error per tensor (<= 2e-4: the oracle's own fp32
+summation-order noise against float64 is ~1e-5..1e-4 on the deepest layers); matcher labels / indices bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def l2rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.fixture(scope="module")
+def T():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from articulation3d_amd import train_ops
+
+    return train_ops
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from articulation3d_amd import ops as o
+
+    return o
+
+
+WG_CASES = [
+    dict(B=2, H=30, W=40, Cin=256, Cout=128, k=1, s=1, p=0),
+    dict(B=2, H=30, W=40, Cin=256, Cout=512, k=1, s=2, p=0),
+    dict(B=2, H=15, W=20, Cin=128, Cout=128, k=3, s=1, p=1),
+    dict(B=1, H=9, W=7, Cin=36, Cout=20, k=3, s=1, p=1),  # ragged channel tiles
+    dict(B=1000, H=1, W=1, Cin=1024, Cout=32, k=1, s=1, p=0),  # predictor-shaped linear
+    dict(B=3, H=8, W=10, Cin=256, Cout=32, k=1, s=1, p=0),
+]
+
+
+@pytest.mark.parametrize("c", WG_CASES, ids=lambda c: f"{c['Cin']}to{c['Cout']}k{c['k']}s{c['s']}")
+def test_conv_wgrad_vs_autograd(T, c):
+    torch.manual_seed(1)
+    x = torch.randn(c["B"], c["Cin"], c["H"], c["W"])
+    w = torch.randn(c["Cout"], c["Cin"], c["k"], c["k"], requires_grad=True)
+    y = F.conv2d(x, w, None, c["s"], c["p"])
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    scale = torch.rand(c["Cout"]) + 0.5
+    ref = w.grad.permute(0, 2, 3, 1).reshape(c["Cout"], -1)
+    dw = torch.full((c["Cout"], c["k"] * c["k"] * c["Cin"]), 7.0, device="cuda")
+    T.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, KH=c["k"], KW=c["k"], stride=c["s"], pad=c["p"])
+    assert l2rel(dw, ref) < 1e-5
+    # folded-BN scale + accumulation + an explicit slice count (deterministic: two runs agree bit for bit)
+    dw2 = dw.clone()
+    T.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw2, KH=c["k"], KW=c["k"], stride=c["s"], pad=c["p"], scale=scale.cuda(),
+                 accumulate=True, splitk=3)
+    assert l2rel(dw2, ref + ref * scale[:, None]) < 1e-5
+    dw3 = dw.clone()
+    T.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw3, KH=c["k"], KW=c["k"], stride=c["s"], pad=c["p"], scale=scale.cuda(),
+                 accumulate=True, splitk=3)
+    assert torch.equal(dw2, dw3)
+
+
+@pytest.mark.parametrize("k,s,wino", [(3, 1, False), (3, 1, True), (1, 1, False), (1, 2, False)])
+def test_conv_dgrad_through_forward_kernel(T, ops, k, s, wino):
+    """dx = conv(dy, transposed + flipped filter) with the ReLU gate and the residual add fused, vs autograd."""
+    torch.manual_seed(2)
+    B, Cin, Cout, H, W = 2, 128, 256, 30, 40
+    x = torch.randn(B, Cin, H, W, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k) / (k * k * Cin) ** 0.5
+    scale = torch.rand(Cout) + 0.5
+    pre = torch.randn(B, Cin, H, W)  # the forward tensor whose ReLU produced x: gate = pre > 0
+    y = F.conv2d(F.relu(pre) * 0 + x * (pre > 0), w, None, s, k // 2) * scale[None, :, None, None]
+    dy = torch.randn_like(y)
+    extra = torch.randn(B, Cin, H, W)  # gradient arriving on the identity shortcut
+    y.backward(dy)
+    ref = x.grad + extra * (pre > 0)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().cuda()
+    wt = torch.empty(Cin * k * k * Cout, device="cuda")
+    T.weight_transpose(wp, wt, Cout, k, k, Cin, scale=scale.cuda())
+    pk = ops.PackedConv(wt.view(Cin, k * k * Cout), None, None, k, k, 1, k // 2, Cout, Cin, k * k * Cout)
+    if wino:
+        U = torch.empty(16 * Cin * Cout, device="cuda")
+        T.wino_weight_transform(wt, U, Cin, Cout)
+        pk.w_wino = U.view(16, Cin, Cout)
+    dyd = nhwc(dy).cuda()
+    gate = nhwc(pre).cuda()
+    if s == 1:
+        if wino:  # the Winograd form has no residual operand: add the shortcut gradient before gating is not possible -> gate only
+            dx = ops.conv2d(dyd, pk, wino=True, gate=gate)
+            ref = x.grad
+        else:
+            dx = ops.conv2d(dyd, pk, res=nhwc(extra).cuda(), gate=gate, wino=False)
+    else:
+        low = ops.conv2d(dyd, pk, wino=False)
+        up = T.zero_insert2(low, H, W)
+        dx = up * (gate > 0) + nhwc(extra).cuda() * (gate > 0)  # (test-side combination; the step fuses it into the next conv)
+    assert l2rel(dx, nhwc(ref)) < (5e-6 if not wino else 2e-5)
+
+
+def test_wino_weight_transform_matches_host_packing(T, ops):
+    torch.manual_seed(3)
+    w = torch.randn(64, 48, 3, 3)
+    ref = ops.winograd_weights(w)
+    wp = w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().cuda()
+    U = torch.empty(16 * 64 * 48, device="cuda")
+    T.wino_weight_transform(wp, U, 64, 48)
+    assert l2rel(U.view(16, 64, 48), ref) < 1e-6
+
+
+def test_spatial_gradient_plumbing(T):
+    torch.manual_seed(4)
+    x = torch.randn(2, 8, 10, 64, device="cuda")
+    y = T.zero_insert2(x, 15, 20)
+    ref = torch.zeros(2, 15, 20, 64, device="cuda")
+    ref[:, ::2, ::2] = x
+    assert torch.equal(y, ref)
+    T.zero_insert2(x, 15, 20, out=y, accumulate=True)
+    assert torch.equal(y, 2 * ref)
+    big = torch.randn(2, 16, 20, 64, device="cuda")
+    acc = torch.randn(2, 8, 10, 64, device="cuda")
+    want = acc + big.view(2, 8, 2, 10, 2, 64).sum((2, 4))
+    T.sumpool2_add(big, acc)
+    assert l2rel(acc, want) < 1e-6
+    dy = torch.randn(5000, 264, device="cuda")
+    out = torch.ones(264, device="cuda")
+    T.colsum(dy, out, accumulate=True)
+    assert l2rel(out, 1 + dy.double().sum(0)) < 1e-6
+
+
+def test_roi_align_backward_vs_oracle(T, oracle):
+    from oracle import train_oracle as TO
+
+    torch.manual_seed(5)
+    B, C, R = 2, 64, 37
+    feats = {n: torch.randn(B, C, 480 // s, 640 // s, requires_grad=True) for n, s in (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32))}
+    g = torch.Generator().manual_seed(5)
+    wh = torch.rand(B, R, 2, generator=g) * torch.tensor([500.0, 400.0]) + 4
+    xy = torch.rand(B, R, 2, generator=g) * (torch.tensor([640.0, 480.0]) - wh * 0.8)
+    boxes = torch.cat([xy, xy + wh], 2)
+    boxes[0, 0] = torch.tensor([-20.0, -30.0, 700.0, 520.0])  # outside the image
+    boxes[1, 1] = torch.tensor([100.0, 100.0, 100.5, 100.2])  # tiny
+    pooled = TO.roi_pool_fpn_diff(feats, [boxes[0], boxes[1]], 7, 0, True)
+    dout = torch.randn_like(pooled)
+    pooled.backward(dout)
+    dfe = [torch.zeros(B, f.shape[2], f.shape[3], C, device="cuda") for f in feats.values()]
+    T.roi_align_fpn_backward(dfe, [1 / 4, 1 / 8, 1 / 16, 1 / 32], boxes.cuda(), nhwc(dout).contiguous().cuda(), P=7,
+                             sampling_ratio=0, aligned=True)
+    for d, f in zip(dfe, feats.values()):
+        assert l2rel(d, nhwc(f.grad)) < 1e-5
+
+
+def test_matcher_bit_exact_vs_oracle(T, oracle):
+    from oracle import train_oracle as TO
+
+    cfg, tc = oracle.OracleCfg(), TO.TrainCfg()
+    feat_hw = [(120, 160), (60, 80), (30, 40), (15, 20), (8, 10)]
+    anchors = TO.all_anchors(feat_hw, cfg)
+    tg = TO.synthetic_targets(3)
+    tg[2] = (tg[2][0][:0], tg[2][1][:0])  # an image without ground truth
+    Gmax = 8
+    gtb = torch.zeros(3, Gmax, 4)
+    cnt = torch.zeros(3, dtype=torch.int32)
+    for i, (b, _) in enumerate(tg):
+        gtb[i, : len(b)] = b
+        cnt[i] = len(b)
+    midx, lab = T.match_boxes(anchors.cuda(), gtb.cuda(), cnt.cuda(), thresholds=tc.rpn_iou_thresholds, labels=(0, -1, 1),
+                              allow_low_quality=True, shared=True)
+    for i, (b, _) in enumerate(tg):
+        ri, rl = TO.matcher(TO.pairwise_iou(b, anchors), tc.rpn_iou_thresholds, (0, -1, 1), True)
+        assert torch.equal(lab[i].cpu(), rl)
+        assert torch.equal(midx[i].cpu().long(), ri)
+    # proposal matcher: per-image boxes, one threshold, no low-quality matches
+    g = torch.Generator().manual_seed(6)
+    props = torch.rand(3, 500, 4, generator=g) * 300
+    props[..., 2:] += props[..., :2] + 5
+    props[0, :4] = tg[0][0][:4] if len(tg[0][0]) >= 4 else props[0, :4]
+    midx, lab, iou = T.match_boxes(props.cuda(), gtb.cuda(), cnt.cuda(), thresholds=(0.5,), labels=(0, 1), allow_low_quality=False,
+                                   return_iou=True)
+    for i, (b, _) in enumerate(tg):
+        q = TO.pairwise_iou(b, props[i])
+        ri, rl = TO.matcher(q, (0.5,), (0, 1), False)
+        assert torch.equal(lab[i].cpu(), rl) and torch.equal(midx[i].cpu().long(), ri)
+        if len(b):
+            assert torch.equal(iou[i].cpu(), q.max(0)[0])
+
+
+def test_rpn_and_box_losses_vs_oracle(T, oracle):
+    from oracle import train_oracle as TO
+
+    cfg, tc = oracle.OracleCfg(), TO.TrainCfg()
+    feat_hw = [(30, 40), (15, 20), (8, 10)]
+    strides = [16, 32, 64]
+    sizes = (128, 256, 512)
+    torch.manual_seed(7)
+    B, A, CH = 2, 3, 32
+    anchors = torch.cat([oracle.grid_anchors(h, w, s, z, cfg.anchor_ratios) for (h, w), s, z in zip(feat_hw, strides, sizes)], 0)
+    tg = TO.synthetic_targets(B)
+    gen = torch.Generator().manual_seed(7)
+    matched = TO.match_anchors(anchors, [t[0] for t in tg], tc)
+    labels = torch.stack([TO.sample_anchors(m[1], tc, gen) for m in matched])
+    heads = [torch.randn(B, h, w, CH) for h, w in feat_hw]
+    logits = [h[..., :A].reshape(B, -1).clone().requires_grad_(True) for h in heads]
+    deltas = [h[..., A : 5 * A].reshape(B, -1, 4).clone().requires_grad_(True) for h in heads]
+    mgt = torch.stack([t[0][m[0]] for t, m in zip(tg, matched)])
+    ref = TO.rpn_losses(logits, deltas, anchors, labels, mgt, cfg, tc)
+    (ref["loss_rpn_cls"] + ref["loss_rpn_loc"]).backward()
+    Gmax = 8
+    gtb = torch.zeros(B, Gmax, 4)
+    for i, (b, _) in enumerate(tg):
+        gtb[i, : len(b)] = b
+    midx = torch.stack([m[0] for m in matched]).int()
+    cell = torch.stack([oracle.cell_anchors(z, cfg.anchor_ratios) for z in sizes])
+    loss, dheads = T.rpn_loss([h.cuda() for h in heads], strides, cell, labels.cuda(), midx.cuda(), gtb.cuda(), A=A,
+                              weights=cfg.rpn_weights, normalizer=tc.rpn_batch_per_image * B)
+    assert abs(loss[0].item() - ref["loss_rpn_cls"].item()) < 1e-5 * abs(ref["loss_rpn_cls"].item()) + 1e-7
+    assert abs(loss[1].item() - ref["loss_rpn_loc"].item()) < 1e-5 * abs(ref["loss_rpn_loc"].item()) + 1e-7
+    for l, dh in enumerate(dheads):
+        dh = dh.cpu()
+        assert l2rel(dh[..., :A].reshape(B, -1), logits[l].grad) < 1e-5
+        assert torch.equal(dh[..., A : 5 * A].reshape(B, -1, 4), deltas[l].grad)  # +-1/normalizer or 0
+        assert float(dh[..., 5 * A :].abs().max()) == 0.0
+
+    # box losses
+    M, K, pitch = 700, cfg.num_classes, 32
+    pred = torch.randn(M, pitch)
+    cls = torch.randint(0, K + 1, (M,))
+    boxes = torch.rand(M, 4) * 300
+    boxes[:, 2:] += boxes[:, :2] + 8
+    gtbx = boxes + torch.randn(M, 4) * 6
+    gtbx[:, 2:] = torch.maximum(gtbx[:, 2:], gtbx[:, :2] + 4)
+    sc = pred[:, : K + 1].clone().requires_grad_(True)
+    dl = pred[:, K + 1 : K + 1 + 4 * K].clone().requires_grad_(True)
+    rb = TO.box_losses(sc, dl, boxes, cls, gtbx, cfg)
+    (rb["loss_cls"] + rb["loss_box_reg"]).backward()
+    loss, dpred = T.box_loss(pred.cuda(), cls.int().cuda(), boxes.cuda(), gtbx.cuda(), num_classes=K, weights=cfg.box_weights)
+    assert abs(loss[0].item() - rb["loss_cls"].item()) < 1e-5 * rb["loss_cls"].item()
+    assert abs(loss[1].item() - rb["loss_box_reg"].item()) < 1e-5 * rb["loss_box_reg"].item()
+    dpred = dpred.cpu()
+    assert l2rel(dpred[:, : K + 1], sc.grad) < 1e-5
+    assert torch.equal(dpred[:, K + 1 : K + 1 + 4 * K], dl.grad)
+    assert float(dpred[:, K + 1 + 4 * K :].abs().max()) == 0.0
+
+
+def test_sgd_momentum_vs_oracle(T, oracle):
+    from oracle import train_oracle as TO
+
+    tc = TO.TrainCfg()
+    torch.manual_seed(8)
+    P = {"w": torch.randn(1000)}
+    bufs = {}
+    p = P["w"].clone().cuda()
+    buf = torch.zeros(1000, device="cuda")
+    for it in range(3):
+        g = torch.randn(1000)
+        lr = TO.lr_at(it, tc)
+        TO.sgd_step(P, {"w": g}, bufs, lr, tc)
+        T.sgd_momentum(p, (2 * g).cuda(), buf, lr=lr, momentum=tc.momentum, weight_decay=tc.weight_decay, grad_scale=0.5, first=it == 0)
+        assert l2rel(p, P["w"]) < 1e-6

@@ -177,7 +177,9 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.a3d_conv_workspace_bytes(ctypes.byref(d)) == 0
     assert lib.a3d_linear_small(None, None, None, None, 4, None, 1024, 3, 3, 0, None) == -1
     # struct layouts agree with the C side (a mismatch would shift every field)
-    assert ctypes.sizeof(_lib.ConvDesc) == 8 * 8 + 19 * 4 + 4 + 8 + 8 + 8  # 8 ptrs, 19 ints, pad, m_dev, tune + phase, w_wino
+    for sid, cls in _lib.STRUCT_IDS.items():
+        assert lib.a3d_struct_size(sid) == ctypes.sizeof(cls), cls.__name__
+    assert ctypes.sizeof(_lib.ConvDesc) == 8 * 8 + 19 * 4 + 4 + 8 + 8 + 8 + 8  # 8 ptrs, 19 ints, pad, m_dev, tune + phase, w_wino, gate
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
