@@ -33,3 +33,16 @@ def gather_records(records: torch.Tensor, rec_count: torch.Tensor):
     dist.all_gather_into_tensor(all_cnt, rec_count.contiguous())
     dist.all_gather_into_tensor(all_rec, records.contiguous())
     return all_rec, all_cnt
+
+
+def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:
+    """Data-parallel training (SURVEY.md 8e "training", 8f-1): ONE sum all-reduce of the trainer's flat gradient buffer
+    (replaces DistributedDataParallel's bucketed all-reduce behind tools/train_net.py:110).  Returns the factor the
+    optimiser applies to turn the sum into DDP's mean (1 / world size); 1.0 when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat_grads, group=group)
+    return 1.0 / world

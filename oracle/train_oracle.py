@@ -265,6 +265,8 @@ def forward_losses(images_chw: List[torch.Tensor], targets, P: Dict[str, torch.T
     with torch.no_grad():  # proposals carry no gradient (d2 RPN.predict_proposals)
         pcfg = O.OracleCfg(**{**cfg.__dict__, "rpn_pre_topk": tc.rpn_pre_topk_train, "rpn_post_topk": tc.rpn_post_topk_train})
         props = O.rpn_select([l.detach() for l in logits], [d.detach() for d in deltas], feat_hw, sizes, pcfg)
+        if samples is not None and "proposals" in samples:  # stage-wise parity: proposal selection is discontinuous in
+            props = [(b, None) for b in samples["proposals"]]  # its inputs, so the test feeds the HIP path's own boxes
     sel_boxes, sel_cls, sel_gt, roi_idx, match_cls = [], [], [], [], []
     for n in range(N):
         boxes, cls, midx = match_proposals(props[n][0], gt_boxes[n], gt_classes[n], cfg, tc)

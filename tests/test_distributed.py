@@ -71,3 +71,40 @@ def test_gather_records_single_process_is_identity():
     a, b = torch.zeros(2, 3, 798), torch.zeros(2, dtype=torch.int32)
     x, y = gather_records(a, b)
     assert x is a and y is b
+
+
+def _grad_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from articulation3d_amd.parallel import allreduce_gradients
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # rank r holds (r+1) * base
+    scale = allreduce_gradients(g)
+    want = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
+    q.put((rank, bool(torch.equal(g, want)) and abs(scale - 1.0 / world) < 1e-12))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """The training step's only collective: sum of the flat gradient buffer, mean applied inside the SGD kernel."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_gradient_allreduce_single_process():
+    from articulation3d_amd.parallel import allreduce_gradients
+
+    g = torch.ones(8)
+    assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.ones(8))

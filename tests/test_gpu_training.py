@@ -268,3 +268,116 @@ def test_sgd_momentum_vs_oracle(T, oracle):
         TO.sgd_step(P, {"w": g}, bufs, lr, tc)
         T.sgd_momentum(p, (2 * g).cuda(), buf, lr=lr, momentum=tc.momentum, weight_decay=tc.weight_decay, grad_scale=0.5, first=it == 0)
         assert l2rel(p, P["w"]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ the whole step
+@pytest.fixture(scope="module")
+def trainer_and_ref(hip_model, oracle, oracle_params):
+    """One forward/backward of the HIP trainer on 2 synthetic frames + the oracle's loss_and_grads on the same
+    sampled index sets and the same proposals (proposal selection is discontinuous -> stage-wise, like the inference suite)."""
+    from articulation3d_amd.training import DetectorTrainer
+    from oracle import train_oracle as TO
+
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    frames = oracle.synthetic_frames(2)
+    tg = TO.synthetic_targets(2)
+    tr = DetectorTrainer(hip_model, seed=11)
+    p0 = {k: v.cpu() for k, v in tr.export_state_dict().items()}
+    losses, aux = tr.forward_backward(torch.from_numpy(frames).cuda(), [t[0] for t in tg], [t[1] for t in tg])
+    torch.cuda.synchronize()
+    pb, pc = aux["proposals"]
+    samples = dict(anchor_labels=aux["anchor_labels"], roi_idx=aux["roi_idx"], proposals=[pb[i, : int(pc[i])].cpu() for i in range(2)])
+    cfg, tc = oracle.OracleCfg(), TO.TrainCfg()
+    rl, rg, raux = TO.loss_and_grads(oracle.frames_to_chw(frames), tg, oracle_params, cfg, tc, samples=samples)
+    # Second oracle evaluation with the ReLU gates of the HIP forward pass.  A ReLU's derivative is discontinuous in its
+    # input: the two fp32 forward passes differ by ~1e-5 relative, which flips ~1e-5 of the gates per layer and moves the
+    # deep-layer gradients by ~sqrt(flipped fraction) ~ 1e-3 per layer, 2e-2 accumulated at res3 (measured; the oracle's
+    # own fp32-vs-fp64 distance is the same size).  Like every discontinuous stage of this suite the backward pass is
+    # therefore ALSO compared on identical gates, where only summation-order noise remains.
+    gates = [(g.permute(0, 3, 1, 2) if g.dim() == 4 else g).cpu() > 0 for g in aux["relu_outputs"]]
+    state = {"n": 0}
+    real = torch.nn.functional
+
+    class _F:  # torch.nn.functional with relu / relu_ replaced by "multiply by the given gate" after the frozen layers
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def relu(self, x, inplace=False):
+            i = state["n"]
+            state["n"] += 1
+            return real.relu(x) if i < 10 else x * gates[i - 10]  # 10 = stem + 3x3 res2 ReLUs (frozen, not kept)
+
+        relu_ = relu
+
+    old = oracle.F
+    oracle.F = _F()
+    try:
+        _, rg_gated, _ = TO.loss_and_grads(oracle.frames_to_chw(frames), tg, oracle_params, cfg, tc, samples=samples)
+    finally:
+        oracle.F = old
+    assert state["n"] == 10 + len(gates), (state["n"], len(gates))
+    return tr, p0, losses, aux, rl, rg, raux, tg, frames, rg_gated
+
+
+def test_training_params_roundtrip(trainer_and_ref, oracle_params):
+    tr, p0 = trainer_and_ref[0], trainer_and_ref[1]
+    from oracle import train_oracle as TO
+
+    names = TO.trainable_names(oracle_params)
+    assert set(names) == set(p0), set(names) ^ set(p0)
+    assert sum(v.numel() for v in p0.values()) == 41077786
+    for k in names:
+        assert torch.equal(p0[k], oracle_params[k]), k
+
+
+def test_training_labels_and_losses_match_oracle(trainer_and_ref):
+    tr, p0, losses, aux, rl, rg, raux, tg, frames, _ = trainer_and_ref
+    # matcher on the anchors: identical to the oracle's (before sub-sampling)
+    midx, lab = aux["anchor_match"]
+    for i in range(2):
+        assert torch.equal(lab[i].cpu(), raux["anchor_match"][i][1])
+        assert torch.equal(midx[i].cpu().long(), raux["anchor_match"][i][0])
+        assert torch.equal(aux["roi_cls"][i], raux["roi_cls"][i])  # class labels of the sampled ROIs
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
+        a, b = losses[k].item(), rl[k].item()
+        assert abs(a - b) <= 2e-4 * abs(b) + 1e-7, (k, a, b)
+
+
+def test_training_gradients_match_autograd(trainer_and_ref):
+    tr, p0, losses, aux, rl, rg, raux, tg, frames, rg_gated = trainer_and_ref
+    g = {k: v.cpu() for k, v in tr.export_grads().items()}
+    assert set(g) == set(rg) == set(rg_gated)
+    import os
+    if os.environ.get("A3D_TRAIN_DEBUG"):
+        for k in rg:
+            print(f"{l2rel(g[k], rg_gated[k]):10.3e} {l2rel(g[k], rg[k]):10.3e}  {float(rg[k].norm()):10.3e}  {k}")
+    worst_gated = max((l2rel(g[k], rg_gated[k]), k) for k in rg)
+    worst_free = max((l2rel(g[k], rg[k]), k) for k in rg)
+    print("worst relative L2 gradient error: identical gates", worst_gated, " free-running", worst_free)
+    for k in rg:  # identical ReLU gates: fp32 summation-order noise only
+        assert l2rel(g[k], rg_gated[k]) < 2e-4, (k, l2rel(g[k], rg_gated[k]))
+    for k in rg:  # free-running fp32 vs fp32: bounded by the gate-flip noise explained in the fixture
+        assert l2rel(g[k], rg[k]) < 5e-2, (k, l2rel(g[k], rg[k]))
+
+
+def test_training_sgd_update_and_loss_decreases(trainer_and_ref, oracle, oracle_params):
+    from oracle import train_oracle as TO
+
+    tr, p0, losses, aux, rl, rg, raux, tg, frames, _ = trainer_and_ref
+    tc = TO.TrainCfg()
+    P = {k: v.clone() for k, v in oracle_params.items()}
+    g_hip = {k: v.cpu() for k, v in tr.export_grads().items()}
+    TO.sgd_step(P, g_hip, {}, TO.lr_at(0, tc), tc)  # the oracle's update applied to the HIP gradients
+    tr.optimizer_step()
+    p1 = {k: v.cpu() for k, v in tr.export_state_dict().items()}
+    for k in g_hip:
+        assert l2rel(p1[k], P[k]) < 1e-6, k
+    # a few more steps on the same batch at a larger learning rate: the total loss goes down
+    tr.s.warmup_iters = 0
+    tr.s.base_lr = 0.01
+    fr = torch.from_numpy(frames).cuda()
+    hist = []
+    for _ in range(6):
+        l, _ = tr.step(fr, [t[0] for t in tg], [t[1] for t in tg], samples=dict(anchor_labels=aux["anchor_labels"], roi_idx=aux["roi_idx"]))
+        hist.append(sum(v.item() for v in l.values()))
+    assert hist[-1] < hist[0], hist
