@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Throughput of the training step (BASELINE configs[4]: train_net.py step1_bbox.yaml) on MI355X.
+
+    python tools/train_bench.py [--gpus N --steps K --warmup W --batch 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py --gpus N ...
+
+One step = forward + losses + backward + gradient all-reduce (N > 1, RCCL) + SGD on `--batch` synthetic 480x640 frames per
+GPU (the reference trains 16 images over 8 GPUs = 2 per GPU, step1_bbox.yaml:40).  Same timing discipline as bench.py:
+W untimed steps, K timed steps between barrier + synchronize, max over ranks, ONE JSON line from rank 0.  This is a
+secondary metric (the headline metric of BASELINE.json is bench.py's frames/s through the detector).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_targets(n, seed, h=480, w=640):
+    """2-6 random ground-truth boxes per frame, classes in {0,1} (same generator as the CPU oracle's)."""
+    rng = np.random.default_rng(seed + 7)
+    out = []
+    for _ in range(n):
+        g = int(rng.integers(2, 7))
+        bw, bh = rng.uniform(40, 320, g), rng.uniform(40, 260, g)
+        x1, y1 = rng.uniform(0, w - bw), rng.uniform(0, h - bh)
+        boxes = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        out.append((torch.from_numpy(boxes), torch.from_numpy(rng.integers(0, 2, g).astype(np.int64))))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (reference: IMS_PER_BATCH 16 over 8 GPUs)")
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE oracle step (autograd on the host cores)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train_bench.py needs an MI355X (HIP) device")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = f"cuda:{local_dev}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
+
+    from bench import build_detector
+    from articulation3d_amd.training import DetectorTrainer
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
+    model, _cfg = build_detector(0.5, dev)
+    tr = DetectorTrainer(model, seed=2020 + rank)
+    B = args.batch
+    frames = torch.from_numpy(synthetic_frames(B, seed=2020 + rank)).to(dev)
+    tg = synthetic_targets(B, 2020 + rank)
+    gtb, gtc = [t[0] for t in tg], [t[1] for t in tg]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(frames, gtb, gtc)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, _ = tr.step(frames, gtb, gtc)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    result = {
+        "metric": "images/sec through the step1_bbox training step at 480x640", "value": round(B * world * args.steps / elapsed, 2),
+        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: Faster R-CNN training step of step1_bbox.yaml (ResNet50-FPN, FREEZE_AT 2, RPN + box head "
+                               "losses, SGD momentum), fp32, random-init weights with calibrated BN, synthetic frames and boxes",
+                   "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
+                   "gradient_exchange": "one RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none (1 GPU)"},
+        "losses_last_step": {k: round(float(v), 5) for k, v in losses.items()},
+    }
+    if args.cpu_baseline and rank == 0 and world == 1:
+        from oracle import planercnn_oracle as O, train_oracle as TO
+
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(avail, 64))
+        torch.set_num_threads(cores)
+        P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        imgs = O.frames_to_chw(synthetic_frames(B, seed=2020))
+        t0 = time.perf_counter()
+        TO.loss_and_grads(imgs, tg, P, O.OracleCfg(), TO.TrainCfg(), gen=torch.Generator().manual_seed(1))
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(B / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+                                  "sample": f"one forward+backward of the autograd oracle on {B} images (no optimiser step)"}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
