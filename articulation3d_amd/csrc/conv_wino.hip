@@ -131,15 +131,16 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
     f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
     int ld_f = 0, ld_kc = 0;  // (frequency plane, k-chunk) of the next chunk to load: incremental, no divisions
     auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
-        const bool live = ld_f < 16;
-        const int f = min(ld_f, 15);  // (tail iterations issue dead loads: keep the base in range)
+        // (the two look-ahead loads past the last chunk re-read plane 15: in range, never consumed; keeping them
+        // unconditional keeps the loop body free of branches)
+        const int f = min(ld_f, 15);
         const __amdgpu_buffer_rsrc_t rv = wmake_rsrc(a.V + (size_t)f * vplane, vbytes);
         const __amdgpu_buffer_rsrc_t ru = wmake_rsrc(a.U + (size_t)f * uplane, ubytes);
         const int soff = ld_kc * BKT * 4;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, live ? xoff[i] : -1, soff);
+        for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, xoff[i], soff);
 #pragma unroll
-        for (int i = 0; i < WR; ++i) ws[i] = wbuf_load4(ru, live ? woff[i] : -1, soff);
+        for (int i = 0; i < WR; ++i) ws[i] = wbuf_load4(ru, woff[i], soff);
         if (++ld_kc == KC) {
             ld_kc = 0;
             ++ld_f;
@@ -173,9 +174,28 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
     __syncthreads();
 
     const int frag_off = (lane & 31) * LK + (lane >> 5) * 4;
-    int cf = 0, ckc = 0;  // (plane, chunk) being multiplied
-    // one iteration: multiply LDS[cur]; write the staged chunk it+1 to LDS[cur^1]; refill that set with chunk it+3
-    auto iteration = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
+    // fold the finished plane f into the outputs with the 0/+-1 coefficients of A^T (x) A^T, and clear it.
+    // The coefficients are wave-uniform and the unconditional FMAs exact, so this is one basic block.
+    auto fold = [&](f32x16 (&m)[TN], const int f) {
+        const int u = f >> 2, v = f & 3;
+        const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
+        const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
+        const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = m[n][r];
+                yy[0][n][r] = __builtin_fmaf(c00, x, yy[0][n][r]);
+                yy[1][n][r] = __builtin_fmaf(c01, x, yy[1][n][r]);
+                yy[2][n][r] = __builtin_fmaf(c10, x, yy[2][n][r]);
+                yy[3][n][r] = __builtin_fmaf(c11, x, yy[3][n][r]);
+                m[n][r] = 0.f;
+            }
+        }
+    };
+    // one chunk: multiply LDS[cur] into `acc`; write the staged chunk it+1 to LDS[cur^1]; refill that set with chunk it+3.
+    auto mma = [&](f32x16 (&acc)[TN], const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         const float *X = lds + cur * BUF + (wm * 32) * LK + frag_off;
         const float *Wt = lds + cur * BUF + BM * LK + (wn * TN * 32) * LK + frag_off;
         f32x4 fa[2][TN], fb[2];
@@ -196,31 +216,26 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    mf[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], mf[ni], 0, 0, 0);
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], acc[ni], 0, 0, 0);
         }
-        // end of a frequency plane: fold M_f into the outputs with the 0/+-1 coefficients of A^T (x) A^T
+    };
+    // Measured and rejected here: a second (ping-pong) plane accumulator that folds plane f behind the MFMAs of plane
+    // f+1 (2-8 % slower: +16 registers, no gain -- the fold is not what idles the pipe); one staging set at 4 waves / SIMD
+    // (__launch_bounds__(256, 4) fits 116 VGPRs: ties with this form).
+    int cf = 0, ckc = 0;  // (plane, chunk) being multiplied
+    for (int it = 0; it < NIT; it += 2) {  // NIT = 16*KC is even
+        mma(mf, 0, xsB, wsB);  // chunk it   in LDS[0]; set B holds chunk it+1, is refilled with chunk it+3
         if (++ckc == KC) {
             ckc = 0;
-            const int u = cf >> 2, v = cf & 3;
-            ++cf;
-            const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
-            const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
-            const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
-#pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                if (c00 != 0.f) yy[0][n] += c00 * mf[n];
-                if (c01 != 0.f) yy[1][n] += c01 * mf[n];
-                if (c10 != 0.f) yy[2][n] += c10 * mf[n];
-                if (c11 != 0.f) yy[3][n] += c11 * mf[n];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mf[n][r] = 0.f;
-            }
+            fold(mf, cf++);
         }
         __syncthreads();
-    };
-    for (int it = 0; it < NIT; it += 2) {  // NIT = 16*KC is even
-        iteration(0, xsB, wsB);  // chunk it   in LDS[0]; set B holds chunk it+1, is refilled with chunk it+3
-        iteration(1, xsA, wsA);  // chunk it+1 in LDS[1]; set A holds chunk it+2, is refilled with chunk it+4
+        mma(mf, 1, xsA, wsA);  // chunk it+1 in LDS[1]; set A holds chunk it+2, is refilled with chunk it+4
+        if (++ckc == KC) {
+            ckc = 0;
+            fold(mf, cf++);
+        }
+        __syncthreads();
     }
 
     // ---- epilogue: lane owns tile t, register quad = 4 consecutive channels -------------------------
@@ -320,6 +335,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     const int bn = tn * 64;
     const int ntiles = (d->Cout + bn - 1) / bn;
     const dim3 grid(mtiles * ntiles);
+    // ping-pong accumulators (PP) whenever a plane has an even number of 32-deep k-chunks; tune % 10 >= 2 turns it off (A/B)
     if (tn == 1 && !bk32) hipLaunchKernelGGL((wino_gemm_kernel<1, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
     else if (tn == 1) hipLaunchKernelGGL((wino_gemm_kernel<1, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
     else if (!bk32) hipLaunchKernelGGL((wino_gemm_kernel<2, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
