@@ -14,14 +14,10 @@ __device__ __forceinline__ float a3d_act(float v) {
 }
 
 __device__ __forceinline__ f32x4 apply_epilogue(const a3d_conv_desc &d, f32x4 v, int n, size_t res_row) {
-    if (d.scale) {
-        const f32x4 s = *reinterpret_cast<const f32x4 *>(d.scale + n);
-        v *= s;
-    }
-    if (d.shift) {
-        const f32x4 s = *reinterpret_cast<const f32x4 *>(d.shift + n);
-        v += s;
-    }
+    f32x4 s = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (d.scale) s = *reinterpret_cast<const f32x4 *>(d.scale + n);
+    if (d.shift) sh = *reinterpret_cast<const f32x4 *>(d.shift + n);
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(v[i], s[i], sh[i]);  // same rounding as a3d_epilogue_math below
     if (d.res) {
         const f32x4 r = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + n);
         v += r;
@@ -29,6 +25,36 @@ __device__ __forceinline__ f32x4 apply_epilogue(const a3d_conv_desc &d, f32x4 v,
     if (d.act == A3D_ACT_RELU) {
         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
     } else if (d.act == A3D_ACT_LEAKY) {
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.01f * v[i];
+    }
+    return v;
+}
+
+// ---- fast epilogue ---------------------------------------------------------------------------------------------
+// The per-quad form above issues three dependent global loads (scale, shift, residual) per output quad, and because
+// y / res / gate may alias the compiler keeps every one of them in program order with the stores: 16 serialized
+// round trips per wave.  The kernels therefore stage scale / shift of their N tile in LDS once (a3d_stage_scale_shift)
+// and fetch all residual quads of an output row before its first store (one wait instead of eight).
+__device__ __forceinline__ void a3d_stage_scale_shift(float *ss /*[2*BN]*/, const a3d_conv_desc &d, int n0, int BN, int tid) {
+    if (tid < BN) {
+        const int n = n0 + tid;
+        const bool ok = n < d.Cout;
+        ss[tid] = (d.scale && ok) ? d.scale[n] : 1.f;
+        ss[BN + tid] = (d.shift && ok) ? d.shift[n] : 0.f;
+    }
+}
+// v * scale + shift (+ residual), activation.  One rounding for the scale/shift pair (fused multiply-add), the same in
+// every kernel, so a layer's result does not depend on which kernel variant ran it.
+__device__ __forceinline__ f32x4 a3d_epilogue_math(const a3d_conv_desc &d, f32x4 v, const f32x4 s, const f32x4 sh, const bool has_res,
+                                                    const f32x4 r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(v[i], s[i], sh[i]);
+    if (has_res) v += r;
+    if (d.act == A3D_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    } else if (d.act == A3D_ACT_LEAKY) {
+#pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.01f * v[i];
     }
     return v;
@@ -72,6 +98,10 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
 // v2 kernel family (conv_gemm_v2.hip): buffer-addressed, branch-free gather + software-pipelined main loop.
 // Returns A3D_ERR_UNSUPPORTED when the descriptor needs the general kernel.
 int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
+
+// Persistent pointwise kernel (conv_pw.hip): 1x1 stride-1 layers with K <= 2048 and enough tiles to keep a persistent
+// grid busy.  Returns A3D_ERR_UNSUPPORTED otherwise.  `force` skips the grid-size heuristic (A/B measurements).
+int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip).  eligible() ignores the workspace pointer (used for sizing).
 int a3d_wino_eligible(const a3d_conv_desc *d);

@@ -258,6 +258,10 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     a3d_begin();
     if ((d->tune == 0 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+    if (d->tune == 0 || d->tune == 6) {  // persistent pointwise kernel for the 1x1 layers (tune 5: never, 6: whenever eligible)
+        const int r1 = a3d_conv_launch_pw(d, s, d->tune == 6);
+        if (r1 != A3D_ERR_UNSUPPORTED) return r1;
+    }
     if (d->tune != 1) {  // tune == 1 forces the general kernel (A/B measurements, fallback)
         const int r2 = a3d_conv_launch_v2(d, s);
         if (r2 != A3D_ERR_UNSUPPORTED) return r2;

@@ -32,7 +32,8 @@ struct ChunkPos {
 };
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int MODE, int PIPE, int BKT>
-__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(const a3d_conv_desc d, const int Mmax,
+// (second argument: workgroups per CU the register allocation must allow -- the LDS footprint of the BK=16 tiles fits 3)
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64, (BKT == 16 && PIPE == 0) ? 3 : 1) void conv_gemm_v2_kernel(const a3d_conv_desc d, const int Mmax,
                                                                               const int ntiles, const int nblk,
                                                                               const int kt_total, const int kt_per_split) {
     constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
     constexpr int BUF = (BM + BN) * LK;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the loader pass");
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];  // folded-BN scale | shift of this N tile (epilogue)
 
     const int M = d.m_dev ? min(Mmax, *d.m_dev) : Mmax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // ---- prologue: chunk 0 -> LDS[0]; chunk 1 (and, PIPE, chunk 2) -> registers ---------------------------
+    a3d_stage_scale_shift(ss, d, n0, BN, tid);  // (visible to the epilogue through the barriers of the main loop)
     load_chunk(xsA, wsA);
     store_chunk(0, xsA, wsA);
     load_chunk(xsB, wsB);
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         for (int it = 0; it < nk; ++it) iteration(it & 1, xsB, wsB);
     }
 
-    // ---- epilogue (identical to v1) ------------------------------------------------------------------
+    // ---- epilogue: scale / shift from LDS, all residual quads of a row fetched before its first store ----------
+    const bool has_res = d.res != nullptr && d.splitk == 1;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
@@ -248,16 +252,26 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_gemm_v2_kernel(con
         out_rows(d, m, res_row, b, oh, ow);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
+            f32x4 rv[4];  // the residual quads of this 32-channel group, all in flight before its first store
+            if (has_res) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    rv[rg] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + min(n, d.Cout - 4));
+                }
+            }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2],
                            acc[ni][mi][rg * 4 + 3]};
                 if (d.splitk > 1) {
                     *reinterpret_cast<f32x4 *>(d.workspace + ((size_t)z * Mmax + m) * d.Cout + n) = v;
                 } else {
-                    v = apply_epilogue(d, v, n, res_row);
+                    v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl),
+                                          has_res, rv[rg]);
                     store_out(d, v, m, n, b, oh, ow);
                 }
             }

@@ -94,13 +94,14 @@ struct WinoArgs {
 };
 
 template <int TN, int BKT>
-__global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const WinoArgs a, const int ntiles, const int nblk) {
     constexpr int BM = 64, BN = 2 * TN * 32;  // 64 Winograd tiles x BN channels; waves 2 (tiles) x 2 (channels)
     constexpr int LK = BKT + 4, TPR = BKT / 4, RPP = 256 / TPR;
     constexpr int XR = (BM + RPP - 1) / RPP, WR = BN / RPP;
     constexpr int BUF = (BM + BN) * LK;
     static_assert(BN % RPP == 0 && (BM % RPP == 0 || BM < RPP), "loader pass must tile the operand rows");
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];  // scale | shift of this N tile, staged once (epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -167,6 +168,11 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
         }
     }
 
+    if (tid < BN) {  // epilogue vectors of this N tile -> LDS (visible through the barriers of the main loop)
+        const int n = n0 + tid;
+        ss[tid] = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        ss[BN + tid] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    }
     load_chunk(xsA, wsA);  // chunk 0
     store_chunk(0, xsA, wsA);
     load_chunk(xsB, wsB);  // chunk 1
@@ -254,11 +260,15 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoArgs a, const 
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
                 if (n >= a.Cout) continue;
                 f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
-                if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
-                if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                // scale / shift from LDS: no global load (and no wait on the stores before it) between two output quads;
+                // one fused multiply-add, the same rounding as the direct kernels' epilogue (a3d_epilogue_math)
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
                 if (a.act == A3D_ACT_RELU) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
                 } else if (a.act == A3D_ACT_LEAKY) {

@@ -24,12 +24,19 @@ GROUP_CAP = 1024
 CONV_TIMING: Optional[list] = None
 
 
-def conv_tile_config(p: "PackedConv", M: int, ups: bool = False) -> str:
+def conv_tile_config(p: "PackedConv", M: int, ups: bool = False, pw_ok: bool = True) -> str:
     """Mirror of the variant selection in csrc/conv_gemm_v2.hip:a3d_conv_launch_v2 (kernel template arguments
     <WAVES_M,WAVES_N,TM,TN,MODE,PIPE,BK> as they appear in a rocprofv3 kernel trace)."""
     if p.stem:
         return "conv_gemm_v2<2,2,2,1,stem,bk32> 128x64"
     n128 = ((M + 127) // 128) * ((p.cols + 127) // 128)
+    if (p.KH * p.KW == 1 and p.stride == 1 and not ups and not p.pixshuf and not p.phase and p.Kpad == p.Cin and p.Kpad <= 2048
+            and p.cols >= 64 and pw_ok):  # mirror of csrc/conv_pw.hip:a3d_conv_launch_pw
+        if p.cols <= 64 or n128 <= 1000:
+            if ((M + 127) // 128) * ((p.cols + 63) // 64) >= 2 * 256 * 4:
+                return "conv_pw<2,1> 128x64 bk16 persistent"
+        elif n128 >= 2 * 256 * 3:
+            return "conv_pw<2,2> 128x128 bk16 persistent"
     cfg = 2 if p.cols <= 32 else (1 if (p.cols <= 64 or n128 <= 1000) else 0)
     bk = 32 if (p.KH * p.KW == 1 and p.Kpad >= 8192) or cfg == 2 else 16
     return {0: "conv_gemm_v2<2,2,2,2> 128x128", 1: "conv_gemm_v2<2,2,2,1> 128x64", 2: "conv_gemm_v2<4,1,1,1> 128x32"}[cfg] + f" bk{bk}"
@@ -275,7 +282,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         e1.record()
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
-        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups) + (" ups-phase" if p.phase else ""), fl, e0, e1, shape))
+        pw_ok = x2 is None and splitk == 1 and m_dev is None and tune in (0, 6)
+        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups, pw_ok) + (" ups-phase" if p.phase else ""), fl, e0, e1, shape))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

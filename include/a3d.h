@@ -79,7 +79,8 @@ typedef struct a3d_conv_desc {
     const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
                          so ragged per-ROI batches need no host synchronisation                      */
     int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel;
-                         2 = direct implicit GEMM even when w_wino is given; >= 100: explicit tile variant */
+                         2 = direct implicit GEMM even when w_wino is given; 5 / 6 = never / always use the persistent
+                         pointwise kernel on eligible 1x1 layers; >= 100: explicit tile variant */
     int phase;        /* 0, or 1..4 = output phase (dy,dx) = ((phase-1)>>1, (phase-1)&1) of a 3x3 pad-1 convolution over a
                          nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
                          taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
