@@ -250,11 +250,12 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         d.gate = gate.data_ptr()
     d.tune = int(tune)
     d.phase = int(p.phase)
-    # Winograd F(2x2,3x3) for 3x3 s1 p1 layers.  The choice must not depend on the batch / ROI count (a frame's
-    # result would otherwise depend on how it was batched): by default every layer whose per-image output is at
-    # least 600 pixels (p4 level and larger); callers with a variable row count (per-ROI heads) pass wino=True.
+    # Winograd F(2x2,3x3) for every 3x3 s1 p1 layer that has Winograd-domain weights.  The choice must not depend on the
+    # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
+    # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
+    # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
     use_wino = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
-                and (wino if wino is not None else (Ho * Wo >= 600 and p.Cin >= 128)))
+                and (wino if wino is not None else True))
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()

@@ -101,6 +101,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # (only used by the single-process A3D_BENCH_FORCE_DIST form)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
         else:

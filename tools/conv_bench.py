@@ -24,11 +24,12 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride, ups
     ("fc1 12544->1024", 32000, 1, 1, 12544, 1024, 1, 1, 0),
     ("head conv 3x3 (D=124)", 124, 14, 14, 256, 256, 3, 1, 0),
     ("p6 rpn 3x3", 32, 8, 10, 256, 256, 3, 1, 0),
+    ("p5 rpn 3x3", 32, 15, 20, 256, 256, 3, 1, 0),
 ]
 
 
 def main():
-    """conv_bench.py [rounds] [filter] [tune,tune,...]: variants are interleaved round by round in ONE process
+    """conv_bench.py [rounds] [filter] [tune,tune,...] (tune + 1000 = force the Winograd form): variants are interleaved round by round in ONE process
     (cross-process / cross-device timings are not comparable); prints the median ms and TF/s per variant."""
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -53,7 +54,7 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(3):
-                        ops.conv2d(x, p, ups=bool(ups), out=y, tune=t)
+                        ops.conv2d(x, p, ups=bool(ups), out=y, tune=t % 1000, wino=(True if t >= 1000 else None))
                     e1.record()
                     torch.cuda.synchronize()
                     if r:
