@@ -25,14 +25,35 @@ def shard_range(num_frames: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_records(records: torch.Tensor, rec_count: torch.Tensor):
     """records [B,R,F] fp32, rec_count [B] int32 (this rank's block) -> ([G*B,R,F], [G*B]) on every rank."""
+    return gather_records_async(records, rec_count).wait()
+
+
+class GatherHandle:
+    """Result of gather_records_async.  `wait()` makes the current stream wait for the collective and returns
+    (all_records, all_counts); until then the exchange runs on RCCL's own stream, under the next batch's kernels."""
+
+    def __init__(self, all_rec, all_cnt, works, keep):
+        self._out, self._works, self._keep = (all_rec, all_cnt), works, keep
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works, self._keep = [], None
+        return self._out
+
+
+def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor) -> GatherHandle:
+    """Starts the all-gather of one batch's detection records without blocking the launch stream: the detector's next
+    batch is enqueued while the records travel over xGMI (one collective per batch, overlapped with compute)."""
     if not (dist.is_available() and dist.is_initialized()):
-        return records, rec_count
+        return GatherHandle(records, rec_count, [], None)
     G = dist.get_world_size()
-    all_rec = torch.empty((G * records.shape[0],) + tuple(records.shape[1:]), device=records.device, dtype=records.dtype)
-    all_cnt = torch.empty((G * rec_count.shape[0],), device=rec_count.device, dtype=rec_count.dtype)
-    dist.all_gather_into_tensor(all_cnt, rec_count.contiguous())
-    dist.all_gather_into_tensor(all_rec, records.contiguous())
-    return all_rec, all_cnt
+    rec, cnt = records.contiguous(), rec_count.contiguous()
+    all_rec = torch.empty((G * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
+    all_cnt = torch.empty((G * cnt.shape[0],), device=cnt.device, dtype=cnt.dtype)
+    w1 = dist.all_gather_into_tensor(all_cnt, cnt, async_op=True)
+    w2 = dist.all_gather_into_tensor(all_rec, rec, async_op=True)
+    return GatherHandle(all_rec, all_cnt, [w1, w2], (rec, cnt))  # inputs stay referenced until the collective is waited for
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:

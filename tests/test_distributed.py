@@ -37,6 +37,12 @@ def _worker(rank, world, port, q):
     for f in range(F_):  # temporal order restored by rank order
         for r in range(f % 3):
             ok = ok and abs(float(all_rec[f, r, 4]) - (f + 0.1 * r)) < 1e-6
+    # two batches in flight (what bench.py does: the gather of batch i overlaps batch i+1), waited for in order
+    from articulation3d_amd.parallel import gather_records_async
+
+    h1, h2 = gather_records_async(rec, cnt), gather_records_async(rec * 2, cnt)
+    (r1, c1), (r2, c2) = h1.wait(), h2.wait()
+    ok = ok and torch.equal(r1, all_rec) and torch.equal(r2, all_rec * 2) and torch.equal(c1, all_cnt) and torch.equal(c2, all_cnt)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
