@@ -12,7 +12,7 @@ import sys
 
 
 def per_dispatch(d, counter, sub):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     agg = {}
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"] and r["Counter_Name"] == counter:

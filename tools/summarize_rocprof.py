@@ -19,8 +19,8 @@ from collections import defaultdict
 
 def main():
     d, bench_json, steps, warmup, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
-    trace = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    stats = max(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    trace = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     rows = list(csv.DictReader(open(stats)))
     per = defaultdict(list)
