@@ -94,6 +94,44 @@ def test_conv_fused_epilogues(ops):
     assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
 
 
+@pytest.mark.parametrize("Cin,Cout,res_mode", [(64, 256, "res"), (128, 192, "none"), (256, 64, "none"), (512, 256, "ups")])
+def test_persistent_pointwise_kernel(ops, Cin, Cout, res_mode):
+    """1x1 layers with many tiles run in the persistent kernel (conv_pw.hip): vs torch, and bit-identical to the
+    one-tile-per-workgroup kernel (tune=5) -- same k order, same epilogue -- including ragged M / N tiles, in-place
+    residual (y aliases res, the training step's gradient accumulation) and the ReLU gate."""
+    torch.manual_seed(11)
+    B, H, W = 7, 122, 158  # M = 134932 rows: not a multiple of 128
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-5)
+    pk = ops.pack_conv(w, None, bn, 1, 0, ops.ACT_RELU)
+    if Cout > 64:
+        assert "conv_pw" in ops.conv_tile_config(pk, B * H * W)
+    else:  # 64-wide layers need more rows for two rounds of the persistent grid
+        B = 14
+        x = torch.randn(B, Cin, H, W)
+        assert "conv_pw" in ops.conv_tile_config(pk, B * H * W)
+    xd = nhwc(x).cuda()
+    kw, ref = {}, F.batch_norm(F.conv2d(x, w), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if res_mode == "res":
+        r = torch.randn(B, Cout, H, W)
+        kw, ref = dict(res=nhwc(r).cuda()), ref + r
+    elif res_mode == "ups":
+        x = x[:, :, :122, :158]
+        r = torch.randn(B, Cout, H // 2, W // 2)
+        kw, ref = dict(res=nhwc(r).cuda(), res_ups=True), ref + F.interpolate(r, scale_factor=2.0, mode="nearest")
+    ref = F.relu(ref)
+    y = ops.conv2d(xd, pk, **kw)
+    y5 = ops.conv2d(xd, pk, tune=5, **kw)
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    assert torch.equal(y, y5)
+    if res_mode == "res":  # in place: the output buffer is the residual
+        buf = kw["res"].clone()
+        gate = torch.randn_like(buf)
+        yg = ops.conv2d(xd, pk, res=buf, out=buf, gate=gate)
+        assert yg.data_ptr() == buf.data_ptr() and torch.equal(buf, y * (gate > 0))
+
+
 def test_stem_pool_resize_small_ops(ops):
     torch.manual_seed(3)
     x = torch.rand(2, 3, 96, 128) * 255 - 110
