@@ -145,6 +145,17 @@ class BoxLossDesc(C.Structure):
         ("M", C.c_int), ("num_classes", C.c_int), ("pitch", C.c_int),
         ("weights", C.c_float * 4),
         ("workspace", fptr), ("loss", fptr),
+        ("count", fptr), ("R", C.c_int),
+    ]
+
+
+class RoiSampleDesc(C.Structure):
+    _fields_ = [
+        ("boxes", fptr), ("box_count", fptr), ("gt_boxes", fptr), ("gt_classes", fptr), ("gt_count", fptr),
+        ("matched_idx", fptr), ("match_label", fptr),
+        ("B", C.c_int), ("N", C.c_int), ("Gmax", C.c_int), ("num_classes", C.c_int), ("num", C.c_int), ("max_fg", C.c_int),
+        ("seed", C.c_ulonglong),
+        ("out_boxes", fptr), ("out_gt_boxes", fptr), ("out_classes", fptr), ("out_index", fptr), ("out_count", fptr),
     ]
 
 
@@ -187,11 +198,14 @@ SIGNATURES = {
     "a3d_loss_workspace_bytes": (C.c_size_t, []),
     "a3d_rpn_loss": (C.c_int, [C.POINTER(RpnLossDesc), fptr]),
     "a3d_box_loss": (C.c_int, [C.POINTER(BoxLossDesc), fptr]),
+    "a3d_sample_labels": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, fptr]),
+    "a3d_append_gt_boxes": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_sample_rois": (C.c_int, [C.POINTER(RoiSampleDesc), fptr]),
     "a3d_sgd_momentum": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
 }
 
 STRUCT_IDS = {0: ConvDesc, 1: RpnDesc, 2: BoxDetDesc, 3: RoiAlignDesc, 4: PasteDesc, 5: PackDesc, 6: WgradDesc,
-              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc}
+              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc, 11: RoiSampleDesc}
 
 _lib = None
 

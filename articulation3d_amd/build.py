@@ -30,6 +30,7 @@ SOURCES = {
     "heads_post.hip": ["-ffp-contract=off"],
     "pack.hip": [],
     "conv_wgrad.hip": [],
+    "train_sample.hip": [],
     "train_ops.hip": ["-ffp-contract=off"],  # matcher IoU / box deltas round like the reference's separate mul, add, div
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

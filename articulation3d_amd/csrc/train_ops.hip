@@ -385,11 +385,17 @@ extern "C" int a3d_rpn_loss(const a3d_rpn_loss_desc *d, void *stream) {
 __global__ __launch_bounds__(256) void box_loss_kernel(const a3d_box_loss_desc d, float *partials) {
     const int K = d.num_classes;
     float lc = 0.f, lb = 0.f;
-    const float inv = 1.f / (float)d.M;
+    int live = d.M;
+    if (d.count) {  // ragged: only the first count[b] rows of every R-row block carry loss
+        live = 0;
+        for (int b = 0; b < d.M / d.R; ++b) live += min(d.count[b], d.R);
+    }
+    const float inv = 1.f / (float)max(live, 1);
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < d.M; r += gridDim.x * blockDim.x) {
         const float *p = d.pred + (size_t)r * d.pitch;
         float *g = d.dpred + (size_t)r * d.pitch;
         for (int c = 0; c < d.pitch; ++c) g[c] = 0.f;
+        if (d.count && (r % d.R) >= d.count[r / d.R]) continue;
         const int cls = d.gt_classes[r];
         float mx = p[0];
         for (int c = 1; c <= K; ++c) mx = fmaxf(mx, p[c]);
@@ -421,20 +427,21 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const a3d_box_loss_desc d
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partials[(size_t)blockIdx.x * 2 + 0] = r0[0];
-        partials[(size_t)blockIdx.x * 2 + 1] = r1[0];
+        partials[(size_t)blockIdx.x * 2 + 0] = r0[0] * inv;  // (normalised here: the live row count lives on the device)
+        partials[(size_t)blockIdx.x * 2 + 1] = r1[0] * inv;
     }
 }
 
 extern "C" int a3d_box_loss(const a3d_box_loss_desc *d, void *stream) {
     if (!d || !d->pred || !d->dpred || !d->gt_classes || !d->boxes || !d->gt_boxes || !d->loss || !d->workspace) return A3D_ERR_ARG;
     if (d->M <= 0 || d->num_classes < 1 || d->pitch < 1 + 5 * d->num_classes) return A3D_ERR_ARG;
+    if (d->count && (d->R <= 0 || d->M % d->R)) return A3D_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int blocks = (d->M + 255) / 256;
     if (blocks > A3D_LOSS_BLOCKS) blocks = A3D_LOSS_BLOCKS;
     a3d_begin();
     hipLaunchKernelGGL(box_loss_kernel, dim3(blocks), dim3(256), 0, s, *d, d->workspace);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, d->workspace, blocks, 2, 1.0f / (float)d->M, d->loss);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, d->workspace, blocks, 2, 1.0f, d->loss);
     return a3d_check_launch();
 }
 

@@ -477,7 +477,8 @@ def group_nms(g_boxes: torch.Tensor, g_valid: torch.Tensor, g_n: torch.Tensor, t
 
 def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor,
                   count: Optional[torch.Tensor], P: int, sampling_ratio: int, aligned: bool, *,
-                  row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, want_level: bool = False):
+                  row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, want_level: bool = False,
+                  zero: bool = False):
     """feats[l] NHWC [B,Hf,Wf,C]; boxes [B,R,4]; -> [rows, P, P, C] (rows = B*R unless compacted)."""
     _req(boxes)
     B, R, _ = boxes.shape
@@ -486,7 +487,7 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     nrows = B * R if rows is None else rows
     # rows of slots past count[b] are never written NOR read downstream (GEMM rows are independent and the selection
     # kernels only look at live rows), so the buffer is not cleared (a 3 GB memset per 64-frame step otherwise)
-    out = torch.empty((nrows, P, P, Cc), device=dev, dtype=torch.float32)
+    out = (torch.zeros if zero else torch.empty)((nrows, P, P, Cc), device=dev, dtype=torch.float32)
     lvl = torch.full((nrows,), -1, device=dev, dtype=torch.int32) if want_level else None
     d = _lib.RoiAlignDesc()
     for l, f in enumerate(feats):

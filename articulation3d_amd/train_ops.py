@@ -142,10 +142,55 @@ def rpn_loss(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_anchors
     return loss, dheads
 
 
-def box_loss(pred: torch.Tensor, gt_classes: torch.Tensor, boxes: torch.Tensor, gt_boxes: torch.Tensor, *, num_classes: int, weights):
-    """pred [M,pitch] fused predictor rows -> (loss [2] = (loss_cls, loss_box_reg), dpred [M,pitch])."""
+def sample_labels(labels: torch.Tensor, *, num: int, max_pos: int, seed: int) -> torch.Tensor:
+    """labels int8 [B,N] in {-1,0,1} -> the same with all but a random `num` (<= max_pos positives) set to -1."""
+    B, N = _req(labels, torch.int8).shape
+    out = torch.empty_like(labels)
+    _lib.check(_lib.lib().a3d_sample_labels(_p(labels), _p(out), B, N, int(num), int(max_pos), int(seed) & (2 ** 64 - 1), _stream()),
+               "a3d_sample_labels")
+    return out
+
+
+def append_gt_boxes(props: torch.Tensor, count: torch.Tensor, gt_boxes: torch.Tensor, gt_count: torch.Tensor):
+    """[B,R,4] live proposals + [B,Gmax,4] ground truth -> ([B,R+Gmax,4], count [B] int32)."""
+    B, R, _ = _req(props).shape
+    Gmax = _req(gt_boxes).shape[1]
+    out = torch.empty((B, R + Gmax, 4), device=props.device, dtype=torch.float32)
+    cnt = torch.empty((B,), device=props.device, dtype=torch.int32)
+    _lib.check(_lib.lib().a3d_append_gt_boxes(_p(props), _p(_req(count, torch.int32)), _p(gt_boxes), _p(_req(gt_count, torch.int32)), _p(out),
+                                              _p(cnt), B, R, Gmax, _stream()), "a3d_append_gt_boxes")
+    return out, cnt
+
+
+def sample_rois(boxes: torch.Tensor, box_count: torch.Tensor, gt_boxes: torch.Tensor, gt_classes: torch.Tensor, gt_count: torch.Tensor,
+                matched_idx: torch.Tensor, match_label: torch.Tensor, *, num_classes: int, num: int, max_fg: int, seed: int):
+    """-> (roi_boxes [B,num,4], roi_gt_boxes [B,num,4], roi_classes [B,num] int32, index [B,num] int32, count [B] int32)."""
+    B, N, _ = _req(boxes).shape
+    dev = boxes.device
+    d = _lib.RoiSampleDesc()
+    d.boxes, d.box_count = _p(boxes), _p(_req(box_count, torch.int32))
+    d.gt_boxes, d.gt_classes, d.gt_count = _p(_req(gt_boxes)), _p(_req(gt_classes, torch.int32)), _p(_req(gt_count, torch.int32))
+    d.matched_idx, d.match_label = _p(_req(matched_idx, torch.int32)), _p(_req(match_label, torch.int8))
+    d.B, d.N, d.Gmax, d.num_classes, d.num, d.max_fg = B, N, gt_boxes.shape[1], num_classes, num, max_fg
+    d.seed = int(seed) & (2 ** 64 - 1)
+    ob = torch.empty((B, num, 4), device=dev, dtype=torch.float32)
+    og = torch.empty((B, num, 4), device=dev, dtype=torch.float32)
+    oc = torch.empty((B, num), device=dev, dtype=torch.int32)
+    oi = torch.empty((B, num), device=dev, dtype=torch.int32)
+    on = torch.empty((B,), device=dev, dtype=torch.int32)
+    d.out_boxes, d.out_gt_boxes, d.out_classes, d.out_index, d.out_count = _p(ob), _p(og), _p(oc), _p(oi), _p(on)
+    _lib.check(_lib.lib().a3d_sample_rois(C.byref(d), _stream()), "a3d_sample_rois")
+    return ob, og, oc, oi, on
+
+
+def box_loss(pred: torch.Tensor, gt_classes: torch.Tensor, boxes: torch.Tensor, gt_boxes: torch.Tensor, *, num_classes: int, weights,
+             count: Optional[torch.Tensor] = None, rows_per_image: int = 0):
+    """pred [M,pitch] fused predictor rows -> (loss [2] = (loss_cls, loss_box_reg), dpred [M,pitch]).  With `count` [B] the
+    rows are `rows_per_image` per image and only the first count[b] of each image are live."""
     M, pitch = _req(pred).shape
     d = _lib.BoxLossDesc()
+    if count is not None:
+        d.count, d.R = _p(_req(count, torch.int32)), int(rows_per_image)
     dpred = torch.empty_like(pred)
     d.pred, d.dpred = pred.data_ptr(), dpred.data_ptr()
     d.gt_classes, d.boxes, d.gt_boxes = _p(_req(gt_classes, torch.int32)), _p(_req(boxes)), _p(_req(gt_boxes))

@@ -15,9 +15,10 @@ Design (MI355X-first, no autograd engine):
   * Backward is written out explicitly: data gradients run through the SAME fp32-MFMA conv kernel with transposed /
     flipped filters (a3d_weight_transpose) and the ReLU mask + shortcut add fused in its epilogue (`gate`, `res`);
     weight gradients through the pixel-reduction GEMM (a3d_conv_wgrad_nhwc_f32); ROIAlign backward by atomics.
-  * Labelling (Matcher) runs on the GPU; the random sub-sampling (256 anchors, 512 ROIs per image) is host control
-    flow on the labels, drawn from a seeded CPU generator exactly as oracle/train_oracle.py does, so both sides can be
-    given identical draws.
+  * Labelling (Matcher) AND the random sub-sampling (256 anchors, 512 ROIs per image) run on the GPU (counter-based
+    RNG: a3d_sample_labels / a3d_sample_rois), all per-image counts stay in device vectors and tensors have fixed shapes
+    (dead slots are zero rows without loss or gradient): the step never waits for the host.  Parity tests read the drawn
+    index sets back and hand them to the oracle.
 Precision: fp32 throughout (the reference config asks for bf16 autocast; fp32 >= that, bf16 kernels are future work).
 """
 from __future__ import annotations
@@ -130,7 +131,7 @@ class DetectorTrainer:
         self.s = solver or SolverCfg()
         self.model = model
         self.dev = next(model.parameters()).device
-        self.gen = torch.Generator().manual_seed(seed)
+        self.seed = int(seed)
         self.pg = process_group
         self.iter = 0
         sd = {k: v.detach().float() for k, v in model.state_dict().items()}
@@ -320,87 +321,64 @@ class DetectorTrainer:
         heads = [ops.conv2d(ti, L[rp + "pred"].fwd()) for ti in t]
         feat_hw = [tuple(feats[n].shape[1:3]) for n in names]
         anchors = self._anchors(feat_hw)
-        # ---- ground truth on the device
-        G = max(1, max(len(g) for g in gt_boxes))
-        assert G <= s.max_gt
+        # ---- ground truth on the device (fixed-size, counts in a device vector: nothing below waits for the host)
+        assert max(len(g) for g in gt_boxes) <= s.max_gt
         gtb = torch.zeros(B, s.max_gt, 4)
-        gtc = torch.zeros(B, s.max_gt, dtype=torch.int64)
+        gtc = torch.zeros(B, s.max_gt, dtype=torch.int32)
         gcount = torch.zeros(B, dtype=torch.int32)
         for i, (gb, gc) in enumerate(zip(gt_boxes, gt_classes)):
             gtb[i, : len(gb)] = gb.cpu()
-            gtc[i, : len(gb)] = gc.cpu()
+            gtc[i, : len(gb)] = gc.cpu().to(torch.int32)
             gcount[i] = len(gb)
-        gtb_d, gcount_d = gtb.to(self.dev), gcount.to(self.dev)
-        # ---- RPN labels: matcher on the GPU, sub-sampling on the host
+        gtb_d, gtc_d, gcount_d = gtb.to(self.dev, non_blocking=True), gtc.to(self.dev, non_blocking=True), gcount.to(self.dev, non_blocking=True)
+        seed = (self.seed * 1000003 + self.iter) * 4
+        # ---- RPN labels: Matcher + random sub-sampling (256 per image, <= half positive), both on the device
         midx, lab = T.match_boxes(anchors, gtb_d, gcount_d, thresholds=s.rpn_iou_thresholds, labels=(0, -1, 1), allow_low_quality=True,
                                   shared=True)
         if samples is None:
-            lab_c = lab.cpu()
-            out_lab = torch.full_like(lab_c, -1)
-            for i in range(B):
-                pos, neg = subsample_labels(lab_c[i], s.rpn_batch_per_image, s.rpn_positive_fraction, 0, self.gen)
-                out_lab[i, pos] = 1
-                out_lab[i, neg] = 0
+            labels_d = T.sample_labels(lab, num=s.rpn_batch_per_image, max_pos=int(s.rpn_batch_per_image * s.rpn_positive_fraction), seed=seed)
         else:
-            out_lab = samples["anchor_labels"].to(torch.int8)
-        labels_d = out_lab.to(self.dev)
+            labels_d = samples["anchor_labels"].to(torch.int8).to(self.dev)
         rpn_l, dheads = T.rpn_loss(heads, self.strides, self.cell_anchors, labels_d, midx, gtb_d, A=3, weights=s.rpn_weights,
                                    normalizer=float(s.rpn_batch_per_image * B))
-        # ---- proposals (no gradient), ground truth appended, matcher, host sub-sampling
+        # ---- proposals (no gradient) + ground truth, Matcher, sub-sampling (512 per image, <= a quarter foreground)
         pb, _ps, _lvl, _pos, pcount = ops.rpn_proposals(heads, self.strides, self.cell_anchors, (H, W), pre_topk=s.rpn_pre_topk_train,
                                                         post_topk=s.rpn_post_topk_train, nms_thresh=s.rpn_nms_thresh, min_size=0.0,
                                                         weights=s.rpn_weights, scale_clamp=math.log(1000.0 / 16))
-        R = pb.shape[1]
-        pcount_c = pcount.cpu()
-        allb = torch.zeros(B, R + s.max_gt, 4, device=self.dev)
-        allb[:, :R] = pb
-        for i in range(B):  # add_ground_truth_to_proposals: gt boxes follow the live proposals
-            n, g = int(pcount_c[i]), int(gcount[i])
-            allb[i, n:n + g] = gtb_d[i, :g]
-        bcount = (pcount_c + gcount).to(torch.int32).to(self.dev)
+        allb, bcount = T.append_gt_boxes(pb, pcount, gtb_d, gcount_d)
         pmidx, plab = T.match_boxes(allb, gtb_d, gcount_d, thresholds=(s.roi_iou_threshold,), labels=(0, 1), allow_low_quality=False,
                                     box_count=bcount)
-        pmidx_c, plab_c = pmidx.cpu().long(), plab.cpu()
-        roi_idx, roi_cls_list = [], []
-        for i in range(B):
-            n = int(pcount_c[i]) + int(gcount[i])
-            if gcount[i] > 0:
-                cls = gtc[i][pmidx_c[i, :n]].clone()
-                cls[plab_c[i, :n] == 0] = s.num_classes
-            else:
-                cls = torch.full((n,), s.num_classes, dtype=torch.int64)
-            if samples is None:
-                fg, bg = subsample_labels(cls, s.roi_batch_per_image, s.roi_positive_fraction, s.num_classes, self.gen)
-                idx = torch.cat([fg, bg])
-            else:
-                idx = samples["roi_idx"][i]
-            roi_idx.append(idx)
-            roi_cls_list.append(cls[idx])
-        Rs = max(len(ix) for ix in roi_idx)
-        sel = torch.zeros(B, Rs, dtype=torch.int64)
-        rcount = torch.zeros(B, dtype=torch.int32)
-        for i, ix in enumerate(roi_idx):
-            sel[i, : len(ix)] = ix
-            rcount[i] = len(ix)
-        sel_d = sel.to(self.dev)
-        roi_boxes = torch.gather(allb, 1, sel_d[:, :, None].expand(B, Rs, 4)).contiguous()  # index plumbing, no arithmetic
-        rcount_d = rcount.to(self.dev)
-        roff = ops.count_offsets(rcount_d, Rs)
-        M = int(rcount.sum())
-        flat_rows = torch.cat([torch.arange(int(rcount[i])) + i * Rs for i in range(B)]).to(self.dev)
-        roi_boxes_rows = roi_boxes.view(B * Rs, 4)[flat_rows].contiguous()
-        roi_gt_rows = torch.gather(gtb_d, 1, torch.gather(pmidx.long(), 1, sel_d)[:, :, None].expand(B, Rs, 4)).view(B * Rs, 4)[flat_rows].contiguous()
-        roi_cls_rows = torch.cat(roi_cls_list).to(torch.int32).to(self.dev)
+        Rs = s.roi_batch_per_image
+        if samples is None:
+            roi_boxes, roi_gt, roi_cls, roi_index, rcount_d = T.sample_rois(
+                allb, bcount, gtb_d, gtc_d, gcount_d, pmidx, plab, num_classes=s.num_classes, num=Rs,
+                max_fg=int(Rs * s.roi_positive_fraction), seed=seed + 1)
+        else:  # given index sets (parity tests): the same fixed-size tensors, built with host control flow
+            roi_index = torch.full((B, Rs), -1, dtype=torch.int32)
+            rcount = torch.zeros(B, dtype=torch.int32)
+            for i, ix in enumerate(samples["roi_idx"]):
+                roi_index[i, : len(ix)] = ix.to(torch.int32)
+                rcount[i] = len(ix)
+            roi_index, rcount_d = roi_index.to(self.dev), rcount.to(self.dev)
+            live = (roi_index >= 0)
+            sel = roi_index.clamp(min=0).long()
+            roi_boxes = (torch.gather(allb, 1, sel[:, :, None].expand(B, Rs, 4)) * live[:, :, None]).contiguous()
+            msel = torch.gather(pmidx.long(), 1, sel)
+            roi_gt = (torch.gather(gtb_d, 1, msel[:, :, None].expand(B, Rs, 4)) * live[:, :, None]).contiguous()
+            fg = (torch.gather(plab.long(), 1, sel) == 1) & (gcount_d[:, None] > 0)
+            roi_cls = torch.where(fg & live, torch.gather(gtc_d.long(), 1, msel), torch.full_like(msel, s.num_classes)).to(torch.int32).contiguous()
+        M = B * Rs  # fixed row count: slots past rcount[b] are zero rows that carry neither loss nor gradient
         # ---- box head forward
         pyr = [feats[n] for n in ("p2", "p3", "p4", "p5")]
         scales = [1.0 / FPN_STRIDES[n] for n in ("p2", "p3", "p4", "p5")]
-        pooled = ops.roi_align_fpn(pyr, scales, roi_boxes, rcount_d, 7, 0, True, row_offset=roff, rows=M)
+        pooled = ops.roi_align_fpn(pyr, scales, roi_boxes, rcount_d, 7, 0, True, zero=True)
         bh, bp = "roi_heads.box_head.", "roi_heads.box_predictor."
         xrow = pooled.view(M, 1, 1, 49 * 256)
         h1 = ops.conv2d(xrow, L[bh + "fc1"].fwd())
         h2 = ops.conv2d(h1, L[bh + "fc2"].fwd())
         pred = ops.conv2d(h2, L[bp + "pred"].fwd())
-        box_l, dpred = T.box_loss(pred.view(M, 32), roi_cls_rows, roi_boxes_rows, roi_gt_rows, num_classes=s.num_classes, weights=s.box_weights)
+        box_l, dpred = T.box_loss(pred.view(M, 32), roi_cls.view(M), roi_boxes.view(M, 4), roi_gt.view(M, 4), num_classes=s.num_classes,
+                                  weights=s.box_weights, count=rcount_d, rows_per_image=Rs)
         losses = {"loss_rpn_cls": rpn_l[0], "loss_rpn_loc": rpn_l[1], "loss_cls": box_l[0], "loss_box_reg": box_l[1]}
 
         # ======================================== backward ========================================
@@ -413,7 +391,7 @@ class DetectorTrainer:
         dpooled = ops.conv2d(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
         dP = {n: torch.zeros_like(feats[n]) for n in ("p2", "p3", "p4", "p5")}
         T.roi_align_fpn_backward([dP[n] for n in ("p2", "p3", "p4", "p5")], scales, roi_boxes, dpooled.view(M, 7, 7, 256), P=7,
-                                 sampling_ratio=0, aligned=True, count=rcount_d, row_offset=roff)
+                                 sampling_ratio=0, aligned=True, count=rcount_d)
         # ---- RPN head backward (weights shared by the five levels: gradients accumulate in level order)
         for li, n in enumerate(names):
             dt = ops.conv2d(dheads[li], L[rp + "pred"].bwd(), gate=t[li])
@@ -457,8 +435,8 @@ class DetectorTrainer:
                 else:
                     g = ops.conv2d(da_, c1.bwd(), res=g, gate=x_in)
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
-        aux = dict(relu_outputs=relu_outputs, anchor_labels=out_lab, roi_idx=roi_idx, roi_cls=roi_cls_list, proposals=(pb, pcount), heads=heads, feats=feats,
-                   pred=pred.view(M, 32), roi_boxes=roi_boxes_rows, anchor_match=(midx, lab))
+        aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
+                   proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))
         return losses, aux
 
     def optimizer_step(self):

@@ -34,7 +34,7 @@ extern "C" {
 int a3d_version(void);
 /* sizeof() of a descriptor struct, for bindings to verify their mirror of the layout.  id: 0 a3d_conv_desc, 1 a3d_rpn_desc,
  * 2 a3d_boxdet_desc, 3 a3d_roialign_desc, 4 a3d_paste_desc, 5 a3d_pack_desc, 6 a3d_wgrad_desc, 7 a3d_roialign_bwd_desc,
- * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc; 0 for an unknown id. */
+ * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc, 11 a3d_roi_sample_desc; 0 for an unknown id. */
 size_t a3d_struct_size(int id);
 
 /* ------------------------------------------------------------------------------------------------
@@ -334,6 +334,38 @@ typedef struct a3d_match_desc {
 } a3d_match_desc;
 int a3d_match_boxes(const a3d_match_desc *d, void *stream);
 
+/* detectron2 subsample_labels on the device (RPN._subsample_labels): out[b,i] = 1 / 0 for a uniformly random subset of
+ * at most max_pos positives (label 1) and negatives (label 0) up to `num` in total, -1 elsewhere.  Counter-based RNG:
+ * the subset is a function of (seed, b, i) only.  N < 2^17. */
+int a3d_sample_labels(const signed char *labels, signed char *out, int B, int N, int num, int max_pos, unsigned long long seed,
+                      void *stream);
+
+/* add_ground_truth_to_proposals: out [B, R+Gmax, 4] = [live proposals | ground truth | zeros], out_count = both counts. */
+int a3d_append_gt_boxes(const float *props, const int *count, const float *gt, const int *gt_count, float *out, int *out_count,
+                        int B, int R, int Gmax, void *stream);
+
+/* ROIHeads._sample_proposals + the gathers that follow it (roi_heads.py:93-95 -> detectron2 label_and_sample_proposals):
+ * class of box i = gt_classes[matched_idx[i]] if match_label[i] == 1 else num_classes (background; also when the image
+ * has no ground truth); keeps a random subset of <= max_fg foreground boxes and background boxes up to `num`;
+ * outputs are fixed-size [B, num] (foreground first), slots >= out_count[b] are zero boxes of the background class. */
+typedef struct a3d_roi_sample_desc {
+    const float *boxes;        /* [B, N, 4] (a3d_append_gt_boxes output) */
+    const int *box_count;      /* [B] */
+    const float *gt_boxes;     /* [B, Gmax, 4] */
+    const int *gt_classes;     /* [B, Gmax] */
+    const int *gt_count;       /* [B] */
+    const int *matched_idx;    /* [B, N] (a3d_match_boxes) */
+    const signed char *match_label; /* [B, N] */
+    int B, N, Gmax, num_classes, num, max_fg;
+    unsigned long long seed;
+    float *out_boxes;          /* [B, num, 4] */
+    float *out_gt_boxes;       /* [B, num, 4] */
+    int *out_classes;          /* [B, num] */
+    int *out_index;            /* [B, num] index into boxes, -1 for unused slots */
+    int *out_count;            /* [B] */
+} a3d_roi_sample_desc;
+int a3d_sample_rois(const a3d_roi_sample_desc *d, void *stream);
+
 /* RPN.losses + its gradient with respect to the head outputs (layout of a3d_rpn_desc.head).  loss[0] = loss_rpn_cls,
  * loss[1] = loss_rpn_loc.  labels: -1 ignore, 0 negative, 1 positive AFTER sub-sampling; anchor order: level-major,
  * then (y, x, a). */
@@ -367,6 +399,9 @@ typedef struct a3d_box_loss_desc {
     float weights[4];      /* (10,10,5,5) */
     float *workspace;      /* a3d_loss_workspace_bytes() */
     float *loss;           /* [2] */
+    const int *count;      /* optional [M / R]: rows are R per image and only the first count[b] of image b are live; the
+                              others get zero gradient and the losses are normalised by the live row count.  NULL: all live */
+    int R;
 } a3d_box_loss_desc;
 int a3d_box_loss(const a3d_box_loss_desc *d, void *stream);
 

@@ -253,6 +253,59 @@ def test_rpn_and_box_losses_vs_oracle(T, oracle):
     assert float(dpred[:, K + 1 + 4 * K :].abs().max()) == 0.0
 
 
+def test_device_samplers_draw_valid_uniform_subsets(T):
+    """a3d_sample_labels / a3d_sample_rois: detectron2's subsample_labels rules (counts, classes) hold exactly; the draw is
+    reproducible per seed, changes with the seed and is uniform over the candidates."""
+    torch.manual_seed(9)
+    B, N = 3, 76740
+    lab = torch.full((B, N), -1, dtype=torch.int8)
+    lab[0, torch.randperm(N)[:40]] = 1      # fewer positives than the cap: all kept
+    lab[0, torch.randperm(N)[:60000]] = 0
+    lab[1, :500] = 1                        # more positives than the cap
+    lab[1, 1000:70000] = 0
+    lab[2, 5:105] = 0                       # fewer negatives than requested, no positives
+    out = T.sample_labels(lab.cuda(), num=256, max_pos=128, seed=5).cpu()
+    for b, (npos, nneg) in enumerate([(int((lab[0] == 1).sum()), 256 - int((lab[0] == 1).sum())), (128, 128), (0, 100)]):
+        assert int((out[b] == 1).sum()) == npos and int((out[b] == 0).sum()) == nneg
+        assert bool(((out[b] == 1) <= (lab[b] == 1)).all()) and bool(((out[b] == 0) <= (lab[b] == 0)).all())
+    assert torch.equal(out, T.sample_labels(lab.cuda(), num=256, max_pos=128, seed=5).cpu())
+    assert not torch.equal(out, T.sample_labels(lab.cuda(), num=256, max_pos=128, seed=6).cpu())
+    # uniformity: over 200 seeds each of the 500 positives of image 1 is kept ~128/500 of the time
+    hits = torch.zeros(500)
+    for sd in range(200):
+        hits += (T.sample_labels(lab[1:2].cuda(), num=256, max_pos=128, seed=100 + sd).cpu()[0, :500] == 1).float()
+    p = 128 / 500
+    z = (hits - 200 * p) / (200 * p * (1 - p)) ** 0.5
+    assert float(z.abs().max()) < 4.5 and abs(float(z.mean())) < 0.3
+
+    # proposals: [boxes | gt] with a matcher result; image 1 has no ground truth
+    Bn, R, Gmax, K = 2, 1000, 16, 2
+    props = torch.rand(Bn, R, 4) * 300
+    props[..., 2:] += props[..., :2] + 4
+    pcount = torch.tensor([900, 1000], dtype=torch.int32)
+    gtb = torch.rand(Bn, Gmax, 4) * 300
+    gtb[..., 2:] += gtb[..., :2] + 30
+    gcount = torch.tensor([5, 0], dtype=torch.int32)
+    gtc = torch.randint(0, K, (Bn, Gmax), dtype=torch.int32)
+    allb, bcount = T.append_gt_boxes(props.cuda(), pcount.cuda(), gtb.cuda(), gcount.cuda())
+    assert bcount.tolist() == [905, 1000]
+    assert torch.equal(allb[0, :900].cpu(), props[0, :900]) and torch.equal(allb[0, 900:905].cpu(), gtb[0, :5]) and float(allb[0, 905:].abs().max()) == 0
+    midx, plab = T.match_boxes(allb, gtb.cuda(), gcount.cuda(), thresholds=(0.5,), labels=(0, 1), allow_low_quality=False, box_count=bcount)
+    rb, rg, rcl, ridx, rcnt = T.sample_rois(allb, bcount, gtb.cuda(), gtc.cuda(), gcount.cuda(), midx, plab, num_classes=K, num=512, max_fg=128, seed=3)
+    assert rcnt.tolist() == [512, 512]
+    for b in range(Bn):
+        idx = ridx[b].cpu().long()
+        assert len(set(idx.tolist())) == 512 and int(idx.max()) < int(bcount[b])  # no repeats, only live boxes
+        cls_all = torch.where(plab[b].cpu() == 1, gtc[b][midx[b].cpu().long()].long(), torch.tensor(K)) if gcount[b] > 0 else torch.full((R + Gmax,), K)
+        assert torch.equal(rcl[b].cpu().long(), cls_all[idx])
+        assert torch.equal(rb[b].cpu(), allb[b].cpu()[idx])
+        nfg = int((cls_all[: int(bcount[b])] < K).sum())
+        assert int((rcl[b] < K).sum()) == min(nfg, 128)
+        if gcount[b] > 0:
+            assert torch.equal(rg[b].cpu(), gtb[b][midx[b].cpu().long()[idx]])
+            assert nfg >= 5  # the appended ground-truth boxes match themselves
+
+
 def test_sgd_momentum_vs_oracle(T, oracle):
     from oracle import train_oracle as TO
 
@@ -286,7 +339,11 @@ def trainer_and_ref(hip_model, oracle, oracle_params):
     losses, aux = tr.forward_backward(torch.from_numpy(frames).cuda(), [t[0] for t in tg], [t[1] for t in tg])
     torch.cuda.synchronize()
     pb, pc = aux["proposals"]
-    samples = dict(anchor_labels=aux["anchor_labels"], roi_idx=aux["roi_idx"], proposals=[pb[i, : int(pc[i])].cpu() for i in range(2)])
+    rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
+    roi_idx = [ri[i, : int(rc[i])].long() for i in range(2)]  # the index sets the device sampler drew
+    live_rows = torch.cat([torch.arange(int(rc[i])) + i * ri.shape[1] for i in range(2)])
+    samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=roi_idx, proposals=[pb[i, : int(pc[i])].cpu() for i in range(2)])
+    aux["roi_idx"], aux["live_rows"] = roi_idx, live_rows
     cfg, tc = oracle.OracleCfg(), TO.TrainCfg()
     rl, rg, raux = TO.loss_and_grads(oracle.frames_to_chw(frames), tg, oracle_params, cfg, tc, samples=samples)
     # Second oracle evaluation with the ReLU gates of the HIP forward pass.  A ReLU's derivative is discontinuous in its
@@ -294,7 +351,7 @@ def trainer_and_ref(hip_model, oracle, oracle_params):
     # deep-layer gradients by ~sqrt(flipped fraction) ~ 1e-3 per layer, 2e-2 accumulated at res3 (measured; the oracle's
     # own fp32-vs-fp64 distance is the same size).  Like every discontinuous stage of this suite the backward pass is
     # therefore ALSO compared on identical gates, where only summation-order noise remains.
-    gates = [(g.permute(0, 3, 1, 2) if g.dim() == 4 else g).cpu() > 0 for g in aux["relu_outputs"]]
+    gates = [(g.permute(0, 3, 1, 2) if g.dim() == 4 else g[live_rows.to(g.device)]).cpu() > 0 for g in aux["relu_outputs"]]
     state = {"n": 0}
     real = torch.nn.functional
 
@@ -337,7 +394,8 @@ def test_training_labels_and_losses_match_oracle(trainer_and_ref):
     for i in range(2):
         assert torch.equal(lab[i].cpu(), raux["anchor_match"][i][1])
         assert torch.equal(midx[i].cpu().long(), raux["anchor_match"][i][0])
-        assert torch.equal(aux["roi_cls"][i], raux["roi_cls"][i])  # class labels of the sampled ROIs
+        n = len(aux["roi_idx"][i])
+        assert torch.equal(aux["roi_cls"][i, :n].cpu().long(), raux["roi_cls"][i])  # class labels of the sampled ROIs
     for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
         a, b = losses[k].item(), rl[k].item()
         assert abs(a - b) <= 2e-4 * abs(b) + 1e-7, (k, a, b)
@@ -378,6 +436,6 @@ def test_training_sgd_update_and_loss_decreases(trainer_and_ref, oracle, oracle_
     fr = torch.from_numpy(frames).cuda()
     hist = []
     for _ in range(6):
-        l, _ = tr.step(fr, [t[0] for t in tg], [t[1] for t in tg], samples=dict(anchor_labels=aux["anchor_labels"], roi_idx=aux["roi_idx"]))
+        l, _ = tr.step(fr, [t[0] for t in tg], [t[1] for t in tg], samples=dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=aux["roi_idx"]))
         hist.append(sum(v.item() for v in l.values()))
     assert hist[-1] < hist[0], hist
