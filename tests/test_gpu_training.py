@@ -439,3 +439,26 @@ def test_training_sgd_update_and_loss_decreases(trainer_and_ref, oracle, oracle_
         l, _ = tr.step(fr, [t[0] for t in tg], [t[1] for t in tg], samples=dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=aux["roi_idx"]))
         hist.append(sum(v.item() for v in l.values()))
     assert hist[-1] < hist[0], hist
+
+
+def test_training_overfits_a_fixed_batch(hip_model, oracle):
+    """40 sync-free steps (device-side sampling with a fresh draw every step) on two fixed frames at lr 0.002 (measured:
+    1.48 -> 0.21-0.25 in every repeat; at 0.005 and above momentum SGD without warm-up spikes late in some runs): every
+    loss term stays finite and the total drops to less than half -- the step trains."""
+    from articulation3d_amd.training import DetectorTrainer, SolverCfg
+    from oracle import train_oracle as TO
+
+    frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
+    tg = TO.synthetic_targets(2)
+    tr = DetectorTrainer(hip_model, SolverCfg(base_lr=0.002, warmup_iters=0), seed=3)
+    hist = []
+    for _ in range(40):
+        losses, _ = tr.step(frames, [t[0] for t in tg], [t[1] for t in tg])
+        hist.append(torch.stack([v for v in losses.values()]))
+    hist = torch.stack(hist).cpu()  # one host read at the end
+    assert bool(torch.isfinite(hist).all())
+    first, last = hist[:5].sum(1).mean().item(), hist[-5:].sum(1).mean().item()
+    print("total loss first/last 5 steps:", first, last)
+    assert last < 0.5 * first, (first, last)
+    sd = tr.export_state_dict()
+    assert all(bool(torch.isfinite(v).all()) for v in sd.values())
