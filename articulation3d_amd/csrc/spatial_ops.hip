@@ -167,36 +167,53 @@ extern "C" int a3d_resize_bilinear_nhwc(const float *x, float *y, int B, int H, 
     return a3d_check_launch();
 }
 
-// ---- 3x3 pad-1 conv to one channel: one wave per output pixel group --------------------------------
-// Each lane owns a float4 of channels (C = 64 -> 16 lanes per pixel, 4 pixels per wave); the 9 taps
-// are accumulated per lane, then reduced across the 16 lanes with DPP shuffles.
+// ---- 3x3 pad-1 conv to one channel -------------------------------------------------------------------
+// HBM-bound (reads C floats per output).  Each lane owns a float4 of channels (C = 64 -> 16 lanes per pixel group); a
+// group produces a run of 4 horizontally adjacent outputs from a 3 x 6 input window (18 float4 loads for 4 outputs
+// instead of 36), the filter lives in registers, and the per-pixel sums are reduced across the group's lanes with
+// xor-shuffles.
 __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           float bias, float *__restrict__ y, int B, int H, int W,
                                                           int C) {
     const int lanes_per_pix = C >> 2;           // 16 for C=64
-    const int pix_per_blk = 256 / lanes_per_pix;
+    const int grp_per_blk = 256 / lanes_per_pix;
     const int sub = threadIdx.x % lanes_per_pix;
-    const size_t npix = (size_t)B * H * W;
-    for (size_t p = (size_t)blockIdx.x * pix_per_blk + threadIdx.x / lanes_per_pix; p < npix;
-         p += (size_t)gridDim.x * pix_per_blk) {
-        const int ow = (int)(p % W);
-        const size_t t = p / W;
+    const int Wr = (W + 3) >> 2;  // 4-pixel runs per row
+    const size_t nruns = (size_t)B * H * Wr;
+    f32x4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4 *>(w + t * C + sub * 4);
+    for (size_t r = (size_t)blockIdx.x * grp_per_blk + threadIdx.x / lanes_per_pix; r < nruns; r += (size_t)gridDim.x * grp_per_blk) {
+        const int ow0 = (int)(r % Wr) * 4;
+        const size_t t = r / Wr;
         const int oh = (int)(t % H);
         const int b = (int)(t / H);
-        float acc = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int ih = oh - 1 + dy;
             if ((unsigned)ih >= (unsigned)H) continue;
-            for (int dx = 0; dx < 3; ++dx) {
-                const int iw = ow - 1 + dx;
+            const float *row = x + ((size_t)b * H + ih) * W * C + sub * 4;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {  // input column ow0 - 1 + c feeds outputs j = c - dx, dx = 0..2
+                const int iw = ow0 - 1 + c;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * H + ih) * W + iw) * C + sub * 4);
-                const f32x4 k = *reinterpret_cast<const f32x4 *>(w + (dy * 3 + dx) * C + sub * 4);
-                acc += v[0] * k[0] + v[1] * k[1] + v[2] * k[2] + v[3] * k[3];
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (size_t)iw * C);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int j = c - dx;
+                    if (j < 0 || j > 3) continue;
+                    const f32x4 kk = k[dy * 3 + dx];
+                    acc[j] += v[0] * kk[0] + v[1] * kk[1] + v[2] * kk[2] + v[3] * kk[3];
+                }
             }
         }
-        for (int off = lanes_per_pix >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (sub == 0) y[p] = acc + bias;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = acc[j];
+            for (int off = lanes_per_pix >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (sub == 0 && ow0 + j < W) y[((size_t)b * H + oh) * W + ow0 + j] = a + bias;
+        }
     }
 }
 
@@ -205,10 +222,10 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
     if (!x || !w || !y || B <= 0) return A3D_ERR_ARG;
     const int lpp = C >> 2;
     if ((C & 3) || lpp > 64 || (lpp & (lpp - 1))) return A3D_ERR_UNSUPPORTED;
-    const size_t npix = (size_t)B * H * W;
-    const int ppb = 256 / lpp;
-    size_t blocks = (npix + ppb - 1) / ppb;
-    if (blocks > 8192) blocks = 8192;
+    const size_t nruns = (size_t)B * H * ((W + 3) / 4);
+    const int gpb = 256 / lpp;
+    size_t blocks = (nruns + gpb - 1) / gpb;
+    if (blocks > 16384) blocks = 16384;
     a3d_begin();
     hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W,
                        C);
