@@ -159,6 +159,17 @@ class RoiSampleDesc(C.Structure):
     ]
 
 
+class SweepDesc(C.Structure):
+    _fields_ = [
+        ("mask", fptr), ("H", C.c_int), ("W", C.c_int),
+        ("normal", C.c_float * 3), ("offset", C.c_float),
+        ("focal", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("pivot", C.c_float * 3),
+        ("xforms", fptr), ("A", C.c_int),
+        ("out_bits", fptr),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/a3d.h declares
 SIGNATURES = {
     "a3d_version": (C.c_int, []),
@@ -201,11 +212,15 @@ SIGNATURES = {
     "a3d_sample_labels": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, fptr]),
     "a3d_append_gt_boxes": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_sample_rois": (C.c_int, [C.POINTER(RoiSampleDesc), fptr]),
+    "a3d_masks_pack_bits": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_masks_unpack_bits": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_project_hypotheses": (C.c_int, [C.POINTER(SweepDesc), fptr]),
+    "a3d_mask_iou_matrix": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_sgd_momentum": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
 }
 
 STRUCT_IDS = {0: ConvDesc, 1: RpnDesc, 2: BoxDetDesc, 3: RoiAlignDesc, 4: PasteDesc, 5: PackDesc, 6: WgradDesc,
-              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc, 11: RoiSampleDesc}
+              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc, 11: RoiSampleDesc, 12: SweepDesc}
 
 _lib = None
 

@@ -31,6 +31,7 @@ SOURCES = {
     "pack.hip": [],
     "conv_wgrad.hip": [],
     "train_sample.hip": [],
+    "opt_sweep.hip": ["-ffp-contract=off"],  # the projected pixel index is a truncation: round like the reference's mul / add
     "train_ops.hip": ["-ffp-contract=off"],  # matcher IoU / box deltas round like the reference's separate mul, add, div
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

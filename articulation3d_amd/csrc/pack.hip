@@ -101,6 +101,7 @@ extern "C" size_t a3d_struct_size(int id) {
         case 9: return sizeof(a3d_rpn_loss_desc);
         case 10: return sizeof(a3d_box_loss_desc);
         case 11: return sizeof(a3d_roi_sample_desc);
+        case 12: return sizeof(a3d_sweep_desc);
         default: return 0;
     }
 }

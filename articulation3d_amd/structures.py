@@ -51,6 +51,10 @@ class Boxes:
         b = self.tensor
         return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
 
+    def get_centers(self):
+        """(N, 2) box centres (x, y) -- detectron2 Boxes.get_centers, used by the optimiser (opt_utils.py:405)."""
+        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
+
     def scale(self, scale_x: float, scale_y: float):
         self.tensor[:, 0::2] *= scale_x
         self.tensor[:, 1::2] *= scale_y

@@ -34,7 +34,7 @@ extern "C" {
 int a3d_version(void);
 /* sizeof() of a descriptor struct, for bindings to verify their mirror of the layout.  id: 0 a3d_conv_desc, 1 a3d_rpn_desc,
  * 2 a3d_boxdet_desc, 3 a3d_roialign_desc, 4 a3d_paste_desc, 5 a3d_pack_desc, 6 a3d_wgrad_desc, 7 a3d_roialign_bwd_desc,
- * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc, 11 a3d_roi_sample_desc; 0 for an unknown id. */
+ * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc, 11 a3d_roi_sample_desc, 12 a3d_sweep_desc; 0 for an unknown id. */
 size_t a3d_struct_size(int id);
 
 /* ------------------------------------------------------------------------------------------------
@@ -409,6 +409,35 @@ int a3d_box_loss(const a3d_box_loss_desc *d, void *stream);
  * d = grad_scale*g + wd*p;  buf = first ? d : momentum*buf + d;  p -= lr*buf */
 int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
                      int first, void *stream);
+
+/* ================================================================================================
+ * Hypothesis sweeps of the temporal optimiser.  Replace the per-hypothesis / per-frame Python loops
+ * inside optimize_planes_3dc and optimize_planes_3d_trans (pkg/utils/opt_utils.py:400-476, 540-611, 700-768, 838-905):
+ * lift a mask onto its plane (get_pcd, pkg/utils/vis.py:86-102), apply every rigid hypothesis, re-project
+ * (project2D, vis.py:62-83) into one binary mask per hypothesis, IoU against the tracked detections' masks.
+ * Masks are bit-packed: words = ceil(H*W/32), bit i of word w = pixel 32w+i (row-major).
+ * ============================================================================================== */
+#define A3D_SWEEP_MAX_HYP 64
+int a3d_masks_pack_bits(const unsigned char *masks /*[n,H,W], non-zero = set*/, unsigned int *bits /*[n,words]*/, int n, int H, int W,
+                        void *stream);
+int a3d_masks_unpack_bits(const unsigned int *bits, unsigned char *masks /*[n,H,W] 0/1*/, int n, int H, int W, void *stream);
+
+typedef struct a3d_sweep_desc {
+    const unsigned char *mask; /* [H,W] source mask (pred_mask.nonzero())                                     */
+    int H, W;
+    float normal[3];           /* unit plane normal in the optimiser's camera frame ((a,b,c) -> (a,-c,b) swap)  */
+    float offset;              /* plane offset = |plane|                                                     */
+    double focal, cx, cy;      /* vis.py intrinsics: 517.97, W/2, H/2                                          */
+    float pivot[3];            /* point the rotations turn about (a 3-D point of the axis); 0 for translations */
+    const float *xforms;       /* [A][12]: R (row-major 3x3) then t; point' = R (point - pivot) + pivot + t      */
+    int A;                     /* hypotheses, <= A3D_SWEEP_MAX_HYP                                             */
+    unsigned int *out_bits;    /* [A, words], cleared by the call                                              */
+} a3d_sweep_desc;
+int a3d_project_hypotheses(const a3d_sweep_desc *d, void *stream);
+
+/* iou[f*A + a] = |target_f & proj_a| / |target_f | proj_a|  (opt_utils.py:470-475). */
+int a3d_mask_iou_matrix(const unsigned int *target_bits /*[F,words]*/, const unsigned int *proj_bits /*[A,words]*/, float *iou, int F,
+                        int A, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }
