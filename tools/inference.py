@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""The reference's tools/inference.py on this package: per-clip articulation prediction.
+
+    python tools/inference.py --config configs/planercnn_inference.yaml --input <frames> --output out/ [--conf-threshold 0.7]
+
+Same stages as the reference script (tools/inference.py:171-250): build the model from the YAML, detect every frame,
+build the `create_instances` records, `track_planes`, `optimize_planes(preds, planes, '3dc')` -- but the frame loop is the
+batched, frame-sharded `pipeline.detect_clip` (one RCCL all-gather per clip when launched with torchrun) and the
+optimiser's sweeps run on the GPU.  `random.seed(2020)` / `np.random.seed(2020)` as in the reference (:172-173).
+
+Input (this image has no video decoder: cv2 / imageio are absent, so .mp4 is refused with a clear message):
+  * a .npy / .npz file with uint8 frames [F,H,W,3] in RGB order (what imageio would hand over), or
+  * a directory of .png / .jpg frames (read with PIL, sorted by name), or
+  * `synthetic:N` -- N seeded random frames (plumbing check).
+Frames are resized to 640x480 (bilinear) and flipped to BGR like the reference (:216-218).
+Output: <output>/predictions.json -- per frame the optimised detections (bbox xyxy, score, class, plane, rotation /
+translation axis, RLE mask) and <output>/tracks.json (tracked planes, has_rot, consensus axis).  The 2-D / 3-D
+visualisations of the reference (imageio video, pytorch3d meshes) are out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def read_frames(path: str) -> np.ndarray:
+    from PIL import Image
+
+    if path.startswith("synthetic:"):
+        from articulation3d_amd.utils.synthetic import synthetic_frames
+
+        return synthetic_frames(int(path.split(":")[1]))[..., ::-1].copy()  # stored BGR -> RGB, flipped back below
+    if path.endswith((".mp4", ".avi", ".mov")):
+        raise SystemExit("no video decoder in this environment (cv2 / imageio absent): pass a .npy of RGB frames or a directory of images")
+    if path.endswith(".npy"):
+        frames = np.load(path)
+    elif path.endswith(".npz"):
+        z = np.load(path)
+        frames = z[list(z.keys())[0]]
+    elif os.path.isdir(path):
+        names = sorted(n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg")))
+        frames = np.stack([np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names])
+    else:
+        frames = np.asarray(Image.open(path).convert("RGB"))[None]
+    assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8, "frames must be uint8 [F,H,W,3]"
+    if frames.shape[1:3] != (480, 640):
+        frames = np.stack([np.asarray(Image.fromarray(f).resize((640, 480), Image.BILINEAR)) for f in frames])
+    return frames
+
+
+def main():
+    random.seed(2020)
+    np.random.seed(2020)
+    ap = argparse.ArgumentParser(description="Articulation prediction on a clip (MI355X).")
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--input", required=True)
+    ap.add_argument("--output", required=True)
+    ap.add_argument("--conf-threshold", default=0.7, type=float)
+    ap.add_argument("--batch", default=32, type=int, help="frames per detector batch per GPU")
+    ap.add_argument("--calibrate-bn", action="store_true", help="random-init weights only: estimate batch-norm statistics on the clip")
+    args = ap.parse_args()
+    os.makedirs(args.output, exist_ok=True)
+
+    from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
+    from articulation3d_amd.pipeline import detect_clip
+    from articulation3d_amd.utils import rle
+    from articulation3d_amd.utils.arti_vis import PlaneRCNN_Branch
+    from articulation3d_amd.utils.opt_utils import optimize_planes, track_planes
+
+    cfg = get_cfg()
+    get_planercnn_cfg_defaults(cfg)
+    cfg.merge_from_file(args.config)
+    branch = PlaneRCNN_Branch(cfg)
+    model = branch.predictor.model
+    frames_rgb = read_frames(args.input)
+    frames_bgr = np.ascontiguousarray(frames_rgb[..., ::-1])
+    if args.calibrate_bn:
+        from articulation3d_amd.utils.synthetic import calibrate_batchnorm
+
+        calibrate_batchnorm(model, torch.from_numpy(frames_bgr[:2]).to(model.device))
+    preds = detect_clip(model, frames_bgr, batch=args.batch, conf_threshold=args.conf_threshold)
+    planes = track_planes(preds)
+    opt_preds = optimize_planes(preds, planes, "3dc", frames=frames_rgb)
+
+    out = []
+    for i, p in enumerate(opt_preds):
+        n = len(p.pred_boxes)
+        out.append({"frame": i, "instances": [{
+            "bbox": [float(v) for v in p.pred_boxes.tensor[k]], "score": float(p.scores[k]), "category_id": int(p.pred_classes[k]),
+            "pred_plane": [float(v) for v in p.pred_planes[k]], "pred_rot_axis": [float(v) for v in p.pred_rot_axis[k]],
+            "pred_tran_axis": [float(v) for v in p.pred_tran_axis[k]],
+            "segmentation": rle.encode(np.asfortranarray(p.pred_masks[k].numpy().astype(np.uint8)))} for k in range(n)]})
+    with open(os.path.join(args.output, "predictions.json"), "w") as f:
+        json.dump(out, f)
+    tracks = {cat: [{"frames": sorted(t["ids"]), "has_motion": bool(t.get("has_rot", False)),
+                     "consensus_axis": (np.asarray(t["std_axis"]).tolist() if "std_axis" in t else None)} for t in ts]
+              for cat, ts in planes.items()}
+    with open(os.path.join(args.output, "tracks.json"), "w") as f:
+        json.dump(tracks, f)
+    kept = sum(len(p.pred_boxes) for p in opt_preds)
+    print(f"{len(frames_bgr)} frames, {kept} detections above {args.conf_threshold}, "
+          f"{len(planes['rot'])} rotation / {len(planes['trans'])} translation tracks -> {args.output}")
+
+
+if __name__ == "__main__":
+    main()
