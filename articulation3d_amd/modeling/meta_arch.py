@@ -134,9 +134,61 @@ class PlaneRCNN(nn.Module):
             return self.inference(batched_inputs)
         raise NotImplementedError("training forward (losses) is outside the inference hot path (SURVEY.md 8f-1)")
 
+    fast_reference_path = True  # route uniform batches of the reference-signature call through inference_batched
+
+    def _fast_path_ok(self, batched_inputs, do_postprocess) -> bool:
+        if not (self.fast_reference_path and do_postprocess) or self._eval_gt_box or self.proposal_generator is None:
+            return False
+        rh = self.roi_heads
+        if not (getattr(rh, "mask_on", False) and getattr(rh, "plane_on", False) and getattr(rh, "axis_on", False) and self.depth_head_on):
+            return False
+        shp = tuple(batched_inputs[0]["image"].shape)
+        div = self.backbone.size_divisibility
+        if len(shp) != 3 or shp[1] % div or shp[2] % div:
+            return False
+        for x in batched_inputs:
+            if tuple(x["image"].shape) != shp or "instances" in x or "proposals" in x:
+                return False
+            if x.get("height", shp[1]) != shp[1] or x.get("width", shp[2]) != shp[2]:
+                return False
+        return True
+
+    @torch.no_grad()
+    def _inference_fast(self, batched_inputs):
+        """Same outputs as inference_single + _postprocess (tests/test_gpu_parity.py::test_reference_api_matches_batched_path
+        holds them bit-identical), from ONE pass of the fixed-size batched path: no per-stage Instances round trips and a
+        single host read of the detection counts, instead of a synchronisation after every stage."""
+        imgs = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]  # (stacking on the host costs ~9 ms per frame)
+        frames = imgs[0][None] if len(imgs) == 1 else torch.stack(imgs)
+        out = self.inference_batched(frames.float(), want_masks=True)  # CHW 0-255 BGR, any integer / float dtype
+        hw = out.image_size
+        cnt, keep = out.det.count.tolist(), out.keep.bool()
+        ro = out.det.row_offset.tolist() if out.det.total else [0] * (len(cnt) + 1)
+        res = []
+        for b, n in enumerate(cnt):
+            inst = Instances(hw)
+            idx = keep[b, :n].nonzero().squeeze(1)
+            inst.pred_boxes = Boxes(out.boxes[b, idx])
+            inst.scores = out.det.scores[b, idx]
+            inst.pred_classes = out.det.classes[b, idx].to(torch.int64)
+            if out.det.total and out.masks is not None:
+                inst.pred_masks = out.masks[b, idx].bool()
+                inst.pred_plane = out.det.pred_plane[ro[b] + idx]
+                inst.pred_rot_axis = out.det.pred_rot_axis[ro[b] + idx]
+                inst.pred_tran_axis = out.det.pred_tran_axis[ro[b] + idx]
+            else:
+                dev = out.boxes.device
+                inst.pred_masks = torch.zeros((0, hw[0], hw[1]), device=dev, dtype=torch.bool)
+                inst.pred_plane, inst.pred_rot_axis = torch.zeros((0, 3), device=dev), torch.zeros((0, 3), device=dev)
+                inst.pred_tran_axis = torch.zeros((0, 2), device=dev)
+            res.append({"instances": inst, "depth": out.depth[b]})
+        return res
+
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
         assert not self.training
         assert detected_instances is None
+        if self._fast_path_ok(batched_inputs, do_postprocess):
+            return self._inference_fast(batched_inputs)
         pred_instances, pred_depth = self.inference_single(batched_inputs, do_postprocess)
         for pre, d in zip(pred_instances, pred_depth):
             pre.update({"depth": d})

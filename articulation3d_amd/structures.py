@@ -17,6 +17,22 @@ class ShapeSpec(namedtuple("_ShapeSpec", ["channels", "height", "width", "stride
         return super().__new__(cls, channels, height, width, stride)
 
 
+def to_host(t: torch.Tensor) -> torch.Tensor:
+    """Device -> host copy through PINNED host memory (torch's caching host allocator keeps the pages locked and re-uses
+    them).  A plain `.cpu()` lands in pageable memory that the HIP runtime has to register with the GPU for the DMA; when
+    that memory is later returned to the OS the driver must tear the registration down, which evicts and restores the
+    process's GPU queues -- measured as 40-70 ms stalls of the NEXT frame every few frames of the reference-style loop."""
+    if not t.is_cuda:
+        return t
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h
+
+
+def _is_cpu(device) -> bool:
+    return str(device) == "cpu" or (isinstance(device, torch.device) and device.type == "cpu")
+
+
 class Boxes:
     """N x 4 xyxy float32 boxes."""
 
@@ -33,7 +49,7 @@ class Boxes:
         return Boxes(self.tensor.clone())
 
     def to(self, device):
-        return Boxes(self.tensor.to(device=device))
+        return Boxes(to_host(self.tensor) if _is_cpu(device) else self.tensor.to(device=device))
 
     def area(self):
         b = self.tensor
@@ -130,8 +146,11 @@ class Instances:
 
     def to(self, *args, **kwargs):
         ret = Instances(self._image_size)
+        to_cpu = len(args) == 1 and not kwargs and _is_cpu(args[0])
         for k, v in self._fields.items():
-            if hasattr(v, "to"):
+            if to_cpu and isinstance(v, torch.Tensor):
+                v = to_host(v)
+            elif hasattr(v, "to"):
                 v = v.to(*args, **kwargs)
             ret.set(k, v)
         return ret

@@ -13,12 +13,14 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 import torch
 
 from .. import ops
 from ..modeling import build_model
-from ..structures import Boxes, Instances
+from ..structures import Boxes, Instances, to_host
 from . import rle as mask_util
 
 FOCAL_LENGTH = 571.623718
@@ -86,6 +88,13 @@ def instances_to_coco_json(instances: Instances, img_id) -> List[dict]:
 
 class PlaneRCNN_Branch:
     def __init__(self, cfg, cpu_device="cpu"):
+        # The host side of the per-frame loop is small tensor glue (RLE, json, record building).  With torch's default
+        # intra-op pool (one OpenMP worker per core, 128-256 on an MI355X host) the workers spin after every tiny CPU op
+        # and starve the HIP runtime's own threads: measured 40-70 ms stalls of the next frame every few frames (31 fps
+        # instead of 84 fps for the unchanged reference loop).  A3D_HOST_THREADS overrides; 0 leaves torch's setting.
+        n = int(os.environ.get("A3D_HOST_THREADS", "8"))
+        if n > 0 and torch.get_num_threads() > n:
+            torch.set_num_threads(n)
         self.predictor = DefaultPredictor(cfg)
         self._cpu_device = cpu_device
         self._device = torch.device(cfg.MODEL.DEVICE)
@@ -94,7 +103,13 @@ class PlaneRCNN_Branch:
 
     def inference(self, img):
         """img: HWC uint8 BGR (arti_vis.py:54-61)."""
-        img = torch.as_tensor(img.transpose(2, 0, 1).astype("float32"))
+        # the reference converts HWC uint8 -> CHW float32 on the host (arti_vis.py:58); the same values are produced by
+        # uploading the uint8 frame (4x fewer bytes over PCIe) and casting on the device
+        # (through a pinned staging buffer: see structures.to_host for why pageable DMA sources / targets are avoided)
+        if getattr(self, "_stage", None) is None or self._stage.shape != img.shape:
+            self._stage = torch.empty(img.shape, dtype=torch.uint8, pin_memory=self._device.type == "cuda")
+        self._stage.copy_(torch.from_numpy(np.ascontiguousarray(img)))
+        img = self._stage.to(self._device).permute(2, 0, 1).float()
         with torch.no_grad():
             pred = self.predictor.model([{"image": img}])[0]
         return pred
@@ -107,15 +122,15 @@ class PlaneRCNN_Branch:
             instances = inst_dev.to(self._cpu_device)
             prediction["instances"] = instances_to_coco_json(instances, "demo")
             if inst_dev.has("pred_plane"):
-                prediction["pred_plane"] = inst_dev.pred_plane.to(self._cpu_device)
+                prediction["pred_plane"] = to_host(inst_dev.pred_plane)
             if inst_dev.has("pred_rot_axis"):
-                prediction["pred_rot_axis"] = inst_dev.pred_rot_axis.to(self._cpu_device)
+                prediction["pred_rot_axis"] = to_host(inst_dev.pred_rot_axis)
             if inst_dev.has("pred_tran_axis"):
-                prediction["pred_tran_axis"] = inst_dev.pred_tran_axis.to(self._cpu_device)
+                prediction["pred_tran_axis"] = to_host(inst_dev.pred_tran_axis)
         if (output.get("depth") is not None) and (not self._refine_on):
-            prediction["pred_depth"] = output["depth"].to(self._cpu_device)
+            prediction["pred_depth"] = to_host(output["depth"])
             if inst_dev is not None and inst_dev.has("pred_plane") and inst_dev.has("pred_masks"):
-                prediction["pred_plane"] = self.override_depth_device(output["depth"], inst_dev).to(self._cpu_device)
+                prediction["pred_plane"] = to_host(self.override_depth_device(output["depth"], inst_dev))
         return prediction
 
     def depth2XYZ(self, depth):

@@ -543,8 +543,18 @@ def test_reference_api_matches_batched_path(hip_model, oracle):
     frames = oracle.synthetic_frames(2, seed=7)
     out_b = model.inference_batched(torch.from_numpy(frames).cuda(), want_masks=True)
     inputs = [{"image": torch.as_tensor(f.transpose(2, 0, 1).astype("float32"))} for f in frames]
-    outs = model(inputs)  # list[{"instances", "depth"}] as planercnn.py:143-146
-    assert len(outs) == 2
+    outs_fast = model(inputs)  # list[{"instances", "depth"}] as planercnn.py:143-146 (uniform batch -> one batched pass)
+    model.fast_reference_path = False
+    try:
+        outs = model(inputs)   # the module-by-module path (proposal generator / ROI heads / postprocess signatures)
+    finally:
+        model.fast_reference_path = True
+    assert len(outs) == len(outs_fast) == 2
+    for o, f in zip(outs, outs_fast):  # the two routes of the reference signature agree bit for bit
+        a, c = o["instances"], f["instances"]
+        assert torch.equal(a.pred_boxes.tensor, c.pred_boxes.tensor) and torch.equal(a.scores, c.scores) and torch.equal(a.pred_classes, c.pred_classes)
+        assert torch.equal(a.pred_masks, c.pred_masks) and torch.equal(a.pred_plane, c.pred_plane)
+        assert torch.equal(a.pred_rot_axis, c.pred_rot_axis) and torch.equal(a.pred_tran_axis, c.pred_tran_axis) and torch.equal(o["depth"], f["depth"])
     for b, o in enumerate(outs):
         inst = o["instances"]
         idx = out_b.keep[b, : int(out_b.det.count[b])].bool().nonzero().squeeze(1)

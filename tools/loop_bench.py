@@ -1,0 +1,46 @@
+"""The reference's own per-frame loop (tools/inference.py:215-228) on this package: inference -> process -> create_instances,
+one frame at a time, timed; and the batched detect_clip on the same frames."""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
+from articulation3d_amd.utils.arti_vis import PlaneRCNN_Branch, create_instances
+from articulation3d_amd.utils.synthetic import synthetic_frames, calibrate_batchnorm
+from articulation3d_amd.pipeline import detect_clip
+
+cfg = get_cfg(); get_planercnn_cfg_defaults(cfg)
+cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "planercnn_inference.yaml"))
+cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.5
+torch.manual_seed(2020)
+branch = PlaneRCNN_Branch(cfg)
+model = branch.predictor.model
+frames = synthetic_frames(40)
+calibrate_batchnorm(model, torch.from_numpy(synthetic_frames(2, 2021)).cuda())
+def loop(fr):
+    out = []
+    for im in fr:
+        pred = branch.inference(im)
+        d = branch.process(pred)
+        out.append(create_instances(d["instances"], im.shape[:2], pred_planes=d["pred_plane"].numpy(), pred_rot_axis=d["pred_rot_axis"],
+                                    pred_tran_axis=d["pred_tran_axis"], conf_threshold=0.5))
+    return out
+loop(frames[:4]); torch.cuda.synchronize()
+t = time.perf_counter(); p1 = loop(frames[4:36]); torch.cuda.synchronize(); t1 = (time.perf_counter() - t) / 32
+detect_clip(model, frames[:4], batch=4, conf_threshold=0.5); torch.cuda.synchronize()
+t = time.perf_counter(); p2 = detect_clip(model, frames[4:36], batch=32, conf_threshold=0.5); torch.cuda.synchronize(); t2 = (time.perf_counter() - t) / 32
+print(f"reference-style loop: {t1 * 1e3:.2f} ms/frame ({1 / t1:.1f} fps); detect_clip(batch 32): {t2 * 1e3:.2f} ms/frame ({1 / t2:.1f} fps); "
+      f"detections {sum(len(p.pred_boxes) for p in p1)} / {sum(len(p.pred_boxes) for p in p2)}")
+
+seg = [0.0, 0.0, 0.0]
+for im in frames[4:36]:
+    t0 = time.perf_counter(); pred = branch.inference(im); torch.cuda.synchronize(); t1 = time.perf_counter()
+    d = branch.process(pred); t2 = time.perf_counter()
+    create_instances(d["instances"], im.shape[:2], pred_planes=d["pred_plane"].numpy(), pred_rot_axis=d["pred_rot_axis"], pred_tran_axis=d["pred_tran_axis"], conf_threshold=0.5)
+    t3 = time.perf_counter()
+    seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2
+print("per frame ms: inference %.2f  process %.2f  create_instances %.2f" % tuple(1e3 * x / 32 for x in seg))
+x = torch.from_numpy(frames[4:5]).cuda()
+for _ in range(3): model.inference_batched(x)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): model.inference_batched(x)
+torch.cuda.synchronize(); print("inference_batched(B=1) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
+
