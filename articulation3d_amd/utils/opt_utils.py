@@ -9,7 +9,12 @@ list[Instances] that `pipeline.detect_clip` rebuilds from the all-gathered detec
 """
 from __future__ import annotations
 
+import random as _random
 from typing import Dict, List
+
+import numpy as np
+import torch
+from scipy.stats import linregress
 
 from ..structures import Instances, pairwise_iou
 
@@ -48,13 +53,6 @@ def track_planes(preds: List[Instances]) -> Dict[str, list]:
 # every tracked mask" -- run as two GPU launches on bit-packed masks (include/a3d.h: a3d_project_hypotheses,
 # a3d_mask_iou_matrix) instead of a Python loop with one scatter and two full-image reductions per (hypothesis, frame).
 # ======================================================================================================
-import math
-import random as _random
-
-import numpy as np
-import torch
-from scipy.stats import linregress
-
 FOCAL = 517.97  # pkg/utils/vis.py:62,86 (the optimiser's intrinsics; the detector's ray table uses 571.62)
 
 
