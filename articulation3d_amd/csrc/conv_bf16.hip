@@ -1,0 +1,191 @@
+// bf16-MFMA variant of the implicit-GEMM convolution / linear kernel (a3d_conv_desc.precision == 1).
+//
+// What it is for.  The reference trains under bf16 autocast (BASELINE configs[4]: tools/train_net.py with
+// config/step1_bbox.yaml, SOLVER.AMP): convolutions and linear layers multiply bf16 operands and accumulate in fp32.
+// Tensors stay fp32 in HBM here (master weights, activations, gradients); this kernel rounds both operands to bf16
+// (round-to-nearest-even, v_cvt_pk_bf16_f32) while it stages them in LDS and multiplies with
+// v_mfma_f32_32x32x16_bf16 -- 16x the matrix rate of the fp32 MFMA, so every layer of the step becomes HBM-bound.
+// The default (precision 0) fp32 path is untouched: inference parity is an fp32 statement.
+//
+// Same decomposition as conv_gemm_v2 (MODE_GENERIC): output tile 128 x (64*TN), 4 waves as 2x2, weights are MFMA
+// operand A and activations operand B (a lane owns one output pixel, register quads are 4 consecutive channels), buffer
+// loads with the hardware range check for padding taps / ragged rows, single register staging set, one barrier per
+// 32-deep k chunk, the LDS-staged epilogue.  LDS image: [row][32 k] bf16 with an 80-byte row pitch -- a fragment is
+// ONE ds_read_b128 (8 consecutive k of one row), and 16 rows x 80 B tile the 64 banks exactly once per lane group.
+#include "conv_common.h"
+
+namespace {
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 bf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    constexpr int TM = 2, BKT = 32;
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    constexpr int LKB = BKT + 8;               // bf16 elements per LDS row (80 bytes)
+    constexpr int TPR = BKT / 4, RPP = 256 / TPR;  // 8 lanes x float4 per row, 32 rows per loader pass
+    constexpr int XR = BM / RPP, WR = BN / RPP;
+    constexpr int BUF = (BM + BN) * LKB;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = d.Kpad / BKT;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    const int cs4 = d.Cin * 4;
+    const __amdgpu_buffer_rsrc_t rx = bf_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const __amdgpu_buffer_rsrc_t rw = bf_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
+
+    int rowoff[XR];
+    unsigned vmask[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = m0 + lr + RPP * i;
+        const bool rok = m < M;
+        const int mm = rok ? m : 0;
+        const int hw = d.Ho * d.Wo;
+        const int b = mm / hw, r = mm - b * hw;
+        const int oh = r / d.Wo, ow = r - oh * d.Wo;
+        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        unsigned mask = 0;
+        for (int kh = 0; kh < d.KH; ++kh)
+            for (int kw = 0; kw < d.KW; ++kw)
+                mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
+        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        vmask[i] = mask;
+    }
+    int woff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int n = n0 + lr + RPP * i;
+        woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
+    }
+    int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next chunk to load inside the filter
+    f32x4 xs[XR], ws[WR];
+    auto load_chunk = [&]() {
+        const int tap = kh * d.KW + kw;
+        const unsigned livebit = (kc < nk) ? 1u : 0u;
+        const int tapoff = (kh * d.W + kw) * cs4 + c0 * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = bf_load4(rx, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+        const int soff = kc * (BKT * 4);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ws[i] = bf_load4(rw, livebit ? woff[i] : -1, soff);
+        ++kc;
+        c0 += BKT;
+        if (c0 >= d.Cin) {
+            c0 = 0;
+            if (++kw == d.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {  // fp32 -> bf16 (RNE) on the way into LDS
+        __bf16 *X = lds + buf * BUF;
+        __bf16 *Wt = X + BM * LKB;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) *reinterpret_cast<bf16x4 *>(X + (lr + RPP * i) * LKB + lc) = __builtin_convertvector(xs[i], bf16x4);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) *reinterpret_cast<bf16x4 *>(Wt + (lr + RPP * i) * LKB + lc) = __builtin_convertvector(ws[i], bf16x4);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    a3d_stage_scale_shift(ss, d, n0, BN, tid);
+    load_chunk();
+    store_chunk(0);
+    load_chunk();
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LKB + (lane >> 5) * 8;  // row = lane % 32, k = 8 * (lane / 32) .. + 7
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        const __bf16 *X = lds + cur * BUF + (wm * TM * 32) * LKB + frag_off;
+        const __bf16 *Wt = lds + cur * BUF + BM * LKB + (wn * TN * 32) * LKB + frag_off;
+        bf16x8 fa[2][TN], fb[2][TM];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {  // two 16-deep MFMA steps per chunk
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) fa[s][ni] = *reinterpret_cast<const bf16x8 *>(Wt + ni * 32 * LKB + s * 16);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) fb[s][mi] = *reinterpret_cast<const bf16x8 *>(X + mi * 32 * LKB + s * 16);
+        }
+        store_chunk(cur ^ 1);
+        load_chunk();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][ni], fb[s][mi], acc[ni][mi], 0, 0, 0);
+        __syncthreads();
+    }
+
+    const bool has_res = d.res != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
+        if (m >= M) continue;
+        size_t res_row;
+        int b, oh, ow;
+        out_rows(d, m, res_row, b, oh, ow);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            f32x4 rv[4];
+            if (has_res) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    rv[rg] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + min(n, d.Cout - 4));
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
+                if (n >= d.Cout) continue;
+                f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                store_out(d, v, m, n, b, oh, ow);
+            }
+        }
+    }
+}
+
+template <int TN>
+void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
+    constexpr int BM = 128, BN = 64 * TN;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_bf16_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+}
+}  // namespace
+
+int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if ((d->Cin & 31) || d->Kpad != d->KH * d->KW * d->Cin || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
+    const int M = d->B * d->Ho * d->Wo;
+    const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (d->Cout <= 64 || n128 <= 1000) launch_bf16<1>(d, s);
+    else launch_bf16<2>(d, s);
+    return a3d_check_launch();
+}

@@ -103,6 +103,9 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
 // grid busy.  Returns A3D_ERR_UNSUPPORTED otherwise.  `force` skips the grid-size heuristic (A/B measurements).
 int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
 
+// bf16-MFMA variant (conv_bf16.hip), selected by a3d_conv_desc.precision == 1.
+int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s);
+
 // Winograd F(2x2,3x3) path (conv_wino.hip).  eligible() ignores the workspace pointer (used for sizing).
 int a3d_wino_eligible(const a3d_conv_desc *d);
 size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d);

@@ -127,6 +127,118 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const a3d_wgrad_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-MFMA variant (a3d_wgrad_desc.precision == 1; see conv_bf16.hip for the why).  The fragments of
+// v_mfma_f32_32x32x16_bf16 want 8 CONSECUTIVE k (= pixels) per lane, but NHWC makes channels contiguous, so the transpose
+// happens on the way into LDS: a thread owns ONE channel and loads it for 8 consecutive pixels (a wave still reads 256
+// contiguous bytes per pixel), rounds the 8 values to bf16 and writes them as one 16-byte row segment of the LDS image
+// [channel][32 pixels] (80-byte pitch: conflict-free ds_write_b128 / ds_read_b128).  Chunk = 32 pixels.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wg_f32x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const a3d_wgrad_desc d, const int P, const int mtiles, const int ntiles,
+                                                                  const int chunk) {
+    constexpr int BKP = 32, LKB = BKP + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][128 * LKB];  // [buffer][A|B][channel][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    const int nt = t % ntiles;
+    t /= ntiles;
+    const int mt = t % mtiles;
+    const int tap = t / mtiles;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int co0 = mt * 128, ci0 = nt * 128;
+    const int p_begin = blockIdx.y * chunk, p_end = min(P, p_begin + chunk);
+    const int ch = tid & 127, kg = tid >> 7;  // channel inside the tile; pixel groups kg*2, kg*2+1 (8 pixels each)
+    const bool a_ok = co0 + ch < d.Cout, b_ok = ci0 + ch < d.Cin;
+    const int HoWo = d.Ho * d.Wo;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.dy), 0, (int)((size_t)P * d.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.x), 0, (int)((size_t)d.B * d.H * d.W * d.Cin * 4), 0x00020000);
+
+    wg_f32x8 ra[2], rb[2];
+    auto load = [&](int p0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int pg = p0 + (kg * 2 + g) * 8;
+            int b = pg / HoWo, r = pg - b * HoWo;
+            int oh = r / d.Wo, ow = r - oh * d.Wo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int p = pg + k;
+                const bool live = p < p_end;
+                const int iy = oh * d.stride + kh - d.pad, ix = ow * d.stride + kw - d.pad;
+                const bool in = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                ra[g][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (live && a_ok) ? (p * d.Cout + co0 + ch) * 4 : -1, 0, 0));
+                rb[g][k] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rx, (in && b_ok) ? (((b * d.H + iy) * d.W + ix) * d.Cin + ci0 + ch) * 4 : -1, 0, 0));
+                if (++ow == d.Wo) {  // next pixel of the run
+                    ow = 0;
+                    if (++oh == d.Ho) {
+                        oh = 0;
+                        ++b;
+                    }
+                }
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][ch * LKB + (kg * 2 + g) * 8]) = __builtin_convertvector(ra[g], wg_bf16x8);
+            *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][ch * LKB + (kg * 2 + g) * 8]) = __builtin_convertvector(rb[g], wg_bf16x8);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nchunks = (p_end - p_begin + BKP - 1) / BKP;
+    if (nchunks > 0) {
+        load(p_begin);
+        store(0);
+        __syncthreads();
+    }
+    const int foff = (lane & 31) * LKB + (lane >> 5) * 8;
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) load(p_begin + (c + 1) * BKP);
+        const __bf16 *A = &lds[cur][0][(wm * 64) * LKB + foff];
+        const __bf16 *Bm = &lds[cur][1][(wn * 64) * LKB + foff];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const wg_bf16x8 a0 = *reinterpret_cast<const wg_bf16x8 *>(A + s * 16), a1 = *reinterpret_cast<const wg_bf16x8 *>(A + 32 * LKB + s * 16);
+            const wg_bf16x8 b0 = *reinterpret_cast<const wg_bf16x8 *>(Bm + s * 16), b1 = *reinterpret_cast<const wg_bf16x8 *>(Bm + 32 * LKB + s * 16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store(cur ^ 1);
+        __syncthreads();
+    }
+    float *out = d.workspace + (size_t)blockIdx.y * d.Cout * d.KH * d.KW * d.Cin;
+    const int taps = d.KH * d.KW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+            if (ci >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                if (co < d.Cout) out[((size_t)co * taps + tap) * d.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 int wgrad_check(const a3d_wgrad_desc *d) {
     if (!d || !d->x || !d->dy || !d->dw) return A3D_ERR_ARG;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cin <= 0 || d->Cout <= 0) return A3D_ERR_ARG;
@@ -149,10 +261,13 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     const int P = d->B * d->Ho * d->Wo;
     const int mtiles = (d->Cout + 127) / 128, ntiles = (d->Cin + 127) / 128;
     int chunk = (P + d->splitk - 1) / d->splitk;
-    chunk = (chunk + WG_BK - 1) / WG_BK * WG_BK;
+    chunk = (chunk + 31) / 32 * 32;  // a multiple of both kernels' k-chunk (16 / 32 pixels)
     a3d_begin();
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles,
-                       chunk);
+    if (d->precision == 1) {
+        if ((size_t)P * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
+    } else
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
     const size_t total4 = (size_t)d->Cout * d->KH * d->KW * d->Cin / 4;
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -105,6 +105,8 @@ class PlaneRCNN(nn.Module):
             det = BatchedDetections(gb, torch.ones(gb.shape[:2], device=gb.device), torch.zeros(gb.shape[:2], device=gb.device, dtype=torch.int32), gc, hw)
         # (measured: running the depth decoder on a second HIP stream beside the RPN / ROI branch gives no gain --
         # both branches are MFMA-bound, 521 frames/s either way -- so everything stays on one stream)
+        # the live-ROI total starts its trip to the host here and is waited for after the depth decoder has been enqueued
+        self.roi_heads.start_row_count(det)
         depth = self.depth_head.forward_nhwc(feats) if self.depth_head_on else None
         det = self.roi_heads.given_boxes_batched(feats, det)
         return self._post_batched(det, depth, hw, want_masks, proposals)

@@ -89,12 +89,27 @@ class PlaneRCNNROIHeads(nn.Module):
         boxes, scores, classes, _pos, count = self.box_predictor.inference_batched(pred, prop_boxes, prop_count, img_hw)
         return BatchedDetections(boxes, scores, classes, count, img_hw)
 
+    def start_row_count(self, det: BatchedDetections) -> BatchedDetections:
+        """Row offsets of the compacted per-ROI tensors + an ASYNCHRONOUS copy of the live-ROI total into pinned host memory.
+        The caller enqueues independent work (the depth decoder) before `given_boxes_batched` waits on the event, so the one
+        host read of the batch does not drain the GPU queue."""
+        R = det.boxes.shape[1]
+        det.row_offset = ops.count_offsets(det.count, R)
+        if getattr(self, "_total_pin", None) is None:
+            self._total_pin = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        self._total_pin.copy_(det.row_offset[-1:], non_blocking=True)
+        det._total_event = torch.cuda.Event()
+        det._total_event.record()
+        return det
+
     def given_boxes_batched(self, feats: Dict[str, torch.Tensor], det: BatchedDetections) -> BatchedDetections:
         """forward_with_given_boxes on fixed-size detections; one host read of the live-ROI total."""
         lv = [feats[f] for f in self.in_features]
-        R = det.boxes.shape[1]
-        det.row_offset = ops.count_offsets(det.count, R)
-        det.total = int(det.row_offset[-1].item())  # the one D2H sync of the batch
+        if getattr(det, "_total_event", None) is None:
+            self.start_row_count(det)
+        det._total_event.synchronize()  # waits for the count only, not for the work enqueued after it
+        det.total = int(self._total_pin[0])
+        det._total_event = None
         rows = det.total
         if rows == 0:
             return det

@@ -217,7 +217,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -249,13 +249,14 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
+    d.precision = int(precision)
     d.phase = int(p.phase)
     # Winograd F(2x2,3x3) for every 3x3 s1 p1 layer that has Winograd-domain weights.  The choice must not depend on the
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
     use_wino = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
-                and (wino if wino is not None else True))
+                and precision == 0 and (wino if wino is not None else True))
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()

@@ -19,7 +19,7 @@ def choose_wgrad_slices(P: int, tiles: int) -> int:
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int, pad: int,
-               scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None) -> torch.Tensor:
+               scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None, precision: int = 0) -> torch.Tensor:
     """dw [Cout, KH*KW*Cin] (=/+=) weight gradient of y = conv(x) given dy (NHWC tensors)."""
     _req(x), _req(dy), _req(dw)
     B, H, W, Cin = x.shape
@@ -32,6 +32,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * KH * KW
     d.splitk = int(splitk) if splitk else choose_wgrad_slices(B * Ho * Wo, tiles)
     d.accumulate = int(accumulate)
+    d.precision = int(precision)
     ws = torch.empty(_lib.lib().a3d_wgrad_workspace_bytes(C.byref(d)) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
     _lib.check(_lib.lib().a3d_conv_wgrad_nhwc_f32(C.byref(d), _stream()), "a3d_conv_wgrad_nhwc_f32")

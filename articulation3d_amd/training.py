@@ -19,7 +19,8 @@ Design (MI355X-first, no autograd engine):
     RNG: a3d_sample_labels / a3d_sample_rois), all per-image counts stay in device vectors and tensors have fixed shapes
     (dead slots are zero rows without loss or gradient): the step never waits for the host.  Parity tests read the drawn
     index sets back and hand them to the oracle.
-Precision: fp32 throughout (the reference config asks for bf16 autocast; fp32 >= that, bf16 kernels are future work).
+Precision: fp32 by default; `precision="bf16"` is the reference config's autocast arithmetic (bf16 MFMA, fp32 accumulation,
+fp32 tensors and master weights) on every trainable layer.
 """
 from __future__ import annotations
 
@@ -127,7 +128,12 @@ class DetectorTrainer:
     `model` is the product PlaneRCNN (its frozen stem / res2 modules are used as they are; everything trainable is
     copied into the flat buffer at construction and written back by `export_state_dict`)."""
 
-    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None):
+    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "fp32"):
+        """precision: "fp32" (fp32 MFMA everywhere) or "bf16" -- the reference's autocast setting: every trainable conv / linear
+        multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
+        weights, activations, gradients, losses and the optimiser stay fp32."""
+        assert precision in ("fp32", "bf16")
+        self.prec = 1 if precision == "bf16" else 0
         self.s = solver or SolverCfg()
         self.model = model
         self.dev = next(model.parameters()).device
@@ -271,12 +277,16 @@ class DetectorTrainer:
         """Per step: data-gradient filters (and the Winograd images of the 3x3 filters) of the CURRENT weights."""
         for ly in self.layers.values():
             T.weight_transpose(ly.w, ly.wt, ly.rows, ly.k, ly.k, ly.cin, scale=ly.scale)
-            if ly.k == 3:
+            if ly.k == 3 and self.prec == 0:  # (the bf16 step runs its 3x3 layers as direct convolutions)
                 T.wino_weight_transform(ly.w, ly.U, ly.rows, ly.cin)
                 T.wino_weight_transform(ly.wt, ly.Ut, ly.cin, ly.rows)
 
+    def _conv(self, x, pk, **kw):
+        """A trainable layer's forward / data-gradient launch in the step's precision."""
+        return ops.conv2d(x, pk, precision=self.prec, **kw)
+
     def _wgrad(self, ly: _Layer, x, dy, accumulate=False):
-        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate)
+        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate, precision=self.prec)
         if ly.db is not None:
             T.colsum(dy, ly.db, accumulate=accumulate)
 
@@ -298,27 +308,27 @@ class DetectorTrainer:
         for name, nblk, _mid, _cout in RES_STAGES:
             for i in range(nblk):
                 p = f"backbone.bottom_up.{name}.{i}."
-                sc = ops.conv2d(x, L[p + "shortcut"].fwd()) if i == 0 else x
-                a = ops.conv2d(x, L[p + "conv1"].fwd())
-                b = ops.conv2d(a, L[p + "conv2"].fwd())
-                out = ops.conv2d(b, L[p + "conv3"].fwd(), res=sc)
+                sc = self._conv(x, L[p + "shortcut"].fwd()) if i == 0 else x
+                a = self._conv(x, L[p + "conv1"].fwd())
+                b = self._conv(a, L[p + "conv2"].fwd())
+                out = self._conv(b, L[p + "conv3"].fwd(), res=sc)
                 saved[p] = (x, a, b)
                 relu_outputs += [a, b, out]
                 x = out
             res[name] = x
         # ---- FPN
         prev, feats = {}, {}
-        prev[5] = ops.conv2d(res["res5"], L["backbone.fpn_lateral5"].fwd())
-        feats["p5"] = ops.conv2d(prev[5], L["backbone.fpn_output5"].fwd())
+        prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd())
+        feats["p5"] = self._conv(prev[5], L["backbone.fpn_output5"].fwd())
         for l in (4, 3, 2):
-            prev[l] = ops.conv2d(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True)
-            feats[f"p{l}"] = ops.conv2d(prev[l], L[f"backbone.fpn_output{l}"].fwd())
+            prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True)
+            feats[f"p{l}"] = self._conv(prev[l], L[f"backbone.fpn_output{l}"].fwd())
         feats["p6"] = ops.subsample2(feats["p5"])
         names = ("p2", "p3", "p4", "p5", "p6")
         # ---- RPN head
         rp = "proposal_generator.rpn_head."
-        t = [ops.conv2d(feats[n], L[rp + "conv"].fwd()) for n in names]
-        heads = [ops.conv2d(ti, L[rp + "pred"].fwd()) for ti in t]
+        t = [self._conv(feats[n], L[rp + "conv"].fwd()) for n in names]
+        heads = [self._conv(ti, L[rp + "pred"].fwd()) for ti in t]
         feat_hw = [tuple(feats[n].shape[1:3]) for n in names]
         anchors = self._anchors(feat_hw)
         # ---- ground truth on the device (fixed-size, counts in a device vector: nothing below waits for the host)
@@ -374,9 +384,9 @@ class DetectorTrainer:
         pooled = ops.roi_align_fpn(pyr, scales, roi_boxes, rcount_d, 7, 0, True, zero=True)
         bh, bp = "roi_heads.box_head.", "roi_heads.box_predictor."
         xrow = pooled.view(M, 1, 1, 49 * 256)
-        h1 = ops.conv2d(xrow, L[bh + "fc1"].fwd())
-        h2 = ops.conv2d(h1, L[bh + "fc2"].fwd())
-        pred = ops.conv2d(h2, L[bp + "pred"].fwd())
+        h1 = self._conv(xrow, L[bh + "fc1"].fwd())
+        h2 = self._conv(h1, L[bh + "fc2"].fwd())
+        pred = self._conv(h2, L[bp + "pred"].fwd())
         box_l, dpred = T.box_loss(pred.view(M, 32), roi_cls.view(M), roi_boxes.view(M, 4), roi_gt.view(M, 4), num_classes=s.num_classes,
                                   weights=s.box_weights, count=rcount_d, rows_per_image=Rs)
         losses = {"loss_rpn_cls": rpn_l[0], "loss_rpn_loc": rpn_l[1], "loss_cls": box_l[0], "loss_box_reg": box_l[1]}
@@ -384,30 +394,30 @@ class DetectorTrainer:
         # ======================================== backward ========================================
         dpred = dpred.view(M, 1, 1, 32)
         self._wgrad(L[bp + "pred"], h2, dpred)
-        dh2 = ops.conv2d(dpred, L[bp + "pred"].bwd(), gate=h2)
+        dh2 = self._conv(dpred, L[bp + "pred"].bwd(), gate=h2)
         self._wgrad(L[bh + "fc2"], h1, dh2)
-        dh1 = ops.conv2d(dh2, L[bh + "fc2"].bwd(), gate=h1)
+        dh1 = self._conv(dh2, L[bh + "fc2"].bwd(), gate=h1)
         self._wgrad(L[bh + "fc1"], xrow, dh1)
-        dpooled = ops.conv2d(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
+        dpooled = self._conv(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
         dP = {n: torch.zeros_like(feats[n]) for n in ("p2", "p3", "p4", "p5")}
         T.roi_align_fpn_backward([dP[n] for n in ("p2", "p3", "p4", "p5")], scales, roi_boxes, dpooled.view(M, 7, 7, 256), P=7,
                                  sampling_ratio=0, aligned=True, count=rcount_d)
         # ---- RPN head backward (weights shared by the five levels: gradients accumulate in level order)
         for li, n in enumerate(names):
-            dt = ops.conv2d(dheads[li], L[rp + "pred"].bwd(), gate=t[li])
+            dt = self._conv(dheads[li], L[rp + "pred"].bwd(), gate=t[li])
             self._wgrad(L[rp + "pred"], t[li], dheads[li], accumulate=li > 0)
             self._wgrad(L[rp + "conv"], feats[n], dt, accumulate=li > 0)
             if n == "p6":
-                dp6 = ops.conv2d(dt, L[rp + "conv"].bwd(), wino=False)
+                dp6 = self._conv(dt, L[rp + "conv"].bwd(), wino=False)
                 T.zero_insert2(dp6, dP["p5"].shape[1], dP["p5"].shape[2], out=dP["p5"], accumulate=True)
             else:
-                ops.conv2d(dt, L[rp + "conv"].bwd(), res=dP[n], out=dP[n], wino=False)
+                self._conv(dt, L[rp + "conv"].bwd(), res=dP[n], out=dP[n], wino=False)
         # ---- FPN backward (finest level first: the top-down path carries gradient upwards)
         dprev = {}
         for l in (2, 3, 4, 5):
             lo = L[f"backbone.fpn_output{l}"]
             self._wgrad(lo, prev[l], dP[f"p{l}"])
-            dprev[l] = ops.conv2d(dP[f"p{l}"], lo.bwd())
+            dprev[l] = self._conv(dP[f"p{l}"], lo.bwd())
             if l > 2:
                 T.sumpool2_add(dprev[l - 1], dprev[l])
             self._wgrad(L[f"backbone.fpn_lateral{l}"], res[f"res{l}"], dprev[l])
@@ -415,25 +425,25 @@ class DetectorTrainer:
         dx_up = None  # gradient arriving at a stage output from the stage above (un-gated)
         for name, nblk, _mid, _cout in reversed(RES_STAGES):
             l = int(name[3:])
-            g = ops.conv2d(dprev[l], L[f"backbone.fpn_lateral{l}"].bwd(), res=dx_up, gate=res[name])
+            g = self._conv(dprev[l], L[f"backbone.fpn_lateral{l}"].bwd(), res=dx_up, gate=res[name])
             for i in reversed(range(nblk)):
                 p = f"backbone.bottom_up.{name}.{i}."
                 x_in, a, b = saved[p]
                 c1, c2, c3 = L[p + "conv1"], L[p + "conv2"], L[p + "conv3"]
                 self._wgrad(c3, b, g)
-                db_ = ops.conv2d(g, c3.bwd(), gate=b)
+                db_ = self._conv(g, c3.bwd(), gate=b)
                 self._wgrad(c2, a, db_)
-                da_ = ops.conv2d(db_, c2.bwd(), gate=a)
+                da_ = self._conv(db_, c2.bwd(), gate=a)
                 self._wgrad(c1, x_in, da_)
                 if i == 0:
                     self._wgrad(L[p + "shortcut"], x_in, g)
                     if name == "res3":
                         break  # res2 is frozen: nothing below needs a gradient
-                    low = ops.conv2d(g, L[p + "shortcut"].bwd())
-                    low = ops.conv2d(da_, c1.bwd(), res=low, out=low)
+                    low = self._conv(g, L[p + "shortcut"].bwd())
+                    low = self._conv(da_, c1.bwd(), res=low, out=low)
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
-                    g = ops.conv2d(da_, c1.bwd(), res=g, gate=x_in)
+                    g = self._conv(da_, c1.bwd(), res=g, gate=x_in)
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))

@@ -92,6 +92,10 @@ typedef struct a3d_conv_desc {
     const float *gate;   /* optional [B,Ho,Wo,Cout]: outputs are zeroed where gate <= 0 -- the ReLU backward of the
                             training step (section "Training step" below): y = dgrad(...) * (forward activation > 0).
                             Plain output layout only (no pixshuf / phase)                                     */
+    int precision;       /* 0: fp32 MFMA (the inference / parity path).  1: bf16 MFMA with fp32 accumulation -- both operands
+                            are rounded to bf16 (nearest-even) while they are staged in LDS, tensors stay fp32 in memory: the
+                            arithmetic of torch.autocast(bfloat16), which the reference's training config asks for
+                            (plain convolutions / linears only: no stem, ups, phase, pixshuf, concat, split-K)      */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -281,6 +285,7 @@ typedef struct a3d_wgrad_desc {
     int KH, KW, stride, pad;
     int splitk;         /* >= 1 pixel slices (summed in slice order: deterministic) */
     int accumulate;     /* 1: dw += (weights shared by several call sites, e.g. the RPN head over 5 levels) */
+    int precision;      /* 0: fp32 MFMA; 1: bf16 MFMA, fp32 accumulation (see a3d_conv_desc.precision)        */
 } a3d_wgrad_desc;
 size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
 int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);
