@@ -23,6 +23,11 @@ GROUP_CAP = 1024
 # (tile_config, algorithmic_flops, start_event, end_event).
 CONV_TIMING: Optional[list] = None
 
+# Arithmetic of conv2d() calls that do not ask for one: 0 = fp32 MFMA (the parity path, default), 1 = bf16 MFMA with fp32
+# accumulation on the layer kinds csrc/conv_bf16.hip covers (plain convolutions / linears); the rest stay fp32.  An opt-in
+# throughput mode for deployments that accept autocast-level error -- never used by the parity tests or the headline bench.
+DEFAULT_PRECISION = 0
+
 
 def conv_tile_config(p: "PackedConv", M: int, ups: bool = False, pw_ok: bool = True) -> str:
     """Mirror of the variant selection in csrc/conv_gemm_v2.hip:a3d_conv_launch_v2 (kernel template arguments
@@ -217,7 +222,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision: int = 0) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision: Optional[int] = None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -249,6 +254,9 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
+    if precision is None:  # module-level default, only where the bf16 kernel applies
+        bf16_ok = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
+        precision = DEFAULT_PRECISION if bf16_ok else 0
     d.precision = int(precision)
     d.phase = int(p.phase)
     # Winograd F(2x2,3x3) for every 3x3 s1 p1 layer that has Winograd-domain weights.  The choice must not depend on the
@@ -285,7 +293,10 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
         pw_ok = x2 is None and splitk == 1 and m_dev is None and tune in (0, 6)
-        CONV_TIMING.append((conv_tile_config(p, B * Ho * Wo, ups, pw_ok) + (" ups-phase" if p.phase else ""), fl, e0, e1, shape))
+        name = conv_tile_config(p, B * Ho * Wo, ups, pw_ok) + (" ups-phase" if p.phase else "")
+        if d.precision == 1:
+            name = "conv_bf16<%d> 128x%d bk32 (bf16 MFMA)" % ((1, 64) if (p.cols <= 64 or ((B * Ho * Wo + 127) // 128) * ((p.cols + 127) // 128) <= 1000) else (2, 128))
+        CONV_TIMING.append((name, fl, e0, e1, shape))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

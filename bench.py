@@ -83,6 +83,9 @@ def main():
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 (default; the parity path and the headline number) or bf16: opt-in autocast arithmetic (bf16 MFMA, fp32 "
+                         "accumulate) on the plain conv / linear layers -- reported with its own dtype, not comparable with the headline")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the bounded CPU-baseline sample (~10 s of host work)")
     args = ap.parse_args()
@@ -114,6 +117,8 @@ def main():
     from articulation3d_amd.utils.synthetic import synthetic_frames
 
     model, cfg = build_detector(args.score_thresh, dev)
+    if args.precision == "bf16":
+        ops.DEFAULT_PRECISION = 1
     B = args.batch
     # contiguous block of the synthetic clip per rank (temporal order is restored by rank order)
     frames_np = synthetic_frames(B, seed=2020 + rank)
@@ -197,7 +202,7 @@ def main():
         "metric": "frames/sec through PlaneRCNN detector at 480x640",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in, NOT the headline", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full PlaneRCNN detector (ResNet50-FPN + RPN + ROIAlign + box/mask/plane/axis heads "
                                "+ depth head + NMS + mask paste + plane-offset LSQ + record pack), fp32, random-init weights with "
                                "calibrated BN, synthetic 480x640 uint8 frames resident in HBM",

@@ -132,6 +132,28 @@ def test_persistent_pointwise_kernel(ops, Cin, Cout, res_mode):
         assert yg.data_ptr() == buf.data_ptr() and torch.equal(buf, y * (gate > 0))
 
 
+def test_opt_in_bf16_arithmetic_mode(ops, hip_model, oracle):
+    """ops.DEFAULT_PRECISION = 1 (bench.py --precision bf16): plain conv / linear layers on the bf16 MFMA.  Not a parity
+    mode -- the check is that it is wired through the whole detector and stays at autocast-level distance from fp32."""
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.5
+    frames = torch.from_numpy(oracle.synthetic_frames(2, seed=3)).cuda()
+    ref = model.inference_batched(frames)
+    ops.DEFAULT_PRECISION = 1
+    try:
+        out = model.inference_batched(frames)
+    finally:
+        ops.DEFAULT_PRECISION = 0
+    l2 = ((out.depth - ref.depth).norm() / ref.depth.norm()).item()
+    print("bf16 mode: depth relative L2 distance from fp32 %.4f, detections %s vs %s" % (l2, out.rec_count.tolist(), ref.rec_count.tolist()))
+    # random-init weights make the depth map a near-cancelling 576-term sum: bf16 rounding moves it by ~0.6 relative L2 here (measured);
+    # the assertion only pins that the mode is different from fp32, finite and of the same scale
+    assert 1e-4 < l2 < 1.0 and bool(torch.isfinite(out.depth).all())
+    assert (out.rec_count - ref.rec_count).abs().max().item() <= 8
+    again = model.inference_batched(frames)  # the switch is off again: fp32 results are reproduced bit for bit
+    assert torch.equal(again.depth, ref.depth) and torch.equal(again.records, ref.records)
+
+
 def test_stem_pool_resize_small_ops(ops):
     torch.manual_seed(3)
     x = torch.rand(2, 3, 96, 128) * 255 - 110
