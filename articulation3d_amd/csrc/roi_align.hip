@@ -292,19 +292,16 @@ __global__ __launch_bounds__(256) void roi_align_fpn_backward_kernel(const RoiBw
             for (int bin = wave; bin < a.P * a.P; bin += 4) {
                 const int ph = bin / a.P, pw = bin - ph * a.P;
                 const int ry0 = Y0[ph], ny = NY[ph], rx0 = X0[pw], nx = NX[pw];
-                for (int c4 = lane; c4 < C4; c4 += 64) {
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) / count;
+                // lane l owns channels l, l+64, ...: one atomic instruction covers 64 CONSECUTIVE floats (2 cache lines); with a
+                // float4 of channels per lane the four instructions of a cell each touched all 8 lines of the 1 KB vector
+                for (int c = lane; c < a.C; c += 64) {
+                    const float g = orow[(size_t)bin * a.C + c] / count;
                     for (int ky = 0; ky < ny; ++ky) {
                         const float wy = WY[ph][ky];
-                        float *frow = feat + ((size_t)(ry0 + ky) * W + rx0) * a.C + c4 * 4;
+                        float *frow = feat + ((size_t)(ry0 + ky) * W + rx0) * a.C + c;
                         for (int kx = 0; kx < nx; ++kx) {
                             const float w = wy * WX[pw][kx];
-                            if (w == 0.f) continue;
-                            float *dst = frow + (size_t)kx * a.C;
-                            unsafeAtomicAdd(dst + 0, w * g[0]);
-                            unsafeAtomicAdd(dst + 1, w * g[1]);
-                            unsafeAtomicAdd(dst + 2, w * g[2]);
-                            unsafeAtomicAdd(dst + 3, w * g[3]);
+                            if (w != 0.f) unsafeAtomicAdd(frow + (size_t)kx * a.C, w * g);
                         }
                     }
                 }
