@@ -186,6 +186,7 @@ SIGNATURES = {
     "a3d_resize_bilinear_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_conv3x3_to1_nhwc": (C.c_int, [fptr, fptr, C.c_float, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_group_buffers_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_rpn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3d_rpn_proposals": (C.c_int, [C.POINTER(RpnDesc), fptr]),
     "a3d_box_detections": (C.c_int, [C.POINTER(BoxDetDesc), fptr]),
     "a3d_group_nms": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_float, fptr]),

@@ -92,15 +92,17 @@ struct RpnSelectArgs {
     int *g_n;          // [B*L]
 };
 
+template <int CAP>
 __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a) {
-    __shared__ u64 sel[GROUP_CAP];
+    constexpr int CB = (CAP == 1024) ? 10 : 11;  // bits of a slot index inside a group
+    __shared__ u64 sel[CAP];
     __shared__ unsigned int hist[256];
     __shared__ u64 s_prefix;
     __shared__ int s_krem, s_cnt;
     const int l = blockIdx.x, b = blockIdx.y, g = b * a.L + l;
     const RpnLevel &lv = a.lv[l];
     const int n = lv.Hf * lv.Wf * a.A;
-    const int k = min(a.pre_topk, min(n, GROUP_CAP));
+    const int k = min(a.pre_topk, min(n, CAP));
     const float *head = lv.head + (size_t)b * lv.Hf * lv.Wf * a.CH;
     int nb = 8;
     while ((1 << nb) < n) nb += 8;
@@ -139,17 +141,17 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
         __syncthreads();
     }
     const u64 T = s_prefix;
-    for (int i = threadIdx.x; i < GROUP_CAP; i += blockDim.x) sel[i] = 0;
+    for (int i = threadIdx.x; i < CAP; i += blockDim.x) sel[i] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const u64 c = composite(i);
         if (c >= T) {
             const int slot = atomicAdd(&s_cnt, 1);
-            if (slot < GROUP_CAP) sel[slot] = c;
+            if (slot < CAP) sel[slot] = c;
         }
     }
-    bitonic_sort_desc(sel, GROUP_CAP);
-    for (int r = threadIdx.x; r < GROUP_CAP; r += blockDim.x) {
+    bitonic_sort_desc(sel, CAP);
+    for (int r = threadIdx.x; r < CAP; r += blockDim.x) {
         float box[4] = {0.f, 0.f, 0.f, 0.f};
         float score = 0.f;
         int valid = 0;
@@ -167,10 +169,10 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
             const bool nonempty = (box[2] - box[0]) > a.min_size && (box[3] - box[1]) > a.min_size;
             valid = (fin && isfinite(score) && nonempty) ? 1 : 0;
         }
-        const size_t o = (size_t)g * GROUP_CAP + r;
+        const size_t o = (size_t)g * CAP + r;
         *reinterpret_cast<f32x4 *>(a.g_boxes + o * 4) = f32x4{box[0], box[1], box[2], box[3]};
         a.g_scores[o] = score;
-        a.g_pos[o] = (l << 10) | r;
+        a.g_pos[o] = (l << CB) | r;
         a.g_valid[o] = valid;
     }
     if (threadIdx.x == 0) a.g_n[g] = k;
@@ -256,22 +258,27 @@ __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandArgs 
 // group_nms: grid (G), block 1024.  Boxes of a group are already score-descending.
 // LDS: 1024 x 16 suppression words (128 KiB) + boxes (16 KiB).
 // ------------------------------------------------------------------------------------------------
+// CAP = 1024: the suppression words live in LDS (128 KiB).  CAP = 2048 (training's PRE_NMS_TOPK 2000): 2048 x 32 words =
+// 512 KiB per group do not fit, they go to a global scratch area (`gmask`, L2-resident) -- same algorithm, same results.
+template <int CAP>
 __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                          const int *__restrict__ g_n, int *__restrict__ g_keep,
-                                                         float thr) {
-    __shared__ u64 mask[GROUP_CAP * 16];
-    __shared__ f32x4 sb[GROUP_CAP];
-    __shared__ unsigned char sv[GROUP_CAP];
+                                                         float thr, u64 *__restrict__ gmask) {
+    constexpr int W = CAP / 64;  // suppression words per row
+    __shared__ u64 smask[CAP == 1024 ? 1024 * 16 : 1];
+    __shared__ f32x4 sb[CAP];
+    __shared__ unsigned char sv[CAP];
     const int g = blockIdx.x;
-    const int n = min(g_n[g], GROUP_CAP);
-    for (int i = threadIdx.x; i < GROUP_CAP; i += blockDim.x) {
-        sb[i] = *reinterpret_cast<const f32x4 *>(g_boxes + ((size_t)g * GROUP_CAP + i) * 4);
-        sv[i] = (i < n) ? (unsigned char)g_valid[(size_t)g * GROUP_CAP + i] : 0;
+    u64 *mask = (CAP == 1024) ? smask : gmask + (size_t)g * CAP * W;
+    const int n = min(g_n[g], CAP);
+    for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+        sb[i] = *reinterpret_cast<const f32x4 *>(g_boxes + ((size_t)g * CAP + i) * 4);
+        sv[i] = (i < n) ? (unsigned char)g_valid[(size_t)g * CAP + i] : 0;
     }
     __syncthreads();
     const int nwords = (n + 63) >> 6;
-    for (int wd = threadIdx.x; wd < n * 16; wd += blockDim.x) {
-        const int i = wd >> 4, w = wd & 15;
+    for (int wd = threadIdx.x; wd < n * W; wd += blockDim.x) {
+        const int i = wd / W, w = wd % W;
         u64 bits = 0;
         if (w < nwords && (w << 6) + 63 > i && sv[i]) {
             const f32x4 bi = sb[i];
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
         mask[wd] = bits;
     }
     __syncthreads();
-    // Wavefront scan by wave 0: lane l < 16 carries removed-word l.  Per 64-box block: resolve the
+    // Wavefront scan by wave 0: lane l < W carries removed-word l.  Per 64-box block: resolve the
     // block with its diagonal words in registers (v_readlane chain), then OR the kept rows' words
     // into the carried state (4 row subsets x 16 words over the 64 lanes, xor-shuffle reduce).
     if (threadIdx.x < 64) {
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
         u64 R = 0;
         for (int wi = 0; wi < nwords; ++wi) {
             const int row = (wi << 6) + lane;
-            const u64 diag = (row < n) ? mask[row * 16 + wi] : 0;
+            const u64 diag = (row < n) ? mask[row * W + wi] : 0;
             const u64 validbits = __ballot(row < n && sv[row]);
             u64 cur = __shfl(R, wi, 64);  // removed bits of this block so far
             u64 kept = 0;
@@ -313,18 +320,18 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
                     cur |= d;
                 }
             }
-            if (row < GROUP_CAP) g_keep[(size_t)g * GROUP_CAP + row] = (int)((kept >> lane) & 1);
-            const int w = lane & 15, sub = lane >> 4;
+            if (row < CAP) g_keep[(size_t)g * CAP + row] = (int)((kept >> lane) & 1);
+            const int w = lane % W, sub = lane / W;  // 64 / W row subsets of W rows each
             u64 acc = 0;
-            for (int t = 0; t < 16; ++t) {
-                const int rr = sub * 16 + t;
-                if ((kept >> rr) & 1) acc |= mask[((wi << 6) + rr) * 16 + w];
+            for (int t = 0; t < W; ++t) {
+                const int rr = sub * W + t;
+                if ((kept >> rr) & 1) acc |= mask[((wi << 6) + rr) * W + w];
             }
-            acc |= __shfl_xor(acc, 16, 64);
-            acc |= __shfl_xor(acc, 32, 64);
-            R |= acc;  // lanes >= 16 carry copies; only lanes < 16 are read via __shfl(R, wi)
+#pragma unroll
+            for (int off = W; off < 64; off <<= 1) acc |= __shfl_xor(acc, off, 64);
+            R |= acc;  // lanes >= W carry copies; only lanes < W are read via __shfl(R, wi)
         }
-        for (int row = (nwords << 6) + lane; row < GROUP_CAP; row += 64) g_keep[(size_t)g * GROUP_CAP + row] = 0;
+        for (int row = (nwords << 6) + lane; row < CAP; row += 64) g_keep[(size_t)g * CAP + row] = 0;
     }
 }
 
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
 // merge_topk: grid (B), block 1024.  groups of image b: [b*NG, (b+1)*NG).
 // ------------------------------------------------------------------------------------------------
 #define MERGE_CAP 8192
+template <int CAP, int MCAP>
 __global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restrict__ g_boxes,
                                                           const float *__restrict__ g_scores,
                                                           const int *__restrict__ g_pos, const int *__restrict__ g_keep,
@@ -339,23 +347,24 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restric
                                                           float *__restrict__ out_boxes, float *__restrict__ out_scores,
                                                           int *__restrict__ out_cat, int *__restrict__ out_pos,
                                                           int *__restrict__ out_count) {
-    __shared__ u64 keys[MERGE_CAP];
-    __shared__ unsigned short ref[MERGE_CAP];
+    constexpr int CB = (CAP == 1024) ? 10 : 11;
+    __shared__ u64 keys[MCAP];
+    __shared__ unsigned short ref[MCAP == 8192 ? 8192 : 5 * CAP];  // indexed by position (group << CB | slot)
     __shared__ int s_cnt;
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < MERGE_CAP; i += blockDim.x) keys[i] = 0;
+    for (int i = threadIdx.x; i < MCAP; i += blockDim.x) keys[i] = 0;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     for (int gl = 0; gl < NG; ++gl) {
         const int g = b * NG + gl;
-        const int n = min(g_n[g], GROUP_CAP);
+        const int n = min(g_n[g], CAP);
         for (int r = threadIdx.x; r < n; r += blockDim.x) {
-            const size_t o = (size_t)g * GROUP_CAP + r;
+            const size_t o = (size_t)g * CAP + r;
             if (g_keep[o]) {
                 const int pos = g_pos[o];
                 const int slot = atomicAdd(&s_cnt, 1);
                 keys[slot] = ((u64)ordered_key(g_scores[o]) << 32) | (u64)(0xffffffffu - (uint32_t)pos);
-                ref[pos] = (unsigned short)((gl << 10) | r);
+                ref[pos] = (unsigned short)((gl << CB) | r);
             }
         }
     }
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restric
         if (i < cnt) {
             pos = (int)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffu));
             const int rf = ref[pos];
-            cat = rf >> 10;
-            const size_t o = (size_t)(b * NG + cat) * GROUP_CAP + (rf & 1023);
+            cat = rf >> CB;
+            const size_t o = (size_t)(b * NG + cat) * CAP + (rf & (CAP - 1));
             box = *reinterpret_cast<const f32x4 *>(g_boxes + o * 4);
             sc = g_scores[o];
         }
@@ -391,35 +400,48 @@ extern "C" size_t a3d_group_buffers_bytes(int n_groups) {
     return (size_t)n_groups * GROUP_CAP * 32 + (size_t)n_groups * 4 + 256;
 }
 
+// Workspace of a3d_rpn_proposals: group buffers with 1024 slots (pre_topk <= 1024) or 2048 slots plus the global
+// suppression words of the 2048-candidate NMS (training's PRE_NMS_TOPK_TRAIN 2000).
+extern "C" size_t a3d_rpn_workspace_bytes(int B, int L, int pre_topk) {
+    const size_t G = (size_t)B * L;
+    if (pre_topk <= GROUP_CAP) return a3d_group_buffers_bytes((int)G);
+    const size_t cap = 2048;
+    return G * cap * 32 + G * 4 + 256 + G * cap * (cap / 64) * sizeof(u64);
+}
+
 struct GroupBufs {
     float *boxes, *scores;
     int *pos, *valid, *keep, *n;
+    u64 *mask;
 };
-static GroupBufs carve(void *ws, int G) {
+static GroupBufs carve(void *ws, int G, int cap = GROUP_CAP) {
     GroupBufs gb;
     char *p = (char *)ws;
     gb.boxes = (float *)p;
-    p += (size_t)G * GROUP_CAP * 16;
+    p += (size_t)G * cap * 16;
     gb.scores = (float *)p;
-    p += (size_t)G * GROUP_CAP * 4;
+    p += (size_t)G * cap * 4;
     gb.pos = (int *)p;
-    p += (size_t)G * GROUP_CAP * 4;
+    p += (size_t)G * cap * 4;
     gb.valid = (int *)p;
-    p += (size_t)G * GROUP_CAP * 4;
+    p += (size_t)G * cap * 4;
     gb.keep = (int *)p;
-    p += (size_t)G * GROUP_CAP * 4;
+    p += (size_t)G * cap * 4;
     gb.n = (int *)p;
+    p += (size_t)G * 4 + 256;
+    gb.mask = (u64 *)(((uintptr_t)p + 7) & ~(uintptr_t)7);  // (only the 2048-slot form owns bytes here)
     return gb;
 }
 
 extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     if (!d || d->L < 1 || d->L > 5 || d->A != 3 || !d->workspace || !d->out_boxes || !d->out_scores || !d->out_count)
         return A3D_ERR_ARG;
-    if (d->pre_topk > GROUP_CAP || d->post_topk <= 0 || d->L * GROUP_CAP > MERGE_CAP) return A3D_ERR_UNSUPPORTED;
+    if (d->pre_topk > 2048 || d->post_topk <= 0 || d->L * GROUP_CAP > MERGE_CAP) return A3D_ERR_UNSUPPORTED;
     if (d->CH < 5 * d->A) return A3D_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int G = d->B * d->L;
-    GroupBufs gb = carve(d->workspace, G);
+    const int cap = d->pre_topk <= GROUP_CAP ? GROUP_CAP : 2048;  // workspace: a3d_rpn_workspace_bytes()
+    GroupBufs gb = carve(d->workspace, G, cap);
     RpnSelectArgs a;
     for (int l = 0; l < d->L; ++l) {
         a.lv[l].head = d->head[l];
@@ -448,10 +470,17 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     a.g_valid = gb.valid;
     a.g_n = gb.n;
     a3d_begin();
-    hipLaunchKernelGGL(rpn_select_kernel, dim3(d->L, d->B), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->L,
-                       d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
+    if (cap == GROUP_CAP) {
+        hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(d->L, d->B), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr);
+        hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
+                           d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
+    } else {
+        hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(d->L, d->B), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask);
+        hipLaunchKernelGGL((merge_topk_kernel<2048, 16384>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
+                           d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
+    }
     return a3d_check_launch();
 }
 
@@ -486,8 +515,8 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
     a.g_n = gb.n;
     a3d_begin();
     hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(group_nms_kernel, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh);
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
+    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr);
+    hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
                        d->topk, d->out_boxes, d->out_scores, d->out_classes, d->out_pos, d->out_count);
     return a3d_check_launch();
 }
@@ -497,7 +526,7 @@ extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int
                              float thresh, void *stream) {
     if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
     a3d_begin();
-    hipLaunchKernelGGL(group_nms_kernel, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
-                       g_keep, thresh);
+    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
+                       g_keep, thresh, nullptr);
     return a3d_check_launch();
 }

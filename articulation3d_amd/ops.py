@@ -427,7 +427,11 @@ def rpn_proposals(heads: Sequence[torch.Tensor], strides: Sequence[int], cell_an
     for j in range(4):
         d.weights[j] = float(weights[j])
     d.scale_clamp = float(scale_clamp)
-    ws = group_workspace(B * L, dev)
+    if pre_topk <= GROUP_CAP:
+        ws = group_workspace(B * L, dev)
+    else:  # training's 2000 candidates per level: 2048-slot groups + global NMS words
+        assert not return_groups, "group buffers are only exposed in the 1024-slot layout"
+        ws = torch.empty(_lib.lib().a3d_rpn_workspace_bytes(B, L, int(pre_topk)), device=dev, dtype=torch.uint8)
     boxes = torch.empty((B, post_topk, 4), device=dev, dtype=torch.float32)
     scores = torch.empty((B, post_topk), device=dev, dtype=torch.float32)
     level = torch.empty((B, post_topk), device=dev, dtype=torch.int32)

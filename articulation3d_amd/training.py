@@ -45,7 +45,7 @@ class SolverCfg:
     rpn_batch_per_image: int = 256
     rpn_positive_fraction: float = 0.5
     rpn_iou_thresholds: Tuple[float, float] = (0.3, 0.7)
-    rpn_pre_topk_train: int = 1000  # step1_bbox.yaml:21 asks 2000; the selection kernels hold <= 1024 candidates per level
+    rpn_pre_topk_train: int = 2000  # step1_bbox.yaml:21 (2048-slot selection groups, NMS words in global memory)
     rpn_post_topk_train: int = 1000
     rpn_nms_thresh: float = 0.7
     roi_batch_per_image: int = 512

@@ -143,6 +143,9 @@ typedef struct a3d_rpn_desc {
 } a3d_rpn_desc;
 
 size_t a3d_group_buffers_bytes(int n_groups);
+/* bytes of a3d_rpn_desc.workspace: pre_topk <= 1024 (inference) equals a3d_group_buffers_bytes(B*L); up to 2048 (the
+ * training configuration's PRE_NMS_TOPK_TRAIN 2000) adds the global suppression words of the 2048-candidate NMS. */
+size_t a3d_rpn_workspace_bytes(int B, int L, int pre_topk);
 int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ class TrainCfg:
     rpn_batch_per_image: int = 256  # MODEL.RPN.BATCH_SIZE_PER_IMAGE
     rpn_positive_fraction: float = 0.5  # MODEL.RPN.POSITIVE_FRACTION
     rpn_iou_thresholds: Tuple[float, float] = (0.3, 0.7)  # MODEL.RPN.IOU_THRESHOLDS, labels [0,-1,1]
-    rpn_pre_topk_train: int = 1000  # step1_bbox.yaml:21 says 2000; the HIP selection kernels hold <= 1024 per level
+    rpn_pre_topk_train: int = 2000  # step1_bbox.yaml:21
     rpn_post_topk_train: int = 1000  # step1_bbox.yaml:26
     roi_batch_per_image: int = 512  # MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE
     roi_positive_fraction: float = 0.25  # MODEL.ROI_HEADS.POSITIVE_FRACTION

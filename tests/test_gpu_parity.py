@@ -484,6 +484,35 @@ def staged_box(staged, hip_model, oracle, oracle_params):
     return dict(pooled=pooled, pred=pred, det=det, props_cpu=[pb[b, : int(pc[b])].cpu() for b in range(s["nf"])])
 
 
+def test_stage_proposals_with_2000_candidates_per_level(ops, staged, oracle):
+    """The training configuration's PRE_NMS_TOPK_TRAIN = 2000 (step1_bbox.yaml:21): 2048-slot selection groups, NMS with its
+    suppression words in global memory, 16 384-key merge.  Same discrete results as the oracle on identical head outputs:
+    count, level of every proposal, boxes to expf rounding, scores bit for bit."""
+    s, O = staged, oracle
+    nf = s["nf"]
+    heads = s["heads"]
+    rpn = None
+    ocfg = O.OracleCfg(**{**s["ocfg"].__dict__, "rpn_pre_topk": 2000, "rpn_post_topk": 1000})
+    gl_ = [h[..., :3].reshape(nf, -1).cpu() for h in heads]
+    gd_ = [h[..., 3:15].reshape(nf, -1, 4).cpu() for h in heads]
+    feat_hw = [tuple(s["feats"][k].shape[1:3]) for k in NAMES]
+    oprops = O.rpn_select(gl_, gd_, feat_hw, [HW] * nf, ocfg)
+    import math
+    cell = torch.stack([O.cell_anchors(z, ocfg.anchor_ratios) for z in ocfg.anchor_sizes])
+    pb, pl, plv, ppos, pc = ops.rpn_proposals(heads, [4, 8, 16, 32, 64], cell, HW, pre_topk=2000, post_topk=1000, nms_thresh=0.7, min_size=0.0,
+                                              weights=(1.0, 1.0, 1.0, 1.0), scale_clamp=math.log(1000.0 / 16))
+    for b in range(nf):
+        ob, osc = oprops[b]
+        n = int(pc[b])
+        assert n == len(ob)
+        assert torch.equal(pl[b, :n].cpu(), osc)
+        assert (pb[b, :n].cpu() - ob).abs().max().item() < 1e-3
+    # and the 1000-candidate setting still goes through the LDS-resident kernels with identical results
+    pb1, pl1, _, _, pc1 = ops.rpn_proposals(heads, [4, 8, 16, 32, 64], cell, HW, pre_topk=1000, post_topk=1000, nms_thresh=0.7, min_size=0.0,
+                                            weights=(1.0, 1.0, 1.0, 1.0), scale_clamp=math.log(1000.0 / 16))
+    assert torch.equal(pb1, s["props"][0]) and torch.equal(pc1, s["props"][4])
+
+
 def test_stage_box_head_and_detections(staged, staged_box, oracle, oracle_params):
     s, sb, O, P = staged, staged_box, oracle, oracle_params
     nf, ocfg = s["nf"], s["ocfg"]

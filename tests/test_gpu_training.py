@@ -5,6 +5,8 @@ whole step against the oracle's loss_and_grads on identical sampled index sets.
 Tolerances (fp32): gradients are long sums, compared by relative L2 error per tensor (<= 2e-4: the oracle's own fp32
 summation-order noise against float64 is ~1e-5..1e-4 on the deepest layers); matcher labels / indices bit-exact.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -432,10 +434,10 @@ def test_training_sgd_update_and_loss_decreases(trainer_and_ref, oracle, oracle_
         assert l2rel(p1[k], P[k]) < 1e-6, k
     # a few more steps on the same batch at a larger learning rate: the total loss goes down
     tr.s.warmup_iters = 0
-    tr.s.base_lr = 0.01
+    tr.s.base_lr = 0.002  # (0.01 without warm-up is occasionally unstable on this random-init net)
     fr = torch.from_numpy(frames).cuda()
     hist = []
-    for _ in range(6):
+    for _ in range(10):
         l, _ = tr.step(fr, [t[0] for t in tg], [t[1] for t in tg], samples=dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=aux["roi_idx"]))
         hist.append(sum(v.item() for v in l.values()))
     assert hist[-1] < hist[0], hist
@@ -515,8 +517,9 @@ def test_bf16_training_step_tracks_fp32(hip_model, oracle):
     t16 = DetectorTrainer(hip_model, seed=5, precision="bf16")
     l16, aux16 = t16.forward_backward(frames, gb, gc, samples=samples)
     g16 = {k: v.cpu() for k, v in t16.export_grads().items()}
-    for k in l32:
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):  # (the box losses see different proposals in the two runs: not comparable)
         assert abs(l16[k].item() - l32[k].item()) < 0.02 * abs(l32[k].item()) + 1e-3, (k, l16[k].item(), l32[k].item())
+    assert all(math.isfinite(v.item()) for v in l16.values())
     # The proposals of the two runs differ (different head outputs), so the given ROI index sets select different boxes:
     # only the RPN head's gradients (fixed anchors, identical sampled labels) are comparable tensor by tensor.
     rpn = [k for k in g32 if k.startswith("proposal_generator.rpn_head.")]
