@@ -263,7 +263,7 @@ __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandArgs 
 template <int CAP>
 __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                          const int *__restrict__ g_n, int *__restrict__ g_keep,
-                                                         float thr, u64 *__restrict__ gmask) {
+                                                         float thr, u64 *__restrict__ gmask, const int have_mask) {
     constexpr int W = CAP / 64;  // suppression words per row
     __shared__ u64 smask[CAP == 1024 ? 1024 * 16 : 1];
     __shared__ f32x4 sb[CAP];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
     }
     __syncthreads();
     const int nwords = (n + 63) >> 6;
-    for (int wd = threadIdx.x; wd < n * W; wd += blockDim.x) {
+    for (int wd = threadIdx.x; wd < (have_mask ? 0 : n * W); wd += blockDim.x) {  // (have_mask: nms_mask_kernel already filled it)
         const int i = wd / W, w = wd % W;
         u64 bits = 0;
         if (w < nwords && (w << 6) + 63 > i && sv[i]) {
@@ -332,6 +332,49 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
             R |= acc;  // lanes >= W carry copies; only lanes < W are read via __shfl(R, wi)
         }
         for (int row = (nwords << 6) + lane; row < CAP; row += 64) g_keep[(size_t)g * CAP + row] = 0;
+    }
+}
+
+// Suppression words of a 2048-slot group computed by 16 workgroups instead of one (the single-workgroup form spends
+// 2 ms per launch on the 2M IoUs of a full group while 246 CUs idle): grid (G, 16), block y owns rows [128y, 128y+128).
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
+                                                       const int *__restrict__ g_n, float thr, u64 *__restrict__ gmask) {
+    constexpr int CAP = 2048, W = 32, ROWS = 128;
+    __shared__ f32x4 sb[CAP];
+    __shared__ unsigned char sv[CAP];
+    const int g = blockIdx.x;
+    const int n = min(g_n[g], CAP);
+    const int r0 = blockIdx.y * ROWS;
+    if (r0 >= n) return;
+    for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+        sb[i] = *reinterpret_cast<const f32x4 *>(g_boxes + ((size_t)g * CAP + i) * 4);
+        sv[i] = (i < n) ? (unsigned char)g_valid[(size_t)g * CAP + i] : 0;
+    }
+    __syncthreads();
+    const int nwords = (n + 63) >> 6;
+    u64 *mask = gmask + (size_t)g * CAP * W;
+    for (int wd = threadIdx.x; wd < ROWS * W; wd += blockDim.x) {
+        const int i = r0 + wd / W, w = wd % W;
+        if (i >= n) continue;
+        u64 bits = 0;
+        if (w < nwords && (w << 6) + 63 > i && sv[i]) {
+            const f32x4 bi = sb[i];
+            const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+            const int j0 = w << 6;
+            for (int t = 0; t < 64; ++t) {
+                const int j = j0 + t;
+                if (j <= i || j >= n || !sv[j]) continue;
+                const f32x4 bj = sb[j];
+                const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+                const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                const float inter = iw * ih;
+                const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+                const float ovr = inter / (ai + aj - inter);
+                if (ovr > thr) bits |= (u64)1 << t;
+            }
+        }
+        mask[(size_t)i * W + w] = bits;
     }
 }
 
@@ -472,12 +515,13 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     a3d_begin();
     if (cap == GROUP_CAP) {
         hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(d->L, d->B), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr);
+        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0);
         hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     } else {
         hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(d->L, d->B), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(G, 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
+        hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask, 1);
         hipLaunchKernelGGL((merge_topk_kernel<2048, 16384>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     }
@@ -515,7 +559,7 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
     a.g_n = gb.n;
     a3d_begin();
     hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr);
+    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0);
     hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
                        d->topk, d->out_boxes, d->out_scores, d->out_classes, d->out_pos, d->out_count);
     return a3d_check_launch();
@@ -527,6 +571,6 @@ extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int
     if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
     a3d_begin();
     hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
-                       g_keep, thresh, nullptr);
+                       g_keep, thresh, nullptr, 0);
     return a3d_check_launch();
 }
