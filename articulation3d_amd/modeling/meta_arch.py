@@ -107,8 +107,26 @@ class PlaneRCNN(nn.Module):
         # both branches are MFMA-bound, 521 frames/s either way -- so everything stays on one stream)
         # the live-ROI total starts its trip to the host here and is waited for after the depth decoder has been enqueued
         self.roi_heads.start_row_count(det)
-        depth = self.depth_head.forward_nhwc(feats) if self.depth_head_on else None
-        det = self.roi_heads.given_boxes_batched(feats, det)
+        if self.depth_head_on and B <= self.small_batch_overlap and frames.is_cuda:
+            # Small batches leave most of the 256 CUs idle (a 30x40 level is 10 tiles): the depth decoder runs on a second HIP
+            # stream beside the ROI branch: +14% frames/s at 1-4 frames, +8% at 8, +4% at 16.  At 64 frames it is +1.7% and is
+            # left off so that the per-kernel durations of the headline run are those of kernels running alone.
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ready)
+                depth = self.depth_head.forward_nhwc(feats)
+                done = torch.cuda.Event()
+                done.record(self._side_stream)
+            det = self.roi_heads.given_boxes_batched(feats, det)
+            main.wait_event(done)
+            depth.record_stream(main)
+        else:
+            depth = self.depth_head.forward_nhwc(feats) if self.depth_head_on else None
+            det = self.roi_heads.given_boxes_batched(feats, det)
         return self._post_batched(det, depth, hw, want_masks, proposals)
 
     def _post_batched(self, det: BatchedDetections, depth, hw, want_masks, proposals) -> BatchedOutput:
@@ -136,6 +154,7 @@ class PlaneRCNN(nn.Module):
             return self.inference(batched_inputs)
         raise NotImplementedError("training forward (losses) is outside the inference hot path (SURVEY.md 8f-1)")
 
+    small_batch_overlap = 16  # batches up to this size run the depth decoder on a second HIP stream (0 disables)
     fast_reference_path = True  # route uniform batches of the reference-signature call through inference_batched
 
     def _fast_path_ok(self, batched_inputs, do_postprocess) -> bool:
