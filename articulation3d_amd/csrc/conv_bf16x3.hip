@@ -1,0 +1,259 @@
+// fp32-grade convolution / linear kernel on the bf16 matrix pipe (a3d_conv_desc.precision == 2, "bf16x3").
+//
+// The fp32 MFMA of gfx950 peaks at 157 TFLOP/s, the bf16 MFMA at 2.5 PFLOP/s.  An fp32 number is EXACTLY the sum of
+// three bf16 numbers (x = hi + mid + lo: each split rounds to nearest even and the sign carries one bit, so 3 x 8
+// significand bits cover the 24 of fp32), and a bf16 x bf16 product is exact in fp32.  So
+//     a*b = hi_a*hi_b + hi_a*mid_b + mid_a*hi_b + mid_a*mid_b + hi_a*lo_b + lo_a*hi_b   (+ terms <= 2^-24 |a*b|)
+// -- six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to the rounding level of a single fp32 multiply
+// (the dropped terms mid*lo, lo*mid, lo*lo are <= 2^-24 relative, the size of the rounding of one fp32 FMA), at
+// 16/6 = 2.67x the matrix rate of the fp32 MFMA.  Tensors stay fp32 in HBM; the split happens while a chunk is staged
+// into LDS (v_cvt_pk_bf16_f32 + subtract, ~22 VALU ops per float4, behind the other waves' MFMAs).
+// tools/x3_bench.py measures rate and error against float64 next to the native fp32 kernels.
+//
+// Decomposition: output tile 128 pixels x (64*TN) channels, 4 waves as 2x2, wave tile 64 x (32*TN); weights are MFMA
+// operand A and activations operand B (a lane owns one output pixel, register quads are 4 consecutive channels).
+// k chunks of 16 (= one v_mfma_f32_32x32x16_bf16 step): per chunk 3+3 operand planes in LDS ([plane][row][16 k],
+// 48-byte row pitch: a fragment is ONE ds_read_b128 and 16 rows tile the 64 banks exactly once), double-buffered,
+// one barrier per chunk; 6 x TN x 2 MFMAs per wave per chunk against (TN + 2) x 3 fragment reads.
+#include "conv_common.h"
+
+namespace {
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 x3_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+// x = h + m + l exactly (round-to-nearest-even at each level)
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    constexpr int TM = 2, BKT = 16;
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    constexpr int LKB = BKT;                       // bf16 elements per LDS row (32 bytes, no padding: the two 16-B halves of
+                                                   // a row are XOR-swizzled with bit 3 of the row index instead)
+    constexpr int TPR = BKT / 4, RPP = 256 / TPR;  // 4 lanes x float4 per row, 64 rows per loader pass
+    constexpr int XR = BM / RPP, WR = BN / RPP;
+    constexpr int PX = BM * LKB, PW = BN * LKB;    // one operand plane
+    constexpr int BUF = 3 * (PX + PW);
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = d.Kpad / BKT;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    // LDS image: [plane][row][16 k] bf16, 32-byte rows; the 16-byte half holding k = 8h..8h+7 of row r sits at slot
+    // h ^ ((r >> 3) & 1).  ds_read_b128 (64-bank rule, 16-lane groups of rows {0-3,12-15,20-27} / ...) and ds_write_b64
+    // (32-bank rule, 16 contiguous lanes = 4 rows) are both conflict-free with it; a padded 48-byte pitch made the
+    // writes 2-way conflicted (SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles).
+    const int lcs = (lc & 7) | ((((lc >> 3) ^ (lr >> 3)) & 1) << 3);
+    const int cs4 = d.Cin * 4;
+    const __amdgpu_buffer_rsrc_t rx = x3_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const __amdgpu_buffer_rsrc_t rw = x3_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
+
+    int rowoff[XR];
+    unsigned vmask[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = m0 + lr + RPP * i;
+        const bool rok = m < M;
+        const int mm = rok ? m : 0;
+        const int hw = d.Ho * d.Wo;
+        const int b = mm / hw, r = mm - b * hw;
+        const int oh = r / d.Wo, ow = r - oh * d.Wo;
+        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        unsigned mask = 0;
+        for (int kh = 0; kh < d.KH; ++kh)
+            for (int kw = 0; kw < d.KW; ++kw)
+                mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
+        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        vmask[i] = mask;
+    }
+    int woff[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int n = n0 + lr + RPP * i;
+        woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
+    }
+    int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next chunk to load inside the filter
+    // Two register staging sets: the loads of chunk c are issued at iteration c-3, split into LDS at iteration c-1 and
+    // multiplied at iteration c, so a buffer load has two full iterations (2 x 6*TN*2 MFMAs per wave) to land.
+    f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
+    auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
+        const int tap = kh * d.KW + kw;
+        const unsigned livebit = (kc < nk) ? 1u : 0u;
+        const int tapoff = (kh * d.W + kw) * cs4 + c0 * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = x3_load4(rx, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+        const int soff = kc * (BKT * 4);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+        ++kc;
+        c0 += BKT;
+        if (c0 >= d.Cin) {
+            c0 = 0;
+            if (++kw == d.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[WR]) {  // fp32 -> hi | mid | lo planes on the way into LDS
+        __bf16 *X = lds + buf * BUF;
+        __bf16 *Wt = X + 3 * PX;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            bf16x4 h, m, l;
+            split3(xs[i], h, m, l);
+            __bf16 *p = X + (lr + RPP * i) * LKB + lcs;
+            *reinterpret_cast<bf16x4 *>(p) = h;
+            *reinterpret_cast<bf16x4 *>(p + PX) = m;
+            *reinterpret_cast<bf16x4 *>(p + 2 * PX) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            bf16x4 h, m, l;
+            split3(ws[i], h, m, l);
+            __bf16 *p = Wt + (lr + RPP * i) * LKB + lcs;
+            *reinterpret_cast<bf16x4 *>(p) = h;
+            *reinterpret_cast<bf16x4 *>(p + PW) = m;
+            *reinterpret_cast<bf16x4 *>(p + 2 * PW) = l;
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    a3d_stage_scale_shift(ss, d, n0, BN, tid);
+    load_chunk(xsA, wsA);  // chunk 0
+    store_chunk(0, xsA, wsA);
+    load_chunk(xsB, wsB);  // chunk 1
+    load_chunk(xsA, wsA);  // chunk 2
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int frag_off = frow * LKB + ((((lane >> 5) ^ (frow >> 3)) & 1) << 3);  // row = lane % 32, k = 8 * (lane / 32) .. + 7
+    // [hi | mid | lo] fragments: set 0 holds the chunk being multiplied in even iterations, set 1 in odd ones; the other
+    // set is filled (behind the second half of the MFMAs) with the next chunk.
+    bf16x8 fa0[3][TN], fb0[3][TM], fa1[3][TN], fb1[3][TM];
+    auto read_frags = [&](int buf, bf16x8 (&fa)[3][TN], bf16x8 (&fb)[3][TM]) {
+        const __bf16 *X = lds + buf * BUF + (wm * TM * 32) * LKB + frag_off;
+        const __bf16 *Wt = lds + buf * BUF + 3 * PX + (wn * TN * 32) * LKB + frag_off;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) fa[p][ni] = *reinterpret_cast<const bf16x8 *>(Wt + p * PW + ni * 32 * LKB);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) fb[p][mi] = *reinterpret_cast<const bf16x8 *>(X + p * PX + mi * 32 * LKB);
+        }
+    };
+    read_frags(0, fa0, fb0);
+#define X3_TERM(PA, PB)                                                                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) acc[ni][mi] =  \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][ni], fb[PB][mi], acc[ni][mi], 0, 0, 0);
+    // One chunk.  A wave issues in order and an MFMA holds the matrix pipe for 8 passes, so everything else is placed in
+    // the MFMAs' shadows: first half = 3 product terms + the split of the staged chunk it+1 into LDS[cur^1]; ONE barrier;
+    // second half = 3 terms + the fragment reads of chunk it+1 + the buffer loads of chunk it+3.  (With the reads behind
+    // the barrier and outside the MFMA stream, the two co-resident workgroups fall into lockstep and the pipe idles
+    // during both their read phases: 58 % MFMA-busy measured.)
+    auto step = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR], bf16x8 (&fa)[3][TN], bf16x8 (&fb)[3][TM],
+                    bf16x8 (&fan)[3][TN], bf16x8 (&fbn)[3][TM]) {
+        X3_TERM(0, 0)
+        X3_TERM(0, 1)
+        X3_TERM(1, 0)
+        store_chunk(cur ^ 1, xs, ws);
+#pragma unroll
+        for (int g = 0; g < 3 * TN * TM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // <= 8 VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // <= 1 LDS write
+        }
+        __syncthreads();
+        X3_TERM(1, 1)
+        X3_TERM(2, 0)
+        X3_TERM(0, 2)
+        read_frags(cur ^ 1, fan, fbn);
+        load_chunk(xs, ws);
+#pragma unroll
+        for (int g = 0; g < 3 * TN * TM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);  // <= 1 LDS read
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // <= 1 buffer load
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);  // <= 3 VALU (addresses)
+        }
+    };
+    for (int it = 0; it < nk; it += 2) {  // (an odd chunk count multiplies one all-zero chunk: loads past nk read as 0)
+        step(0, xsB, wsB, fa0, fb0, fa1, fb1);
+        step(1, xsA, wsA, fa1, fb1, fa0, fb0);
+    }
+#undef X3_TERM
+
+    const bool has_res = d.res != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
+        if (m >= M) continue;
+        size_t res_row;
+        int b, oh, ow;
+        out_rows(d, m, res_row, b, oh, ow);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            f32x4 rv[4];
+            if (has_res) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    rv[rg] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + min(n, d.Cout - 4));
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
+                if (n >= d.Cout) continue;
+                f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                store_out(d, v, m, n, b, oh, ow);
+            }
+        }
+    }
+}
+
+template <int TN>
+void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
+    constexpr int BM = 128, BN = 64 * TN;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_x3_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+}
+}  // namespace
+
+int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * d->Cin || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
+    const int M = d->B * d->Ho * d->Wo;
+    const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (d->Cout <= 64 || n128 <= 500) launch_x3<1>(d, s);
+    else launch_x3<2>(d, s);
+    return a3d_check_launch();
+}

@@ -105,6 +105,8 @@ int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
 
 // bf16-MFMA variant (conv_bf16.hip), selected by a3d_conv_desc.precision == 1.
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s);
+// fp32-grade 3-way bf16 split on the bf16 matrix pipe (conv_bf16x3.hip), selected by a3d_conv_desc.precision == 2.
+int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip).  eligible() ignores the workspace pointer (used for sizing).
 int a3d_wino_eligible(const a3d_conv_desc *d);

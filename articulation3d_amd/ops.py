@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -26,7 +27,11 @@ CONV_TIMING: Optional[list] = None
 # Arithmetic of conv2d() calls that do not ask for one: 0 = fp32 MFMA (the parity path, default), 1 = bf16 MFMA with fp32
 # accumulation on the layer kinds csrc/conv_bf16.hip covers (plain convolutions / linears); the rest stay fp32.  An opt-in
 # throughput mode for deployments that accept autocast-level error -- never used by the parity tests or the headline bench.
-DEFAULT_PRECISION = 0
+# 2 = "bf16x3": fp32-grade arithmetic on the bf16 matrix pipe (csrc/conv_bf16x3.hip: every fp32 operand split exactly into
+# three bf16 terms, six MFMAs per k step, fp32 accumulate; measured error against float64 is slightly BELOW the fp32
+# MFMA's, tools/x3_bench.py) on the plain non-Winograd layers (1x1 convs, linears, strided 3x3); the Winograd layers keep
+# the fp32 MFMA.  Opt-in as well (A3D_PRECISION=2 / bench.py --precision bf16x3); the whole fp32 parity suite passes under it.
+DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "0"))
 
 
 def conv_tile_config(p: "PackedConv", M: int, ups: bool = False, pw_ok: bool = True) -> str:
@@ -254,17 +259,23 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
-    if precision is None:  # module-level default, only where the bf16 kernel applies
-        bf16_ok = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
-        precision = DEFAULT_PRECISION if bf16_ok else 0
+    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
+               and (wino if wino is not None else True))
+    if precision is None:  # module-level default, only where the bf16 kernels apply
+        plain = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
+        if DEFAULT_PRECISION == 1:
+            precision = 1 if plain and p.Cin % 32 == 0 else 0
+        elif DEFAULT_PRECISION == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
+            precision = 2 if plain and p.Cin % 16 == 0 and not wino_ok and tune == 0 else 0
+        else:
+            precision = 0
     d.precision = int(precision)
     d.phase = int(p.phase)
     # Winograd F(2x2,3x3) for every 3x3 s1 p1 layer that has Winograd-domain weights.  The choice must not depend on the
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
-    use_wino = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
-                and precision == 0 and (wino if wino is not None else True))
+    use_wino = wino_ok and precision == 0
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()
@@ -294,6 +305,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
         pw_ok = x2 is None and splitk == 1 and m_dev is None and tune in (0, 6)
         name = conv_tile_config(p, B * Ho * Wo, ups, pw_ok) + (" ups-phase" if p.phase else "")
+        if d.precision == 2:
+            name = "conv_x3<%d> 128x%d bk16 (3-way bf16 split, 6 MFMAs per k step)" % ((1, 64) if (p.cols <= 64 or ((B * Ho * Wo + 127) // 128) * ((p.cols + 127) // 128) <= 500) else (2, 128))
         if d.precision == 1:
             name = "conv_bf16<%d> 128x%d bk32 (bf16 MFMA)" % ((1, 64) if (p.cols <= 64 or ((B * Ho * Wo + 127) // 128) * ((p.cols + 127) // 128) <= 1000) else (2, 128))
         CONV_TIMING.append((name, fl, e0, e1, shape))

@@ -83,7 +83,7 @@ def main():
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 (default; the parity path and the headline number) or bf16: opt-in autocast arithmetic (bf16 MFMA, fp32 "
                          "accumulate) on the plain conv / linear layers -- reported with its own dtype, not comparable with the headline")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
@@ -119,6 +119,8 @@ def main():
     model, cfg = build_detector(args.score_thresh, dev)
     if args.precision == "bf16":
         ops.DEFAULT_PRECISION = 1
+    elif args.precision == "bf16x3":  # fp32-grade arithmetic on the bf16 pipe for the non-Winograd layers (csrc/conv_bf16x3.hip)
+        ops.DEFAULT_PRECISION = 2
     B = args.batch
     # contiguous block of the synthetic clip per rank (temporal order is restored by rank order)
     frames_np = synthetic_frames(B, seed=2020 + rank)
@@ -202,7 +204,9 @@ def main():
         "metric": "frames/sec through PlaneRCNN detector at 480x640",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in, NOT the headline", "data": "synthetic",
+        "dtype": {"fp32": "f32", "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in, NOT the headline",
+                  "bf16x3": "f32 via exact 3-way bf16 operand split on the bf16 MFMA (fp32-grade error, fp32 tensors / accumulate) on the "
+                            "non-Winograd layers -- opt-in, NOT the headline"}[args.precision], "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full PlaneRCNN detector (ResNet50-FPN + RPN + ROIAlign + box/mask/plane/axis heads "
                                "+ depth head + NMS + mask paste + plane-offset LSQ + record pack), fp32, random-init weights with "
                                "calibrated BN, synthetic 480x640 uint8 frames resident in HBM",

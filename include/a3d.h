@@ -95,7 +95,10 @@ typedef struct a3d_conv_desc {
     int precision;       /* 0: fp32 MFMA (the inference / parity path).  1: bf16 MFMA with fp32 accumulation -- both operands
                             are rounded to bf16 (nearest-even) while they are staged in LDS, tensors stay fp32 in memory: the
                             arithmetic of torch.autocast(bfloat16), which the reference's training config asks for
-                            (plain convolutions / linears only: no stem, ups, phase, pixshuf, concat, split-K)      */
+                            (plain convolutions / linears only: no stem, ups, phase, pixshuf, concat, split-K).
+                            2: fp32-grade on the bf16 pipe -- each fp32 operand is split EXACTLY into three bf16 terms in LDS and
+                            six bf16 MFMAs per k step reproduce the fp32 product to 2^-24 relative (csrc/conv_bf16x3.hip);
+                            same layer kinds as 1, Cin % 16 == 0.  Opt-in: the default everywhere is 0           */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);

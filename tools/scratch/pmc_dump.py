@@ -1,0 +1,10 @@
+import csv, glob, sys, collections
+for d in sys.argv[1:]:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:60]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, v in acc.items():
+        if "x3" in k or "bf16" in k or "conv" in k:
+            print(d, k, {a: f"{b:.4g}" for a, b in v.items()})
