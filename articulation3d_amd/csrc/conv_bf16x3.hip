@@ -7,7 +7,9 @@
 // -- six bf16 MFMAs with fp32 accumulation reproduce the fp32 product to the rounding level of a single fp32 multiply
 // (the dropped terms mid*lo, lo*mid, lo*lo are <= 2^-24 relative, the size of the rounding of one fp32 FMA), at
 // 16/6 = 2.67x the matrix rate of the fp32 MFMA.  Tensors stay fp32 in HBM; the split happens while a chunk is staged
-// into LDS (v_cvt_pk_bf16_f32 + subtract, ~22 VALU ops per float4, behind the other waves' MFMAs).
+// into LDS (v_cvt_pk_bf16_f32 + subtract, ~22 VALU ops per float4, in the MFMAs' shadows).  Measured and rejected:
+// weights pre-split once per layer into bf16 planes in HBM (halves the VALU work, same rate -- the loop is bound by the
+// clock the chip holds under bf16 MFMA load, 1.5-1.7 GHz here, and by ~65 % matrix-pipe occupancy, not by the VALU).
 // tools/x3_bench.py measures rate and error against float64 next to the native fp32 kernels.
 //
 // Decomposition: output tile 128 pixels x (64*TN) channels, 4 waves as 2x2, wave tile 64 x (32*TN); weights are MFMA
@@ -62,7 +64,9 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // writes 2-way conflicted (SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles).
     const int lcs = (lc & 7) | ((((lc >> 3) ^ (lr >> 3)) & 1) << 3);
     const int cs4 = d.Cin * 4;
+    const int CinT = d.Cin + d.Cin2;  // (a second source has the same channel count: checked by the launcher)
     const __amdgpu_buffer_rsrc_t rx = x3_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const __amdgpu_buffer_rsrc_t rx2 = x3_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rw = x3_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
 
     int rowoff[XR];
@@ -75,7 +79,11 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
         const int hw = d.Ho * d.Wo;
         const int b = mm / hw, r = mm - b * hw;
         const int oh = r / d.Wo, ow = r - oh * d.Wo;
-        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        if (d.phase) {  // 2x2 taps of output phase (dy,dx) of an upsampled 3x3 conv, on the source grid (conv_gemm_v2.hip)
+            ih0 = oh - 1 + ((d.phase - 1) >> 1);
+            iw0 = ow - 1 + ((d.phase - 1) & 1);
+        }
         unsigned mask = 0;
         for (int kh = 0; kh < d.KH; ++kh)
             for (int kw = 0; kw < d.KW; ++kw)
@@ -96,15 +104,17 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         const int tap = kh * d.KW + kw;
         const unsigned livebit = (kc < nk) ? 1u : 0u;
-        const int tapoff = (kh * d.W + kw) * cs4 + c0 * 4;
+        const bool second = c0 >= d.Cin;  // channel concat: the second source supplies channels Cin .. Cin+Cin2-1 of every tap
+        const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
+        const int tapoff = (kh * d.W + kw) * cs4 + (second ? c0 - d.Cin : c0) * 4;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) xs[i] = x3_load4(rx, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+        for (int i = 0; i < XR; ++i) xs[i] = x3_load4(r, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
         const int soff = kc * (BKT * 4);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
         ++kc;
         c0 += BKT;
-        if (c0 >= d.Cin) {
+        if (c0 >= CinT) {
             c0 = 0;
             if (++kw == d.KW) {
                 kw = 0;
@@ -248,8 +258,10 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
 }  // namespace
 
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
-    if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
-    if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * d->Cin || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
+    if (d->stem || d->ups || d->pixshuf || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->phase && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->res)) return A3D_ERR_UNSUPPORTED;
+    if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_UNSUPPORTED;
+    if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * (d->Cin + d->Cin2) || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
     const int M = d->B * d->Ho * d->Wo;
     const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);

@@ -266,7 +266,10 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         if DEFAULT_PRECISION == 1:
             precision = 1 if plain and p.Cin % 32 == 0 else 0
         elif DEFAULT_PRECISION == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
-            precision = 2 if plain and p.Cin % 16 == 0 and not wino_ok and tune == 0 else 0
+            # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
+            x3_ok = (not (p.stem or ups or p.pixshuf or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
+                     and (x2 is None or Cin2 == Cin) and Cin % 16 == 0 and not (p.phase and res is not None))
+            precision = 2 if x3_ok and not wino_ok and tune == 0 else 0
         else:
             precision = 0
     d.precision = int(precision)

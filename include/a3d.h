@@ -98,7 +98,8 @@ typedef struct a3d_conv_desc {
                             (plain convolutions / linears only: no stem, ups, phase, pixshuf, concat, split-K).
                             2: fp32-grade on the bf16 pipe -- each fp32 operand is split EXACTLY into three bf16 terms in LDS and
                             six bf16 MFMAs per k step reproduce the fp32 product to 2^-24 relative (csrc/conv_bf16x3.hip);
-                            same layer kinds as 1, Cin % 16 == 0.  Opt-in: the default everywhere is 0           */
+                            same layer kinds as 1 plus the phase convs and their equal-width 2-source concat, Cin % 16 == 0.
+                            Opt-in: the default everywhere is 0                                                  */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
