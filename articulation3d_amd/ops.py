@@ -227,7 +227,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision: Optional[int] = None) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
     _req(x)
     B, H, W, Cin = x.shape
@@ -261,11 +261,12 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     d.tune = int(tune)
     wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
                and (wino if wino is not None else True))
-    if precision is None:  # module-level default, only where the bf16 kernels apply
+    if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
+        mode = DEFAULT_PRECISION if precision is None else 2
         plain = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
-        if DEFAULT_PRECISION == 1:
+        if mode == 1:
             precision = 1 if plain and p.Cin % 32 == 0 else 0
-        elif DEFAULT_PRECISION == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
+        elif mode == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
             # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
             x3_ok = (not (p.stem or ups or p.pixshuf or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
                      and (x2 is None or Cin2 == Cin) and Cin % 16 == 0 and not (p.phase and res is not None))

@@ -132,8 +132,11 @@ class DetectorTrainer:
         """precision: "fp32" (fp32 MFMA everywhere) or "bf16" -- the reference's autocast setting: every trainable conv / linear
         multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
         weights, activations, gradients, losses and the optimiser stay fp32."""
-        assert precision in ("fp32", "bf16")
-        self.prec = 1 if precision == "bf16" else 0
+        assert precision in ("fp32", "bf16", "bf16x3")
+        # "bf16x3": fp32-grade arithmetic on the bf16 pipe (csrc/conv_bf16x3.hip) for the forward / data-gradient launches of the
+        # non-Winograd layers; Winograd layers and the weight-gradient kernel stay on the fp32 MFMA
+        self.prec = {"fp32": 0, "bf16": 1, "bf16x3": "bf16x3"}[precision]
+        self.wgrad_prec = 1 if precision == "bf16" else 0
         self.s = solver or SolverCfg()
         self.model = model
         self.dev = next(model.parameters()).device
@@ -277,7 +280,7 @@ class DetectorTrainer:
         """Per step: data-gradient filters (and the Winograd images of the 3x3 filters) of the CURRENT weights."""
         for ly in self.layers.values():
             T.weight_transpose(ly.w, ly.wt, ly.rows, ly.k, ly.k, ly.cin, scale=ly.scale)
-            if ly.k == 3 and self.prec == 0:  # (the bf16 step runs its 3x3 layers as direct convolutions)
+            if ly.k == 3 and self.prec != 1:  # (the bf16 step runs its 3x3 layers as direct convolutions)
                 T.wino_weight_transform(ly.w, ly.U, ly.rows, ly.cin)
                 T.wino_weight_transform(ly.wt, ly.Ut, ly.cin, ly.rows)
 
@@ -286,7 +289,7 @@ class DetectorTrainer:
         return ops.conv2d(x, pk, precision=self.prec, **kw)
 
     def _wgrad(self, ly: _Layer, x, dy, accumulate=False):
-        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate, precision=self.prec)
+        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate, precision=self.wgrad_prec)
         if ly.db is not None:
             T.colsum(dy, ly.db, accumulate=accumulate)
 

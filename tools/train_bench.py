@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (reference: IMS_PER_BATCH 16 over 8 GPUs)")
     ap.add_argument("--dist-backend", default="nccl")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16 = autocast arithmetic (bf16 MFMA, fp32 accumulate)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="bf16 = autocast arithmetic (bf16 MFMA, fp32 accumulate); bf16x3 = fp32-grade 3-way bf16 split on the non-Winograd layers")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE oracle step (autograd on the host cores)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,7 +97,8 @@ def main():
     result = {
         "metric": "images/sec through the step1_bbox training step at 480x640", "value": round(B * world * args.steps / elapsed, 2),
         "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 (fp32 accumulate, fp32 master weights)",
+                                                                         "bf16x3": "f32 via exact 3-way bf16 operand split (forward / data gradients of the non-Winograd layers)"}[args.precision], "data": "synthetic",
         "config": {"workload": "BASELINE configs[4]: Faster R-CNN training step of step1_bbox.yaml (ResNet50-FPN, FREEZE_AT 2, RPN + box head "
                                "losses, SGD momentum), fp32, random-init weights with calibrated BN, synthetic frames and boxes",
                    "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
