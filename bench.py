@@ -83,6 +83,7 @@ def main():
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST; 0.5 gives a realistic handful of detections per frame on "
                          "random-init weights (0.7, the reference default, gives none; 0.0 gives 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the secondary timed loop in the opt-in bf16x3 mode")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 (default; the parity path and the headline number) or bf16: opt-in autocast arithmetic (bf16 MFMA, fp32 "
                          "accumulate) on the plain conv / linear layers -- reported with its own dtype, not comparable with the headline")
@@ -162,6 +163,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary figure, same clip, same timing discipline: the opt-in fp32-grade bf16x3 mode.  Reported
+    # beside the headline, never as it: `value` is plain fp32-MFMA arithmetic.
+    alt = None
+    if args.precision == "fp32" and not args.no_alt_modes:
+        ops.DEFAULT_PRECISION = 2
+        try:
+            for _ in range(max(1, min(args.warmup, 2))):
+                step()
+            drain()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            drain()
+            barrier()
+            el = time.perf_counter() - t0
+        finally:
+            ops.DEFAULT_PRECISION = 0
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        alt = {"bf16x3": {"value": round(B * world * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / args.steps, 3),
+                          "dtype": "f32 via exact 3-way bf16 operand split on the bf16 MFMA for the non-Winograd layers (error vs float64 <= the "
+                                   "fp32 MFMA's; the fp32 parity suite passes under it) -- opt-in (--precision bf16x3), NOT the headline"}}
+
     total_frames = B * world * args.steps
     fps = total_frames / elapsed
     dets = out.rec_count.float().mean().item()
@@ -215,6 +242,7 @@ def main():
                    "proposals_per_frame": round(out.proposals[4].float().mean().item(), 1),
                    "sharding": "contiguous frame blocks per rank" + (", RCCL all-gather of detection records per step" if world > 1 else "")},
         "roofline": roofline,
+        **({"alt_modes": alt} if alt else {}),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, synthetic_frames(args.cpu_frames + 1, 2020), args.score_thresh, args.cpu_frames)
