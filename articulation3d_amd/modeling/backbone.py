@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..streams import SMALL_BATCH, run_branches
 from ..registry import BACKBONE_REGISTRY
 from ..structures import ShapeSpec
 from .layers import ACT_NONE, ACT_RELU, Conv2d, FrozenBatchNorm2d, c2_msra_fill, c2_xavier_fill, to_nchw_view
@@ -127,12 +128,15 @@ class FPN(nn.Module):
         """x4: [B,H,W,4] normalised frames -> {p2..p6} fp32 NHWC."""
         res = self.bottom_up(x4)
         top = self._levels[-1]
-        feats = {}
-        prev = getattr(self, f"fpn_lateral{top}")(res[f"res{top}"])
-        feats[f"p{top}"] = getattr(self, f"fpn_output{top}")(prev)
-        for s in reversed(self._levels[:-1]):
-            prev = getattr(self, f"fpn_lateral{s}")(res[f"res{s}"], res=prev, res_ups=True)
-            feats[f"p{s}"] = getattr(self, f"fpn_output{s}")(prev)
+        prev = {top: getattr(self, f"fpn_lateral{top}")(res[f"res{top}"])}
+        for s in reversed(self._levels[:-1]):  # the top-down chain (1x1 laterals + upsampled residual) is serial ...
+            prev[s] = getattr(self, f"fpn_lateral{s}")(res[f"res{s}"], res=prev[s + 1], res_ups=True)
+        # ... the 3x3 output convs are independent of each other: concurrent for 1-2 frame batches (streams.py), the stride-4
+        # level on the current stream
+        levels = list(self._levels)
+        outs = run_branches([(lambda s=s: getattr(self, f"fpn_output{s}")(prev[s])) for s in levels],
+                            concurrent=x4.is_cuda and x4.shape[0] <= SMALL_BATCH)
+        feats = {f"p{s}": o for s, o in zip(levels, outs)}
         feats[f"p{top + 1}"] = ops.subsample2(feats[f"p{top}"])  # LastLevelMaxPool: max_pool2d(k=1, s=2)
         return feats
 

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ...streams import SMALL_BATCH, run_branches
 from ...registry import ROI_HEADS_REGISTRY
 from ...structures import Boxes, Instances, ShapeSpec
 from ..box_head import FastRCNNOutputLayers, build_box_head
@@ -114,16 +115,26 @@ class PlaneRCNNROIHeads(nn.Module):
         if rows == 0:
             return det
         same_pool = self.plane_on and self.axis_on and self._same_pooler(self.plane_pooler, self.axis_pooler)
+        pool = lambda p: p.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
+        shared = pool(self.plane_pooler) if self.plane_on else None
+        # the three heads are independent: concurrent branches for 1-2 frame batches (streams.py)
+        names, fns = [], []
         if self.mask_on:
-            x = self.mask_pooler.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
-            det.mask_prob = self.mask_head.forward_rows(x)
-        shared = None
+            names.append("mask")
+            fns.append(lambda: self.mask_head.forward_rows(pool(self.mask_pooler)))
         if self.plane_on:
-            shared = self.plane_pooler.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
-            det.pred_plane = self.plane_head.forward_rows(shared)
+            names.append("plane")
+            fns.append(lambda: self.plane_head.forward_rows(shared))
         if self.axis_on:
-            x = shared if same_pool else self.axis_pooler.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
-            det.pred_rot_axis, det.pred_tran_axis = self.axis_head.forward_rows(x)
+            names.append("axis")
+            fns.append(lambda: self.axis_head.forward_rows(shared if same_pool else pool(self.axis_pooler)))
+        outs = dict(zip(names, run_branches(fns, concurrent=det.boxes.is_cuda and det.boxes.shape[0] <= SMALL_BATCH)))
+        if "mask" in outs:
+            det.mask_prob = outs["mask"]
+        if "plane" in outs:
+            det.pred_plane = outs["plane"]
+        if "axis" in outs:
+            det.pred_rot_axis, det.pred_tran_axis = outs["axis"]
         return det
 
     @staticmethod

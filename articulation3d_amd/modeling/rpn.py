@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..streams import SMALL_BATCH, run_branches
 from ..registry import ANCHOR_GENERATOR_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
 from ..structures import Boxes, ImageList, Instances
 from .layers import ACT_RELU, Conv2d, _Packable, to_nhwc
@@ -82,7 +83,13 @@ class StandardRPNHead(nn.Module):
     def forward_nhwc(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
         """-> per level [B,Hf,Wf,16]: channels 0..2 objectness, 3..14 deltas (a*4+coord), 15 unused."""
         fused = self._fused.packed()
-        return [ops.conv2d(self.conv(f), fused) for f in feats]
+        level = lambda f: ops.conv2d(self.conv(f), fused)
+        if len(feats) >= 3 and feats[0].is_cuda and feats[0].shape[0] <= SMALL_BATCH:
+            # 1-2 frames: the levels are independent chains of latency-bound launches -- three concurrent branches
+            # (stride 4 | stride 8 | the rest), streams.py
+            a, b, c = run_branches([lambda: [level(feats[0])], lambda: [level(feats[1])], lambda: [level(f) for f in feats[2:]]], True)
+            return a + b + c
+        return [level(f) for f in feats]
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()

@@ -1,0 +1,65 @@
+"""Concurrency between independent branches of a 1-2 frame batch.
+
+A 1-frame pass is not launch-bound but latency-bound ON the GPU: ~200 kernels whose grids fill a fraction of the 256 CUs
+while every workgroup still walks its whole k loop.  Independent branches (the FPN output convs, the
+RPN levels, the mask / plane / axis heads) therefore run on side HIP streams for 1-2 frame batches.  Measured per batch size
+(bench.py --batch b, separate processes, A3D_SMALL_BATCH=0 vs 16): +3 % frames/s at 1 frame, +1 % at 2, -4 % at 4 and 8,
+-1..3 % at 16 -- from 4 frames on the branches fill the chip by themselves and the forks only add event waits, hence the
+threshold of 2.  (The depth decoder beside the whole ROI branch is a separate, much larger overlap: meta_arch.py, up to 16 frames.)
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+
+SMALL_BATCH = int(os.environ.get("A3D_SMALL_BATCH", "2"))  # frames (see above); 0 disables
+_side: dict = {}
+
+
+def _stream(i: int) -> "torch.cuda.Stream":
+    key = (torch.cuda.current_device(), i)
+    s = _side.get(key)
+    if s is None:
+        s = _side[key] = torch.cuda.Stream()
+    return s
+
+
+def _tensors(o):
+    if isinstance(o, torch.Tensor):
+        yield o
+    elif isinstance(o, (list, tuple)):
+        for x in o:
+            yield from _tensors(x)
+    elif isinstance(o, dict):
+        for x in o.values():
+            yield from _tensors(x)
+
+
+def run_branches(fns: Sequence[Callable[[], object]], concurrent: bool) -> List[object]:
+    """Evaluate independent thunks; with `concurrent` the first runs on the current stream and the others on side streams
+    that start behind everything enqueued so far and are joined before returning.  Inputs must stay referenced by the
+    caller until the call returns (they are: the join orders any later reuse behind the side streams)."""
+    if not concurrent or len(fns) < 2 or not torch.cuda.is_available():
+        return [f() for f in fns]
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    outs: List[object] = [None] * len(fns)
+    done = []
+    for i in range(1, len(fns)):
+        s = _stream(i)
+        with torch.cuda.stream(s):
+            s.wait_event(ready)
+            outs[i] = fns[i]()
+            e = torch.cuda.Event()
+            e.record(s)
+            done.append(e)
+    outs[0] = fns[0]()
+    for e in done:
+        main.wait_event(e)
+    for o in outs[1:]:
+        for t in _tensors(o):
+            t.record_stream(main)  # allocated on a side stream, consumed (and later freed) on the main one
+    return outs
