@@ -137,10 +137,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const a3d_wgrad_
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float wg_f32x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const a3d_wgrad_desc d, const int P, const int mtiles, const int ntiles,
-                                                                  const int chunk) {
-    constexpr int BKP = 32, LKB = BKP + 8;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][128 * LKB];  // [buffer][A|B][channel][pixel]
+// x == h + m + l exactly (round-to-nearest-even at each level): the 3-way split of csrc/conv_bf16x3.hip, 8 wide
+__device__ __forceinline__ void wg_split3(const wg_f32x8 v, wg_bf16x8 &h, wg_bf16x8 &m, wg_bf16x8 &l) {
+    h = __builtin_convertvector(v, wg_bf16x8);
+    const wg_f32x8 r1 = v - __builtin_convertvector(h, wg_f32x8);
+    m = __builtin_convertvector(r1, wg_bf16x8);
+    const wg_f32x8 r2 = r1 - __builtin_convertvector(m, wg_f32x8);
+    l = __builtin_convertvector(r2, wg_bf16x8);
+}
+
+// X3 = false: precision 1 (operands rounded to bf16, chunk of 32 pixels).  X3 = true: precision 2, fp32-grade -- both
+// operands split exactly into hi | mid | lo bf16 planes in LDS and six MFMAs per 16-pixel k step (conv_bf16x3.hip has the
+// arithmetic); chunk of 16 pixels so that 3 planes x 2 operands x 2 buffers stay at 72 KB (2 workgroups per CU).
+template <bool X3>
+__global__ __launch_bounds__(256, X3 ? 2 : 3) void conv_wgrad_bf16_kernel(const a3d_wgrad_desc d, const int P, const int mtiles, const int ntiles,
+                                                                         const int chunk) {
+    constexpr int BKP = X3 ? 16 : 32, LKB = BKP + 8, NPL = X3 ? 3 : 1, G = BKP / 16, S = BKP / 16;
+    constexpr int PL = 128 * LKB;  // one operand plane: [channel][pixel]
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][NPL * PL];  // [buffer][A|B][plane][channel][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int t = blockIdx.x;
@@ -151,18 +165,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const a3d_wgrad
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
     const int co0 = mt * 128, ci0 = nt * 128;
     const int p_begin = blockIdx.y * chunk, p_end = min(P, p_begin + chunk);
-    const int ch = tid & 127, kg = tid >> 7;  // channel inside the tile; pixel groups kg*2, kg*2+1 (8 pixels each)
+    const int ch = tid & 127, kg = tid >> 7;  // channel inside the tile; pixel groups kg*G .. kg*G+G-1 (8 pixels each)
     const bool a_ok = co0 + ch < d.Cout, b_ok = ci0 + ch < d.Cin;
     const int HoWo = d.Ho * d.Wo;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.dy), 0, (int)((size_t)P * d.Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.x), 0, (int)((size_t)d.B * d.H * d.W * d.Cin * 4), 0x00020000);
 
-    wg_f32x8 ra[2], rb[2];
+    wg_f32x8 ra[G], rb[G];
     auto load = [&](int p0) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int pg = p0 + (kg * 2 + g) * 8;
+        for (int g = 0; g < G; ++g) {
+            const int pg = p0 + (kg * G + g) * 8;
             int b = pg / HoWo, r = pg - b * HoWo;
             int oh = r / d.Wo, ow = r - oh * d.Wo;
 #pragma unroll
@@ -186,9 +200,22 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const a3d_wgrad
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][ch * LKB + (kg * 2 + g) * 8]) = __builtin_convertvector(ra[g], wg_bf16x8);
-            *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][ch * LKB + (kg * 2 + g) * 8]) = __builtin_convertvector(rb[g], wg_bf16x8);
+        for (int g = 0; g < G; ++g) {
+            const int off = ch * LKB + (kg * G + g) * 8;
+            if constexpr (X3) {
+                wg_bf16x8 h, m, l;
+                wg_split3(ra[g], h, m, l);
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][off]) = h;
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][PL + off]) = m;
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][2 * PL + off]) = l;
+                wg_split3(rb[g], h, m, l);
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][off]) = h;
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][PL + off]) = m;
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][2 * PL + off]) = l;
+            } else {
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][off]) = __builtin_convertvector(ra[g], wg_bf16x8);
+                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][off]) = __builtin_convertvector(rb[g], wg_bf16x8);
+            }
         }
     };
 
@@ -212,13 +239,27 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(const a3d_wgrad
         const __bf16 *A = &lds[cur][0][(wm * 64) * LKB + foff];
         const __bf16 *Bm = &lds[cur][1][(wn * 64) * LKB + foff];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const wg_bf16x8 a0 = *reinterpret_cast<const wg_bf16x8 *>(A + s * 16), a1 = *reinterpret_cast<const wg_bf16x8 *>(A + 32 * LKB + s * 16);
-            const wg_bf16x8 b0 = *reinterpret_cast<const wg_bf16x8 *>(Bm + s * 16), b1 = *reinterpret_cast<const wg_bf16x8 *>(Bm + 32 * LKB + s * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        for (int s = 0; s < S; ++s) {
+            wg_bf16x8 a[NPL][2], b[NPL][2];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[p][i] = *reinterpret_cast<const wg_bf16x8 *>(A + p * PL + i * 32 * LKB + s * 16);
+                    b[p][i] = *reinterpret_cast<const wg_bf16x8 *>(Bm + p * PL + i * 32 * LKB + s * 16);
+                }
+#define WG_TERM(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0);
+            WG_TERM(0, 0)
+            if constexpr (X3) {
+                WG_TERM(0, 1)
+                WG_TERM(1, 0)
+                WG_TERM(1, 1)
+                WG_TERM(2, 0)
+                WG_TERM(0, 2)
+            }
+#undef WG_TERM
         }
         if (c + 1 < nchunks) store(cur ^ 1);
         __syncthreads();
@@ -263,9 +304,11 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     int chunk = (P + d->splitk - 1) / d->splitk;
     chunk = (chunk + 31) / 32 * 32;  // a multiple of both kernels' k-chunk (16 / 32 pixels)
     a3d_begin();
-    if (d->precision == 1) {
+    if (d->precision == 1 || d->precision == 2) {
         if ((size_t)P * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
+        const dim3 grid(mtiles * ntiles * d->KH * d->KW, d->splitk);
+        if (d->precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
+        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
     } else
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
     const size_t total4 = (size_t)d->Cout * d->KH * d->KW * d->Cin / 4;

@@ -134,9 +134,9 @@ class DetectorTrainer:
         weights, activations, gradients, losses and the optimiser stay fp32."""
         assert precision in ("fp32", "bf16", "bf16x3")
         # "bf16x3": fp32-grade arithmetic on the bf16 pipe (csrc/conv_bf16x3.hip) for the forward / data-gradient launches of the
-        # non-Winograd layers; Winograd layers and the weight-gradient kernel stay on the fp32 MFMA
+        # non-Winograd layers and for every weight gradient; the Winograd launches stay on the fp32 MFMA
         self.prec = {"fp32": 0, "bf16": 1, "bf16x3": "bf16x3"}[precision]
-        self.wgrad_prec = 1 if precision == "bf16" else 0
+        self.wgrad_prec = {"fp32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self.s = solver or SolverCfg()
         self.model = model
         self.dev = next(model.parameters()).device

@@ -292,7 +292,7 @@ typedef struct a3d_wgrad_desc {
     int KH, KW, stride, pad;
     int splitk;         /* >= 1 pixel slices (summed in slice order: deterministic) */
     int accumulate;     /* 1: dw += (weights shared by several call sites, e.g. the RPN head over 5 levels) */
-    int precision;      /* 0: fp32 MFMA; 1: bf16 MFMA, fp32 accumulation (see a3d_conv_desc.precision)        */
+    int precision;      /* 0: fp32 MFMA; 1: bf16 MFMA, fp32 accumulation; 2: fp32-grade 3-way bf16 split (see a3d_conv_desc.precision) */
 } a3d_wgrad_desc;
 size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
 int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);

@@ -565,3 +565,24 @@ def test_bf16x3_training_step_matches_fp32(hip_model, oracle):
     assert max(v for k, v in errs.items() if "objectness" in k) < 1e-4
     assert max(errs.values()) < 5e-3
     assert all(bool(torch.isfinite(v).all()) for v in gx3.values())
+
+
+def test_bf16x3_weight_gradient_is_fp32_grade(T):
+    """a3d_wgrad_desc.precision == 2: the pixel-reduction GEMM with both operands split exactly into three bf16 terms.  Against
+    the float64 weight gradient its error is no larger than the fp32 MFMA kernel's (3x3 stride 2 with padding, ragged channel
+    tiles, split-K over the pixels)."""
+    torch.manual_seed(31)
+    B, Cin, Cout, H, W, k, s, p = 3, 96, 136, 37, 41, 3, 2, 1
+    x = torch.randn(B, Cin, H, W)
+    w = (torch.randn(Cout, Cin, k, k) / (k * k * Cin) ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, s, p)
+    dy = torch.randn(y.shape)
+    y.backward(dy.double())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
+    err = {}
+    for prec in (0, 2):
+        dw = torch.empty((Cout, k * k * Cin), device="cuda")
+        T.conv_wgrad(nhwc(x).cuda(), nhwc(dy).cuda(), dw, KH=k, KW=k, stride=s, pad=p, precision=prec)
+        err[prec] = ((dw.double().cpu() - ref).norm() / ref.norm()).item()
+    print("weight gradient, relative L2 error vs float64: fp32 MFMA %.3e, bf16x3 %.3e" % (err[0], err[2]))
+    assert err[2] < 1e-6 and err[2] <= 1.05 * err[0]
