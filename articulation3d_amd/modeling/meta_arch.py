@@ -103,8 +103,6 @@ class PlaneRCNN(nn.Module):
         else:  # forward_with_given_boxes entry (roi_heads.py:147): boxes [B,R,4], count [B]
             gb, gc = given_boxes
             det = BatchedDetections(gb, torch.ones(gb.shape[:2], device=gb.device), torch.zeros(gb.shape[:2], device=gb.device, dtype=torch.int32), gc, hw)
-        # (measured: running the depth decoder on a second HIP stream beside the RPN / ROI branch gives no gain --
-        # both branches are MFMA-bound, 521 frames/s either way -- so everything stays on one stream)
         # the live-ROI total starts its trip to the host here and is waited for after the depth decoder has been enqueued
         self.roi_heads.start_row_count(det)
         if self.depth_head_on and B <= self.small_batch_overlap and frames.is_cuda:
