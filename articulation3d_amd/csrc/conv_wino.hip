@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const W
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], acc[ni], 0, 0, 0);
         }
     };
-    // Measured and rejected here: a second (ping-pong) plane accumulator that folds plane f behind the MFMAs of plane
+    // Measured and rejected here: a persistent form (3 workgroups per CU walking tiles, chunk stream continuing across tile
+    // boundaries: bit-identical, 7-14 % slower -- the tile switch inside the loader disturbs this loop); a second (ping-pong) plane accumulator that folds plane f behind the MFMAs of plane
     // f+1 (2-8 % slower: +16 registers, no gain -- the fold is not what idles the pipe); one staging set at 4 waves / SIMD
     // (__launch_bounds__(256, 4) fits 116 VGPRs: ties with this form).
     int cf = 0, ckc = 0;  // (plane, chunk) being multiplied
