@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const W
                     acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fc][ni][j], fb[fc][j], acc[ni], 0, 0, 0);
         }
     };
-    // Measured and rejected here: a persistent form (3 workgroups per CU walking tiles, chunk stream continuing across tile
+    // Measured and rejected here: a separable split of the input transform (the input kernel writes only the x part, R = d B per
+    // pixel row, 2x the input instead of 4x; this loader finishes V = R[ra] +- R[rb] with two loads and one FMA per float4:
+    // same accuracy, input kernel 40 % cheaper, but the GEMM loses 15 % on 256-channel layers to the doubled L2 -> L1 / HBM
+    // reads -- net +2 % on p2 256->256, -13 % on res2 64->64, i.e. 0.4 ms per step: not worth a second code path); a persistent form (3 workgroups per CU walking tiles, chunk stream continuing across tile
     // boundaries: bit-identical, 7-14 % slower -- the tile switch inside the loader disturbs this loop); a second (ping-pong) plane accumulator that folds plane f behind the MFMAs of plane
     // f+1 (2-8 % slower: +16 registers, no gain -- the fold is not what idles the pipe); one staging set at 4 waves / SIMD
     // (__launch_bounds__(256, 4) fits 116 VGPRs: ties with this form).
