@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops
 prec = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 torch.manual_seed(0)

@@ -1,3 +1,4 @@
+# rocprofv3 kernel summary of bench.py --precision bf16x3 (profiles/r01_bf16x3_kernel_summary.md): run through gpurun, then tools/summarize_rocprof.py.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/prof_x3; rm -rf $O
