@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("w_wino", fptr),
         ("gate", fptr),
         ("precision", C.c_int),
+        ("w_wino_x3", fptr),
     ]
 
 
@@ -178,6 +179,7 @@ SIGNATURES = {
     "a3d_preprocess_u8hwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_preprocess_f32chw": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),

@@ -258,7 +258,10 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     a3d_begin();
     if (d->precision == 1) return a3d_conv_launch_bf16(d, s);  // (A3D_ERR_UNSUPPORTED for layer kinds it does not cover)
-    if (d->precision == 2) return a3d_conv_launch_bf16x3(d, s);
+    if (d->precision == 2) {  // Winograd layers keep the Winograd form (split-operand GEMM, conv_wino.hip 2x), the rest go direct
+        if (d->tune == 0 && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+        return a3d_conv_launch_bf16x3(d, s);
+    }
     if (d->precision != 0) return A3D_ERR_ARG;
     if ((d->tune == 0 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
     if (d->tune == 0 || d->tune == 6) {  // persistent pointwise kernel for the 1x1 layers (tune 5: never, 6: whenever eligible)

@@ -91,6 +91,7 @@ struct WinoArgs {
     const float *gate;   // optional [B, Hl, Wl, Cout]: zero the output where gate <= 0
     float *y;            // [B, Hl, Wl, Cout]
     int T, C, Cout, B, Hl, Wl, Ty, Tx, act;
+    const __bf16 *U3;    // precision 2: U split into bf16 planes, chunk-major [16][C/32][3][Cout][32]
 };
 
 template <int TN, int BKT>
@@ -288,6 +289,242 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const W
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2x. The same 16-plane GEMM with fp32-grade products on the bf16 matrix pipe (a3d_conv_desc.precision == 2; the arithmetic
+// is conv_bf16x3.hip's: every fp32 operand split exactly into hi | mid | lo bf16 terms while it is staged in LDS, six
+// v_mfma_f32_32x32x16_bf16 per 16-deep k step, fp32 accumulation).  64 tiles x 64 channels per workgroup, 32-deep chunks,
+// the fold and the epilogue of wino_gemm_kernel unchanged (the 32x32 accumulator layout is the same).  LDS image per
+// operand plane: [64 rows][32 k] bf16, 64-byte rows whose four 16-byte slots are XOR-swizzled with bits 2..3 of the row
+// index (conflict-free ds_read_b128 under the 64-bank / 16-lane-group rule, conflict-free ds_write_b64).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void wsplit3(const f32x4 v, wbf16x4 &h, wbf16x4 &m, wbf16x4 &l) {
+    h = __builtin_convertvector(v, wbf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, wbf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, wbf16x4);
+}
+
+__global__ __launch_bounds__(256, 3) void wino_gemm_x3_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+    constexpr int TN = 1, BKT = 32;
+    constexpr int BM = 64, BN = 64;
+    constexpr int LKB = BKT;                      // bf16 elements per LDS row (64 bytes, swizzled, no padding)
+    constexpr int TPR = BKT / 4, RPP = 256 / TPR;  // 8 lanes x float4 per row, 32 rows per loader pass
+    constexpr int XR = BM / RPP;
+    constexpr int PL = 64 * LKB;                  // one operand plane
+    constexpr int BUF = 6 * PL;                   // X hi|mid|lo, W hi|mid|lo
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float ss[2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int t0 = mt * BM, n0 = nt * BN;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    const size_t vplane = (size_t)a.T * a.C, uplane = (size_t)a.Cout * a.C;
+    const unsigned vbytes = (unsigned)(vplane * 4), ubytes = (unsigned)(uplane * 4);
+    const int KC = a.C / BKT;
+    const int NIT = 16 * KC;
+
+    int xoff[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int t = t0 + lr + RPP * i;
+        xoff[i] = t < a.T ? (t * a.C + lc) * 4 : -1;
+    }
+    // weights: pre-split planes U3 [16][C/32][3][Cout][32] bf16 (a3d_split_bf16x3 at pack time); a lane moves one 16-byte
+    // slot (8 k) of one row per plane: row = tid / 4, slot = tid % 4 -- the 64 rows of a plane are 4 KB contiguous
+    const int wrow = tid >> 2, wq = tid & 3;
+    const int woff = (n0 + wrow < a.Cout) ? (n0 + wrow) * 64 + wq * 16 : -1;
+    const int wlds = wrow * LKB + (((wq ^ (wrow >> 2)) & 3) << 3);
+    const unsigned u3tile = (unsigned)a.Cout * 64u;  // bytes of one (f, chunk, plane) tile
+    // slot swizzle: k = 8q .. 8q+7 of row r lives in slot q ^ ((r >> 2) & 3); the loader rows lr + 32 i share (r >> 2) & 3
+    const int lcs = ((((lc >> 3) ^ (lr >> 2)) & 3) << 3) | (lc & 7);
+    f32x4 xsA[XR], wsA[3], xsB[XR], wsB[3];
+    int ld_f = 0, ld_kc = 0;
+    auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[3]) {
+        const int f = min(ld_f, 15);
+        const __amdgpu_buffer_rsrc_t rv = wmake_rsrc(a.V + (size_t)f * vplane, vbytes);
+        const __amdgpu_buffer_rsrc_t ru = wmake_rsrc(reinterpret_cast<const float *>(a.U3 + (size_t)f * 3 * uplane), (unsigned)(uplane * 6));
+        const int soff = ld_kc * BKT * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, xoff[i], soff);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ws[p] = wbuf_load4(ru, woff, (ld_kc * 3 + p) * (int)u3tile);
+        if (++ld_kc == KC) {
+            ld_kc = 0;
+            ++ld_f;
+        }
+    };
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[3]) {
+        __bf16 *X = lds + buf * BUF;
+        __bf16 *Wt = X + 3 * PL;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            wbf16x4 h, m, l;
+            wsplit3(xs[i], h, m, l);
+            __bf16 *p = X + (lr + RPP * i) * LKB + lcs;
+            *reinterpret_cast<wbf16x4 *>(p) = h;
+            *reinterpret_cast<wbf16x4 *>(p + PL) = m;
+            *reinterpret_cast<wbf16x4 *>(p + 2 * PL) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4 *>(Wt + p * PL + wlds) = ws[p];
+    };
+
+    f32x16 mf[TN];
+    f32x16 yy[4][TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mf[n][r] = 0.f;
+            yy[0][n][r] = yy[1][n][r] = yy[2][n][r] = yy[3][n][r] = 0.f;
+        }
+    if (tid < BN) {
+        const int n = n0 + tid;
+        ss[tid] = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        ss[BN + tid] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    }
+    load_chunk(xsA, wsA);
+    store_chunk(0, xsA, wsA);
+    load_chunk(xsB, wsB);
+    load_chunk(xsA, wsA);
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fsw = (frow >> 2) & 3;
+    auto fold = [&](f32x16 (&m)[TN], const int f) {
+        const int u = f >> 2, v = f & 3;
+        const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
+        const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
+        const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = m[n][r];
+                yy[0][n][r] = __builtin_fmaf(c00, x, yy[0][n][r]);
+                yy[1][n][r] = __builtin_fmaf(c01, x, yy[1][n][r]);
+                yy[2][n][r] = __builtin_fmaf(c10, x, yy[2][n][r]);
+                yy[3][n][r] = __builtin_fmaf(c11, x, yy[3][n][r]);
+                m[n][r] = 0.f;
+            }
+        }
+    };
+    // one chunk: 2 k steps x 6 product terms from LDS[cur]; the staged chunk it+1 is split into LDS[cur^1]; its set is refilled
+    auto mma = [&](f32x16 (&acc)[TN], const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[3]) {
+        const __bf16 *X = lds + cur * BUF + (wm * 32 + frow) * LKB;
+        const __bf16 *Wt = lds + cur * BUF + 3 * PL + (wn * 32 + frow) * LKB;
+        // fragments of ONE 16-deep step at a time (24 registers; both steps at once cost 48 and spill at 3 workgroups per CU)
+        wbf16x8 fa[3], fb[3];
+        auto frags = [&](const int st) {
+            const int slot = (((2 * st + (lane >> 5)) ^ fsw) & 3) << 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                fa[p] = *reinterpret_cast<const wbf16x8 *>(Wt + p * PL + slot);
+                fb[p] = *reinterpret_cast<const wbf16x8 *>(X + p * PL + slot);
+            }
+        };
+#define WX3(PA, PB) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[PB], acc[0], 0, 0, 0);
+#define WX3_STEP WX3(0, 0) WX3(0, 1) WX3(1, 0) WX3(1, 1) WX3(2, 0) WX3(0, 2)
+        frags(0);
+        store_chunk(cur ^ 1, xs, ws);
+        load_chunk(xs, ws);
+        WX3_STEP
+        frags(1);
+        WX3_STEP
+#undef WX3_STEP
+#undef WX3
+        // the split's VALU work, the LDS writes and the buffer loads go into the shadows of the 12 MFMAs
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    int cf = 0, ckc = 0;
+    for (int it = 0; it < NIT; it += 2) {
+        mma(mf, 0, xsB, wsB);
+        if (++ckc == KC) {
+            ckc = 0;
+            fold(mf, cf++);
+        }
+        __syncthreads();
+        mma(mf, 1, xsA, wsA);
+        if (++ckc == KC) {
+            ckc = 0;
+            fold(mf, cf++);
+        }
+        __syncthreads();
+    }
+
+    const int t = t0 + wm * 32 + (lane & 31);
+    if (t >= a.T) return;
+    const int tx = t % a.Tx;
+    const int r = t / a.Tx;
+    const int ty = r % a.Ty, b = r / a.Ty;
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+        const int oy = 2 * ty + (ij >> 1), ox = 2 * tx + (ij & 1);
+        if (oy >= a.Hl || ox >= a.Wl) continue;
+        const size_t ooff = (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
+        float *orow = a.y + ooff;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int nl = wn * 32 + rg * 8 + (lane >> 5) * 4;
+            const int n = n0 + nl;
+            if (n >= a.Cout) continue;
+            f32x4 v = {yy[ij][0][rg * 4 + 0], yy[ij][0][rg * 4 + 1], yy[ij][0][rg * 4 + 2], yy[ij][0][rg * 4 + 3]};
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+            if (a.act == A3D_ACT_RELU) {
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            } else if (a.act == A3D_ACT_LEAKY) {
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
+            }
+            if (a.gate) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
+                for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(orow + n) = v;
+        }
+    }
+}
+
+// src [outer][rows][cols] fp32 -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly: the chunk-major
+// plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a
+// plain [rows][cols] plane layout a lane's 16-byte piece of a row is a 64-byte-strided access and the kernel runs 2x slower).
+// a3d_conv_desc.w_wino_x3: outer = 16, rows = Cout, cols = Cin + Cin2.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int rows, int cols, size_t total) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const size_t per = (size_t)rows * cols;
+    const size_t o = i / per, r = i - o * per;
+    const int n = (int)(r / cols), c = (int)(r - (size_t)n * cols);
+    wbf16x4 h, m, l;
+    wsplit3(*reinterpret_cast<const f32x4 *>(src + i), h, m, l);
+    __bf16 *d = dst + o * 3 * per + ((size_t)(c >> 5) * 3 * rows + n) * 32 + (c & 31);
+    *reinterpret_cast<wbf16x4 *>(d) = h;
+    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * 32) = m;
+    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * 64) = l;
+}
+
+extern "C" int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream) {
+    if (!src || !dst || outer <= 0 || rows <= 0 || cols <= 0 || (cols & 31)) return A3D_ERR_ARG;
+    a3d_begin();
+    const size_t total = (size_t)outer * rows * cols;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16 *)dst, rows, cols, total);
+    return a3d_check_launch();
+}
+
 int a3d_wino_eligible(const a3d_conv_desc *d) {
     if (!d->w_wino) return 0;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return 0;
@@ -340,6 +577,14 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.Tx = Tx;
     a.act = d->act;
     const int mtiles = (int)((T + 63) / 64);
+    a.U3 = nullptr;
+    if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
+        if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
+        a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
+        const int nt = (d->Cout + 63) / 64;
+        hipLaunchKernelGGL(wino_gemm_x3_kernel, dim3(mtiles * nt), dim3(256), 0, s, a, nt, mtiles * nt);
+        return A3D_OK;
+    }
     // tune >= 200 selects an explicit GEMM variant for A/B measurements: 200 + 10*(TN-1) + (BK==32)
     int tn = 1, bk32 = 1;  // measured best on every layer shape of the detector (64 tiles x 64 channels, 3 waves/SIMD)
     if (d->tune >= 200) {

@@ -87,6 +87,7 @@ class PackedConv:
     pixshuf: bool = False
     stem: bool = False
     w_wino: Optional[torch.Tensor] = None  # [16, cols, Cin] Winograd-domain weights (3x3 s1 p1 convs)
+    w_wino_x3: Optional[torch.Tensor] = None  # [16, Cin/32, 3, cols, 32] bf16 planes of w_wino, made at the first precision-2 use
     phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
 
     @property
@@ -270,7 +271,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
             x3_ok = (not (p.stem or ups or p.pixshuf or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
                      and (x2 is None or Cin2 == Cin) and Cin % 16 == 0 and not (p.phase and res is not None))
-            precision = 2 if x3_ok and not wino_ok and tune == 0 else 0
+            # Winograd layers keep the Winograd form with the split-operand GEMM (conv_wino.hip 2x, 32-deep chunks)
+            precision = 2 if tune == 0 and ((x3_ok and not wino_ok) or (wino_ok and (Cin + Cin2) % 32 == 0)) else 0
         else:
             precision = 0
     d.precision = int(precision)
@@ -279,10 +281,16 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
-    use_wino = wino_ok and precision == 0
+    use_wino = wino_ok and (precision == 0 or (precision == 2 and tune == 0 and (Cin + Cin2) % 32 == 0))
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()
+        if d.precision == 2:
+            if p.w_wino_x3 is None or p.w_wino_x3.device != p.w_wino.device:  # once per layer
+                rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
+                p.w_wino_x3 = torch.empty((16, cols // 32, 3, rows, 32), device=p.w_wino.device, dtype=torch.bfloat16)
+                _lib.check(_lib.lib().a3d_split_bf16x3(p.w_wino.data_ptr(), p.w_wino_x3.data_ptr(), 16, rows, cols, _stream()), "a3d_split_bf16x3")
+            d.w_wino_x3 = p.w_wino_x3.data_ptr()
     if use_wino or splitk > 1:
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
         ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
@@ -299,7 +307,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()
             CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape))
-            CONV_TIMING.append(("wino_gemm_kernel<1,32>", 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape))
+            CONV_TIMING.append(("wino_gemm_x3_kernel" if d.precision == 2 else "wino_gemm_kernel<1,32>", 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape))
             return out
         e0, e1 = ev(), ev()
         e0.record()

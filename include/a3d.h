@@ -100,10 +100,16 @@ typedef struct a3d_conv_desc {
                             six bf16 MFMAs per k step reproduce the fp32 product to 2^-24 relative (csrc/conv_bf16x3.hip);
                             same layer kinds as 1 plus the phase convs and their equal-width 2-source concat, Cin % 16 == 0.
                             Opt-in: the default everywhere is 0                                                  */
+    const void *w_wino_x3; /* precision 2 on a Winograd layer: w_wino split into three bf16 planes, chunk-major
+                            [16][(Cin+Cin2)/32][3][Cout][32] (a3d_split_bf16x3 with outer = 16, rows = Cout, cols = Cin+Cin2);
+                            the layer then runs F(2x2,3x3) with the split-operand GEMM                                */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
 int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
+/* src [outer][rows][cols] fp32 (cols % 32 == 0) -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly
+ * (round-to-nearest-even at each level). */
+int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream);
 
 /* The two launches of the Winograd form, individually (a3d_conv2d_nhwc_f32 issues both when d->w_wino is set):
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */

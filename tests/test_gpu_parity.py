@@ -181,6 +181,26 @@ def test_bf16x3_kernel_is_fp32_grade(ops, case):
     assert ex3 < 1e-6 and ex3 <= 1.05 * e32
 
 
+@pytest.mark.parametrize("shape", [(2, 61, 79, 64, 64), (2, 31, 41, 128, 200), (5, 14, 14, 256, 256)])
+def test_winograd_split_operand_gemm_is_fp32_grade(ops, shape):
+    """precision == 2 on a Winograd layer: F(2x2,3x3) whose 16-plane GEMM multiplies exact 3-way bf16 splits of V and U
+    (csrc/conv_wino.hip, 2x).  Against float64 its error is no larger than the fp32 Winograd form's (odd sizes, ragged channel
+    tiles, the per-ROI 14x14 maps)."""
+    torch.manual_seed(23)
+    B, H, W, Cin, Cout = shape
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    bias = torch.randn(Cout)
+    pk = ops.pack_conv(w, bias, None, 1, 1, ops.ACT_RELU)
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), 1, 1))
+    xd = nhwc(x).cuda()
+    l2 = lambda y: ((y.permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()).item()
+    e32, ex3 = l2(ops.conv2d(xd, pk, precision=0)), l2(ops.conv2d(xd, pk, precision=2))
+    assert pk.w_wino_x3 is not None  # it did take the Winograd route
+    print(f"{shape}: relative L2 error vs float64: fp32 Winograd {e32:.3e}, split-operand Winograd {ex3:.3e}")
+    assert ex3 < 1e-6 and ex3 <= 1.05 * e32
+
+
 def test_bf16x3_mode_through_the_detector(ops, hip_model, oracle):
     """ops.DEFAULT_PRECISION = 2 (A3D_PRECISION=2 / bench.py --precision bf16x3) routes the non-Winograd conv / linear layers
     through the bf16x3 kernel.  It is an fp32-grade mode: features, depth and head outputs stay within the fp32 path's own
