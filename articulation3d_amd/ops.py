@@ -29,8 +29,9 @@ CONV_TIMING: Optional[list] = None
 # throughput mode for deployments that accept autocast-level error -- never used by the parity tests or the headline bench.
 # 2 = "bf16x3": fp32-grade arithmetic on the bf16 matrix pipe (csrc/conv_bf16x3.hip: every fp32 operand split exactly into
 # three bf16 terms, six MFMAs per k step, fp32 accumulate; measured error against float64 is slightly BELOW the fp32
-# MFMA's, tools/x3_bench.py) on the plain non-Winograd layers (1x1 convs, linears, strided 3x3); the Winograd layers keep
-# the fp32 MFMA.  Opt-in as well (A3D_PRECISION=2 / bench.py --precision bf16x3); the whole fp32 parity suite passes under it.
+# MFMA's, tools/x3_bench.py) on the direct layers (1x1 convs, linears, strided 3x3, phase / concat convs); the Winograd layers
+# keep the Winograd form with the split-operand GEMM of csrc/conv_wino.hip.  Opt-in as well (A3D_PRECISION=2 / bench.py
+# --precision bf16x3); the whole fp32 parity suite passes under it.
 DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "0"))
 
 

@@ -186,7 +186,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         alt = {"bf16x3": {"value": round(B * world * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / args.steps, 3),
-                          "dtype": "f32 via exact 3-way bf16 operand split on the bf16 MFMA for the non-Winograd layers (error vs float64 <= the "
+                          "dtype": "f32 via exact 3-way bf16 operand split on the bf16 MFMA, direct and Winograd layers (error vs float64 <= the "
                                    "fp32 MFMA's; the fp32 parity suite passes under it) -- opt-in (--precision bf16x3), NOT the headline"}}
 
     total_frames = B * world * args.steps
@@ -232,8 +232,8 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in, NOT the headline",
-                  "bf16x3": "f32 via exact 3-way bf16 operand split on the bf16 MFMA (fp32-grade error, fp32 tensors / accumulate) on the "
-                            "non-Winograd layers -- opt-in, NOT the headline"}[args.precision], "data": "synthetic",
+                  "bf16x3": "f32 via exact 3-way bf16 operand split on the bf16 MFMA (fp32-grade error, fp32 tensors / accumulate), "
+                            "direct and Winograd layers -- opt-in, NOT the headline"}[args.precision], "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full PlaneRCNN detector (ResNet50-FPN + RPN + ROIAlign + box/mask/plane/axis heads "
                                "+ depth head + NMS + mask paste + plane-offset LSQ + record pack), fp32, random-init weights with "
                                "calibrated BN, synthetic 480x640 uint8 frames resident in HBM",
