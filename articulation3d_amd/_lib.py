@@ -183,6 +183,7 @@ SIGNATURES = {
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_last_conv_variant": (C.c_char_p, []),
     "a3d_maxpool3x3s2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_subsample2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_resize_bilinear_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),

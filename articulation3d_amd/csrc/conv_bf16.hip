@@ -175,6 +175,7 @@ void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = 128, BN = 64 * TN;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    a3d_note_variant("conv_bf16_kernel<%d>", TN);
     hipLaunchKernelGGL((conv_bf16_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
 }
 }  // namespace

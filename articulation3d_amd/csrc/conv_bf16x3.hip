@@ -253,6 +253,7 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = 128, BN = 64 * TN;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    a3d_note_variant("conv_x3_kernel<%d>", TN);
     hipLaunchKernelGGL((conv_x3_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
 }
 }  // namespace

@@ -95,6 +95,11 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
 }
 
 
+// Every conv launcher records the kernel instantiation it dispatched (name + template arguments as they appear in a
+// rocprofv3 kernel trace) in a per-thread slot; `a3d_last_conv_variant()` (include/a3d.h) reads it back, so measurement
+// code labels launches with what the dispatcher DID, not with a host-side copy of its rules.
+void a3d_note_variant(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // v2 kernel family (conv_gemm_v2.hip): buffer-addressed, branch-free gather + software-pipelined main loop.
 // Returns A3D_ERR_UNSUPPORTED when the descriptor needs the general kernel.
 int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);

@@ -19,6 +19,8 @@
 // permutation, so the sum over the slice is complete.  LDS rows are padded to 36 floats: 16
 // consecutive rows then cover all 64 banks exactly once per b128 lane group (conflict-free).
 #include "conv_common.h"
+#include <stdarg.h>
+#include <stdio.h>
 
 struct RowCtx {
     int ih0, iw0, boff;  // top-left input coordinate of the receptive field, b*H*W
@@ -225,6 +227,15 @@ static int conv_check(const a3d_conv_desc *d) {
     return A3D_OK;
 }
 
+static thread_local char g_last_variant[160] = "";
+void a3d_note_variant(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_variant, sizeof(g_last_variant), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *a3d_last_conv_variant(void) { return g_last_variant; }
+
 extern "C" size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d) {
     if (!d) return 0;
     if ((d->tune == 0 || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
@@ -241,6 +252,7 @@ static int launch_cfg(const a3d_conv_desc *d, hipStream_t s) {
     const int kt_total = d->Kpad / BK;
     const int kps = (kt_total + d->splitk - 1) / d->splitk;
     dim3 grid(nblk, d->splitk);
+    a3d_note_variant("conv_gemm_kernel<%d,%d,%d,%d,%d>", WAVES_M, WAVES_N, TM, TN, (int)STEM);
     hipLaunchKernelGGL((conv_gemm_kernel<WAVES_M, WAVES_N, TM, TN, STEM>), grid, dim3(256), 0, s, *d, M, ntiles, nblk,
                        kt_total, kps);
     if (d->splitk > 1) {

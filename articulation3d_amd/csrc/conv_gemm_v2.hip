@@ -287,6 +287,8 @@ static void launch_v2(const a3d_conv_desc *d, hipStream_t s) {
     const int nblk = mtiles * ntiles;
     const int kt_total = d->Kpad / BKT;
     const int kps = (kt_total + d->splitk - 1) / d->splitk;
+    a3d_note_variant("conv_gemm_v2_kernel<%d,%d,%d,%d,%d,%d,%d> %dx%d%s", WAVES_M, WAVES_N, TM, TN, MODE, PIPE, BKT, BM, BN,
+                     MODE == MODE_STEM ? " stem" : (MODE == MODE_UPS ? " ups" : (d->phase ? " ups-phase" : "")));
     hipLaunchKernelGGL((conv_gemm_v2_kernel<WAVES_M, WAVES_N, TM, TN, MODE, PIPE, BKT>), dim3(nblk, d->splitk), dim3(WAVES_M * WAVES_N * 64), 0,
                        s, *d, M, ntiles, nblk, kt_total, kps);
 }

@@ -178,6 +178,7 @@ void launch_pw(const a3d_conv_desc *d, hipStream_t s, int per_cu) {
     const int total = mtiles * ntiles;
     int grid = 256 * per_cu;  // MI355X: 256 CUs
     if (grid > total) grid = total;
+    a3d_note_variant("conv_pw_kernel<%d,%d,%d> %dx%d persistent", TM, TN, BKT, BM, BN);
     hipLaunchKernelGGL((conv_pw_kernel<TM, TN, BKT>), dim3(grid), dim3(256), 0, s, *d, M, ntiles, total);
 }
 }  // namespace

@@ -582,6 +582,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
         const int nt = (d->Cout + 63) / 64;
+        a3d_note_variant("wino_gemm_x3_kernel");
         hipLaunchKernelGGL(wino_gemm_x3_kernel, dim3(mtiles * nt), dim3(256), 0, s, a, nt, mtiles * nt);
         return A3D_OK;
     }
@@ -594,6 +595,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     const int bn = tn * 64;
     const int ntiles = (d->Cout + bn - 1) / bn;
     const dim3 grid(mtiles * ntiles);
+    a3d_note_variant("wino_gemm_kernel<%d,%d>", tn, bk32 ? 32 : 16);
     // ping-pong accumulators (PP) whenever a plane has an even number of 32-deep k-chunks; tune % 10 >= 2 turns it off (A/B)
     if (tn == 1 && !bk32) hipLaunchKernelGGL((wino_gemm_kernel<1, 16>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);
     else if (tn == 1) hipLaunchKernelGGL((wino_gemm_kernel<1, 32>), grid, dim3(256), 0, s, a, ntiles, mtiles * ntiles);

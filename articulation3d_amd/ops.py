@@ -21,7 +21,9 @@ GROUP_CAP = 1024
 
 # Optional per-launch timing of the conv-GEMM kernel (bench.py's roofline leg): when a list is installed
 # here, conv2d() brackets its launch with HIP events on the launch stream and appends
-# (tile_config, algorithmic_flops, start_event, end_event).
+# (kernel variant as recorded by the dispatcher, algorithmic_flops, start_event, end_event, shape, executed_flops).
+# executed_flops = multiply-adds the kernel actually issues on the matrix pipe x2 (Winograd F(2x2,3x3): 16 per 2x2 output
+# tile and channel pair instead of 36; phase convs of an upsampled 3x3: 4 taps instead of 9).
 CONV_TIMING: Optional[list] = None
 
 # Arithmetic of conv2d() calls that do not ask for one: 0 = fp32 MFMA (the parity path, default), 1 = bf16 MFMA with fp32
@@ -35,22 +37,10 @@ CONV_TIMING: Optional[list] = None
 DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "0"))
 
 
-def conv_tile_config(p: "PackedConv", M: int, ups: bool = False, pw_ok: bool = True) -> str:
-    """Mirror of the variant selection in csrc/conv_gemm_v2.hip:a3d_conv_launch_v2 (kernel template arguments
-    <WAVES_M,WAVES_N,TM,TN,MODE,PIPE,BK> as they appear in a rocprofv3 kernel trace)."""
-    if p.stem:
-        return "conv_gemm_v2<2,2,2,1,stem,bk32> 128x64"
-    n128 = ((M + 127) // 128) * ((p.cols + 127) // 128)
-    if (p.KH * p.KW == 1 and p.stride == 1 and not ups and not p.pixshuf and not p.phase and p.Kpad == p.Cin and p.Kpad <= 2048
-            and p.cols >= 64 and pw_ok):  # mirror of csrc/conv_pw.hip:a3d_conv_launch_pw
-        if p.cols <= 64 or n128 <= 1000:
-            if ((M + 127) // 128) * ((p.cols + 63) // 64) >= 2 * 256 * 4:
-                return "conv_pw<2,1> 128x64 bk16 persistent"
-        elif n128 >= 2 * 256 * 3:
-            return "conv_pw<2,2> 128x128 bk16 persistent"
-    cfg = 2 if p.cols <= 32 else (1 if (p.cols <= 64 or n128 <= 1000) else 0)
-    bk = 32 if (p.KH * p.KW == 1 and p.Kpad >= 8192) or cfg == 2 else 16
-    return {0: "conv_gemm_v2<2,2,2,2> 128x128", 1: "conv_gemm_v2<2,2,2,1> 128x64", 2: "conv_gemm_v2<4,1,1,1> 128x32"}[cfg] + f" bk{bk}"
+def last_conv_variant() -> str:
+    """Kernel instantiation dispatched by the calling thread's last conv launch (a3d_last_conv_variant, include/a3d.h):
+    the dispatcher's own record, e.g. "conv_pw_kernel<2,2,16> 128x128 persistent"."""
+    return _lib.lib().a3d_last_conv_variant().decode()
 
 
 def _stream() -> int:
@@ -307,22 +297,18 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             e1.record()
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()
-            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape))
-            CONV_TIMING.append(("wino_gemm_x3_kernel" if d.precision == 2 else "wino_gemm_kernel<1,32>", 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape))
+            tiles = B * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0))
+            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin))
             return out
         e0, e1 = ev(), ev()
         e0.record()
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
-        fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else 2.0 * B * Ho * Wo * p.cols * k_real
-        pw_ok = x2 is None and splitk == 1 and m_dev is None and tune in (0, 6)
-        name = conv_tile_config(p, B * Ho * Wo, ups, pw_ok) + (" ups-phase" if p.phase else "")
-        if d.precision == 2:
-            name = "conv_x3<%d> 128x%d bk16 (3-way bf16 split, 6 MFMAs per k step)" % ((1, 64) if (p.cols <= 64 or ((B * Ho * Wo + 127) // 128) * ((p.cols + 127) // 128) <= 500) else (2, 128))
-        if d.precision == 1:
-            name = "conv_bf16<%d> 128x%d bk32 (bf16 MFMA)" % ((1, 64) if (p.cols <= 64 or ((B * Ho * Wo + 127) // 128) * ((p.cols + 127) // 128) <= 1000) else (2, 128))
-        CONV_TIMING.append((name, fl, e0, e1, shape))
+        executed = 2.0 * B * Ho * Wo * p.cols * k_real
+        fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

@@ -10,7 +10,7 @@ Backend: torch.distributed "nccl" (= RCCL over xGMI on ROCm), "gloo" on CPU for 
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,9 +23,10 @@ def shard_range(num_frames: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + per, num_frames)
 
 
-def gather_records(records: torch.Tensor, rec_count: torch.Tensor):
-    """records [B,R,F] fp32, rec_count [B] int32 (this rank's block) -> ([G*B,R,F], [G*B]) on every rank."""
-    return gather_records_async(records, rec_count).wait()
+def gather_records(records: torch.Tensor, rec_count: torch.Tensor, rows: Optional[int] = None):
+    """records [B,R,F] fp32, rec_count [B] int32 (this rank's block) -> ([G*rows,R,F], [G*rows]) on every rank
+    (rows = B when not given: see gather_records_async for the equal-block contract)."""
+    return gather_records_async(records, rec_count, rows).wait()
 
 
 class GatherHandle:
@@ -42,13 +43,38 @@ class GatherHandle:
         return self._out
 
 
-def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor) -> GatherHandle:
+_blocks_verified = False
+
+
+def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: Optional[int] = None) -> GatherHandle:
     """Starts the all-gather of one batch's detection records without blocking the launch stream: the detector's next
-    batch is enqueued while the records travel over xGMI (one collective per batch, overlapped with compute)."""
+    batch is enqueued while the records travel over xGMI (one collective per batch, overlapped with compute).
+
+    `all_gather_into_tensor` needs the SAME block size on every rank, while `shard_range` hands out uneven blocks
+    whenever F % world != 0 (10 frames on 4 ranks: 3,3,3,1).  Pass `rows` = ceil(F / world): the block is zero-padded to
+    that many frames (count 0) before it travels.  Without `rows` the caller guarantees equal blocks; the first call of a
+    process verifies that with one small synchronous all-gather of the block sizes and raises on a mismatch (instead of
+    hanging in RCCL); later calls trust the same batching."""
+    global _blocks_verified
     if not (dist.is_available() and dist.is_initialized()):
         return GatherHandle(records, rec_count, [], None)
     G = dist.get_world_size()
     rec, cnt = records.contiguous(), rec_count.contiguous()
+    if rows is not None:
+        if rec.shape[0] > rows:
+            raise ValueError(f"block of {rec.shape[0]} frames does not fit rows={rows}")
+        if rec.shape[0] < rows:
+            pad = rows - rec.shape[0]
+            rec = torch.cat([rec, rec.new_zeros((pad,) + tuple(rec.shape[1:]))])
+            cnt = torch.cat([cnt, cnt.new_zeros((pad,))])
+    if not _blocks_verified:
+        mine = torch.tensor([rec.shape[0]], device=rec.device, dtype=torch.int64)
+        sizes = torch.empty((G,), device=rec.device, dtype=torch.int64)
+        dist.all_gather_into_tensor(sizes, mine)
+        sizes = sizes.tolist()
+        if len(set(sizes)) != 1:
+            raise ValueError(f"gather_records: ranks hold blocks of {sizes} frames; pass rows=ceil(F/world) to pad them")
+        _blocks_verified = True
     all_rec = torch.empty((G * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
     all_cnt = torch.empty((G * cnt.shape[0],), device=cnt.device, dtype=cnt.dtype)
     w1 = dist.all_gather_into_tensor(all_cnt, cnt, async_op=True)

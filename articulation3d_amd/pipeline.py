@@ -65,7 +65,7 @@ def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, wit
     dev = model.device
     R = model.roi_heads.box_predictor.test_topk_per_image
     rec_f = ops.record_floats(28)
-    # fixed-size block per rank so the gather is one collective
+    # fixed-size block per rank so the gather is one collective (uneven shards are zero-padded to `per` frames)
     block_rec = torch.zeros((per, R, rec_f), device=dev)
     block_cnt = torch.zeros((per,), device=dev, dtype=torch.int32)
     for s in range(lo, hi, batch):
@@ -73,7 +73,7 @@ def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, wit
         out = model.inference_batched(frames[s:e].to(dev, non_blocking=True).contiguous())
         block_rec[s - lo:e - lo] = out.records
         block_cnt[s - lo:e - lo] = out.rec_count
-    all_rec, all_cnt = gather_records(block_rec, block_cnt)
+    all_rec, all_cnt = gather_records(block_rec, block_cnt, rows=per)
     return instances_from_records(all_rec, all_cnt, [(r * per + i) for r in range(world) for i in range(shard_range(F_, r, world)[1] - shard_range(F_, r, world)[0])],
                                   hw, conf_threshold, with_masks)
 

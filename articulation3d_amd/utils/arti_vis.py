@@ -28,8 +28,25 @@ OFFSET_X, OFFSET_Y = 319.5, 239.5
 
 
 def load_checkpoint(model: torch.nn.Module, path: str) -> None:
-    """`exps/model_final.pth` format: {"model": state_dict} with detectron2 parameter names."""
-    ckpt = torch.load(path, map_location="cpu")
+    """`exps/model_final.pth` format: {"model": state_dict} with detectron2 parameter names (what DetectionCheckpointer
+    writes and the reference's DefaultPredictor loads, arti_vis.py:48).  Like DetectionCheckpointer.load, a missing file is
+    an error -- never a silent random initialisation."""
+    if path.startswith(("detectron2://", "catalog://", "http://", "https://")):
+        raise ValueError(f"MODEL.WEIGHTS={path!r}: model-zoo / remote checkpoints are not resolvable here (no network, no fvcore "
+                         "path manager); download the file and point MODEL.WEIGHTS at it")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"MODEL.WEIGHTS={path!r} does not exist (pass load_weights=False / --random-init for an explicit "
+                                "random initialisation)")
+    if path.endswith(".pkl"):
+        raise ValueError(f"MODEL.WEIGHTS={path!r}: Caffe2 / model-zoo .pkl files carry legacy parameter names and need detectron2's "
+                         "c2 name conversion, which is not part of this path; convert to a .pth {'model': state_dict} first")
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # detectron2 trainer checkpoints can hold arbitrary pickled objects next to "model"
+        if os.environ.get("A3D_TRUSTED_CHECKPOINT") != "1":
+            raise RuntimeError(f"checkpoint {path} is not a plain tensor archive ({type(e).__name__}: {e}); set "
+                               "A3D_TRUSTED_CHECKPOINT=1 to unpickle it fully if you trust its origin") from e
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in sd.items()}
     missing, unexpected = model.load_state_dict(sd, strict=False)
@@ -40,15 +57,14 @@ def load_checkpoint(model: torch.nn.Module, path: str) -> None:
 
 class DefaultPredictor:
     """The part of detectron2's DefaultPredictor the reference uses: `.model` in eval mode with weights
-    loaded (arti_vis.py:48,60)."""
+    loaded (arti_vis.py:48,60).  `load_weights=False` is the ONLY way to get a random initialisation: a non-empty
+    cfg.MODEL.WEIGHTS that cannot be loaded raises."""
 
     def __init__(self, cfg, load_weights: bool = True):
         self.cfg = cfg.clone()
         self.model = build_model(self.cfg)
         self.model.eval()
-        import os
-
-        if load_weights and cfg.MODEL.WEIGHTS and os.path.exists(cfg.MODEL.WEIGHTS):
+        if load_weights and cfg.MODEL.WEIGHTS:
             load_checkpoint(self.model, cfg.MODEL.WEIGHTS)
 
 
@@ -87,7 +103,7 @@ def instances_to_coco_json(instances: Instances, img_id) -> List[dict]:
 
 
 class PlaneRCNN_Branch:
-    def __init__(self, cfg, cpu_device="cpu"):
+    def __init__(self, cfg, cpu_device="cpu", load_weights: bool = True):
         # The host side of the per-frame loop is small tensor glue (RLE, json, record building).  With torch's default
         # intra-op pool (one OpenMP worker per core, 128-256 on an MI355X host) the workers spin after every tiny CPU op
         # and starve the HIP runtime's own threads: measured 40-70 ms stalls of the next frame every few frames (31 fps
@@ -95,7 +111,7 @@ class PlaneRCNN_Branch:
         n = int(os.environ.get("A3D_HOST_THREADS", "8"))
         if n > 0 and torch.get_num_threads() > n:
             torch.set_num_threads(n)
-        self.predictor = DefaultPredictor(cfg)
+        self.predictor = DefaultPredictor(cfg, load_weights=load_weights)
         self._cpu_device = cpu_device
         self._device = torch.device(cfg.MODEL.DEVICE)
         self._K_inv_dot_xy_1 = torch.FloatTensor(get_K_inv_dot_xy_1()).to(self._device)

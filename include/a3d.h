@@ -115,6 +115,10 @@ int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols,
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */
 int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream);
 int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
+/* The kernel instantiation the LAST conv launch of the calling thread dispatched, as it appears in a rocprofv3 kernel trace
+ * ("conv_pw_kernel<2,2,16> 128x128 persistent", "wino_gemm_kernel<1,32>", ...); "" before the first launch.  For measurement
+ * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules. */
+const char *a3d_last_conv_variant(void);
 
 /* Max-pool 3x3 stride 2 pad 1 (ResNet stem) and kernel-1 stride-2 pool (FPN LastLevelMaxPool = p6). */
 int a3d_maxpool3x3s2_nhwc(const float *x, float *y, int B, int H, int W, int C, void *stream);

@@ -71,6 +71,56 @@ void orc_roi_align_nchw(const float *feat, int N, int C, int H, int W, const flo
 }
 
 /*
+ * The same operator in double precision: the float64 YARDSTICK of oracle/exact.py (how far the fp32 CPU path and the
+ * HIP path each are from the exactly evaluated graph).  Identical control flow, every float replaced by double.
+ */
+static inline double bilinear_f64(const double *p, int H, int W, double y, double x) {
+    if (y < -1.0 || y > (double)H || x < -1.0 || x > (double)W) return 0.0;
+    if (y <= 0.0) y = 0.0;
+    if (x <= 0.0) x = 0.0;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (double)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (double)xl; } else xh = xl + 1;
+    double ly = y - (double)yl, lx = x - (double)xl, hy = 1.0 - ly, hx = 1.0 - lx;
+    return hy * hx * p[yl * W + xl] + hy * lx * p[yl * W + xh] + ly * hx * p[yh * W + xl] + ly * lx * p[yh * W + xh];
+}
+
+void orc_roi_align_nchw_f64(const double *feat, int N, int C, int H, int W, const double *rois, int K,
+                            int P, double scale, int sampling_ratio, int aligned, double *out) {
+    (void)N;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int k = 0; k < K; ++k) {
+        const double *r = rois + (size_t)k * 5;
+        int b = (int)r[0];
+        double off = aligned ? 0.5 : 0.0;
+        double x1 = r[1] * scale - off, y1 = r[2] * scale - off;
+        double x2 = r[3] * scale - off, y2 = r[4] * scale - off;
+        double rw = x2 - x1, rh = y2 - y1;
+        if (!aligned) { rw = fmax(rw, 1.0); rh = fmax(rh, 1.0); }
+        double bh = rh / (double)P, bw = rw / (double)P;
+        int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceil(rh / (double)P);
+        int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceil(rw / (double)P);
+        double count = (double)(gh * gw > 1 ? gh * gw : 1);
+        for (int c = 0; c < C; ++c) {
+            const double *plane = feat + ((size_t)b * C + c) * H * W;
+            double *o = out + ((size_t)k * C + c) * P * P;
+            for (int ph = 0; ph < P; ++ph)
+                for (int pw = 0; pw < P; ++pw) {
+                    double acc = 0.0;
+                    for (int iy = 0; iy < gh; ++iy) {
+                        double y = y1 + ph * bh + ((double)iy + 0.5) * bh / (double)gh;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            double x = x1 + pw * bw + ((double)ix + 0.5) * bw / (double)gw;
+                            acc += bilinear_f64(plane, H, W, y, x);
+                        }
+                    }
+                    o[ph * P + pw] = acc / count;
+                }
+        }
+    }
+}
+
+/*
  * Greedy NMS, Appendix A.6.  boxes: n x 4 xyxy ALREADY in score-descending order;
  * cat: n category ids (suppression only within equal ids).  keep[i] = 1 if kept.
  */

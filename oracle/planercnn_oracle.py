@@ -371,7 +371,7 @@ def grid_anchors(Hf, Wf, stride, size, ratios):
 
 def apply_deltas(deltas, boxes, weights, scale_clamp):
     """Box2BoxTransform.apply_deltas (A.5). deltas: N x (k*4), boxes: N x 4."""
-    deltas = deltas.float()
+    deltas = deltas if deltas.dtype == torch.float64 else deltas.float()  # (float64: oracle/exact.py's yardstick run)
     boxes = boxes.to(deltas.dtype)
     widths = boxes[:, 2] - boxes[:, 0]
     heights = boxes[:, 3] - boxes[:, 1]
@@ -481,13 +481,14 @@ def rpn_select_level(logits_l, deltas_l, Hf, Wf, stride, size, cfg: OracleCfg, i
     return idx, sc, bc, fin & ne
 
 
-def rpn_select(logits, deltas, feat_hw, image_sizes, cfg: OracleCfg, return_groups=False):
-    """find_top_rpn_proposals (A.5) on given head outputs.  logits[l] [N,HWA], deltas[l] [N,HWA,4]."""
+def rpn_select(logits, deltas, feat_hw, image_sizes, cfg: OracleCfg, return_groups=False, sources: Optional[list] = None):
+    """find_top_rpn_proposals (A.5) on given head outputs.  logits[l] [N,HWA], deltas[l] [N,HWA,4].
+    `sources` (optional list) receives per image the (level [R], anchor index [R]) of every kept proposal."""
     names = ("p2", "p3", "p4", "p5", "p6")
     N = logits[0].shape[0]
     out, groups = [], []
     for n in range(N):
-        bs, ss, ls, gl = [], [], [], []
+        bs, ss, ls, gl, ai = [], [], [], [], []
         for li, name in enumerate(names[: len(logits)]):
             Hf, Wf = feat_hw[li]
             idx, sc, bc, valid = rpn_select_level(logits[li][n], deltas[li][n], Hf, Wf, FPN_STRIDES[name],
@@ -496,18 +497,21 @@ def rpn_select(logits, deltas, feat_hw, image_sizes, cfg: OracleCfg, return_grou
             bs.append(bc[valid])
             ss.append(sc[valid])
             ls.append(torch.full((int(valid.sum()),), li, dtype=torch.int64))
+            ai.append(idx[valid])
         b, s_, l = torch.cat(bs), torch.cat(ss), torch.cat(ls)
         keep = batched_nms(b, s_, l, cfg.rpn_nms_thresh)[: cfg.rpn_post_topk]
         out.append((b[keep], s_[keep]))
+        if sources is not None:
+            sources.append((l[keep], torch.cat(ai)[keep]))
         groups.append(gl)
     return (out, groups) if return_groups else out
 
 
-def rpn_proposals(feats, P, image_sizes, cfg: OracleCfg):
+def rpn_proposals(feats, P, image_sizes, cfg: OracleCfg, sources: Optional[list] = None):
     """-> list per image of (proposal_boxes Rx4, objectness_logits R)."""
     logits, deltas = rpn_head(feats, P)
     names = ("p2", "p3", "p4", "p5", "p6")
-    return rpn_select(logits, deltas, [tuple(feats[n].shape[-2:]) for n in names], image_sizes, cfg)
+    return rpn_select(logits, deltas, [tuple(feats[n].shape[-2:]) for n in names], image_sizes, cfg, sources=sources)
 
 
 # --------------------------------------------------------------------------------------
@@ -522,6 +526,14 @@ def assign_levels(boxes: torch.Tensor, min_level=2, max_level=5, canon_size=224,
 
 
 def roi_align(feat: torch.Tensor, rois: torch.Tensor, P: int, scale: float, ratio: int, aligned: bool):
+    if feat.dtype == torch.float64:  # the float64 yardstick of oracle/exact.py: same algorithm, double arithmetic
+        feat, rois = feat.contiguous(), rois.contiguous().double()
+        out = torch.empty(rois.shape[0], feat.shape[1], P, P, dtype=torch.float64)
+        if rois.shape[0]:
+            _lib().orc_roi_align_nchw_f64(
+                ctypes.c_void_p(feat.data_ptr()), *feat.shape, ctypes.c_void_p(rois.data_ptr()), rois.shape[0], P,
+                ctypes.c_double(scale), int(ratio), int(bool(aligned)), ctypes.c_void_p(out.data_ptr()))
+        return out
     feat = feat.contiguous().float()
     rois = rois.contiguous().float()
     N, C, H, W = feat.shape
@@ -806,24 +818,28 @@ def override_depth(depth: torch.Tensor, masks: torch.Tensor, planes: torch.Tenso
 # the whole per-frame path: planercnn.py:148-184 + arti_vis.py:54-87
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
-def detect(images_chw: List[torch.Tensor], P, cfg: Optional[OracleCfg] = None, given_boxes=None, return_aux=False):
+def detect(images_chw: List[torch.Tensor], P, cfg: Optional[OracleCfg] = None, given_boxes=None, return_aux=False, features=None):
     """images: list of CHW float32 BGR 0-255.  Returns list[dict] (one per image) with
     pred_boxes, scores, pred_classes, pred_masks (bool HxW), pred_plane, pred_rot_axis,
-    pred_tran_axis, depth, plus 'plane_offset' = process()'s overridden planes."""
+    pred_tran_axis, depth, plus 'plane_offset' = process()'s overridden planes.
+    `features` (optional) replaces the backbone output: the stability search (oracle/seed_search.py) re-runs everything
+    behind the backbone on perturbed feature maps."""
     cfg = cfg or OracleCfg()
     x, sizes = preprocess(images_chw, cfg)
-    feats = backbone(x, P)
+    feats = backbone(x, P) if features is None else features
     aux = {"features": feats}
     if given_boxes is None:
-        props = rpn_proposals(feats, P, sizes, cfg)
+        src = []
+        props = rpn_proposals(feats, P, sizes, cfg, sources=src)
         dets, box_aux = box_inference(feats, props, P, sizes, cfg)
-        aux.update(proposals=props, box=box_aux)
+        aux.update(proposals=props, box=box_aux, proposal_sources=src)
     else:  # forward_with_given_boxes entry, roi_heads.py:147
         dets = [(b.float(), torch.ones(len(b)), torch.zeros(len(b), dtype=torch.int64), torch.arange(len(b))) for b in given_boxes]
     depth = depth_head(feats, P) if cfg.depth_on else [None] * len(sizes)
     boxes = [d[0] for d in dets]
     nper = [len(b) for b in boxes]
-    results = [dict(pred_boxes=d[0], scores=d[1], pred_classes=d[2], image_size=sz) for d, sz in zip(dets, sizes)]
+    # (prop_rows: the proposal each detection came from -- bookkeeping for oracle/exact.py, not a reference field)
+    results = [dict(pred_boxes=d[0], scores=d[1], pred_classes=d[2], prop_rows=d[3], image_size=sz) for d, sz in zip(dets, sizes)]
     if cfg.mask_on:
         m = mask_head(roi_pool_fpn(feats, boxes, *cfg.mask_pool), P)
         for r, mm in zip(results, m.split(nper)):

@@ -71,6 +71,51 @@ def test_gather_records_gloo_world2():
     assert res == [(0, True), (1, True)]
 
 
+def _uneven_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from articulation3d_amd.parallel import gather_records, shard_range
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F_, R, REC = 10, 2, 798  # 10 frames on 4 ranks: blocks of 3, 3, 3, 1 (pipeline.detect_clip's padding path)
+    per = (F_ + world - 1) // world
+    lo, hi = shard_range(F_, rank, world)
+    rec = torch.zeros(hi - lo, R, REC)
+    cnt = torch.ones(hi - lo, dtype=torch.int32)
+    for i, f in enumerate(range(lo, hi)):
+        rec[i, 0, 4] = float(f)
+    ok = True
+    try:  # without `rows` the uneven blocks are refused with an error on every rank instead of a hang
+        gather_records(rec, cnt)
+        ok = False
+    except ValueError as e:
+        ok = "rows=" in str(e)
+    all_rec, all_cnt = gather_records(rec, cnt, rows=per)
+    ok = ok and all_rec.shape == (world * per, R, REC) and all_cnt.shape == (world * per,)
+    slots = [r * per + i for r in range(world) for i in range(shard_range(F_, r, world)[1] - shard_range(F_, r, world)[0])]
+    ok = ok and [float(all_rec[s, 0, 4]) for s in slots] == [float(f) for f in range(F_)] and all_cnt[slots].tolist() == [1] * F_
+    ok = ok and int(all_cnt.sum()) == F_  # padded slots carry count 0
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_uneven_shards_gloo_world4():
+    """F % world != 0 (10 frames / 4 ranks -> 3,3,3,1) must be padded, or refused loudly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(4)]
+
+
 def test_gather_records_single_process_is_identity():
     from articulation3d_amd.parallel import gather_records
 

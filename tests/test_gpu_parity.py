@@ -105,12 +105,9 @@ def test_persistent_pointwise_kernel(ops, Cin, Cout, res_mode):
     w = torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5
     bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-5)
     pk = ops.pack_conv(w, None, bn, 1, 0, ops.ACT_RELU)
-    if Cout > 64:
-        assert "conv_pw" in ops.conv_tile_config(pk, B * H * W)
-    else:  # 64-wide layers need more rows for two rounds of the persistent grid
+    if Cout <= 64:  # 64-wide layers need more rows for two rounds of the persistent grid
         B = 14
         x = torch.randn(B, Cin, H, W)
-        assert "conv_pw" in ops.conv_tile_config(pk, B * H * W)
     xd = nhwc(x).cuda()
     kw, ref = {}, F.batch_norm(F.conv2d(x, w), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
     if res_mode == "res":
@@ -122,7 +119,9 @@ def test_persistent_pointwise_kernel(ops, Cin, Cout, res_mode):
         kw, ref = dict(res=nhwc(r).cuda(), res_ups=True), ref + F.interpolate(r, scale_factor=2.0, mode="nearest")
     ref = F.relu(ref)
     y = ops.conv2d(xd, pk, precision=0, **kw)  # (explicit: the suite can be run with A3D_PRECISION=2, and this is fp32 kernel vs fp32 kernel)
+    assert ops.last_conv_variant().startswith("conv_pw_kernel<"), ops.last_conv_variant()  # what the dispatcher launched
     y5 = ops.conv2d(xd, pk, tune=5, **kw)
+    assert ops.last_conv_variant().startswith("conv_gemm_v2_kernel<"), ops.last_conv_variant()
     assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
     assert rel(ops.conv2d(xd, pk, **kw).permute(0, 3, 1, 2), ref) < 5e-6  # whatever arithmetic the session default selects
     assert torch.equal(y, y5)

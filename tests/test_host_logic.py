@@ -245,3 +245,29 @@ def test_track_planes_associates_by_iou_and_filters_short_tracks():
     # a jump breaks the association -> two short tracks, both filtered
     preds[7].pred_boxes = Boxes(torch.tensor([[300.0, 300.0, 400.0, 400.0]]))
     assert len(track_planes(preds[:9])["rot"]) == 0
+
+
+def test_checkpoint_loading_is_never_silent(tmp_path):
+    """a missing / unsupported MODEL.WEIGHTS raises; only load_weights=False gives random init."""
+    import pytest
+    import torch
+
+    from articulation3d_amd.utils.arti_vis import load_checkpoint
+
+    m = torch.nn.Linear(4, 2)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(m, str(tmp_path / "model_final.pth"))
+    with pytest.raises(ValueError):
+        load_checkpoint(m, "detectron2://ImageNetPretrained/MSRA/R-50.pkl")
+    pkl = tmp_path / "R-50.pkl"
+    pkl.write_bytes(b"x")
+    with pytest.raises(ValueError):
+        load_checkpoint(m, str(pkl))
+    good = tmp_path / "ok.pth"
+    torch.save({"model": {"weight": torch.ones(2, 4), "bias": torch.zeros(2)}}, good)
+    load_checkpoint(m, str(good))
+    assert float(m.weight.sum()) == 8.0
+    bad = tmp_path / "partial.pth"
+    torch.save({"model": {"weight": torch.ones(2, 4)}}, bad)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(m, str(bad))

@@ -1,0 +1,132 @@
+"""Known-answer vectors for the un-vendored third-party operators (tests/golden/third_party_known_answers.json): the
+only independent pin the oracle of backbone-side operators can get (detectron2 / torchvision / pytorch3d are
+absent from /root/reference, which holds no tests of its own).  CPU part: the oracle's C and Python statements; GPU part
+(-m gpu): the HIP kernels behind the C ABI on the same vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KA = json.load(open(os.path.join(ROOT, "tests", "golden", "third_party_known_answers.json")))
+
+
+def _roi_input(c):
+    H, W = c["input_hw"]
+    if c["input"].startswith("arange"):
+        return torch.arange(H * W, dtype=torch.float32).reshape(H, W)
+    if c["input"].startswith("full"):
+        return torch.full((H, W), float(c["input"][5:-1]))
+    return torch.arange(W, dtype=torch.float32)[None, :].expand(H, W).contiguous()  # ramp_x
+
+
+def _roi_expected(c):
+    P = c["output_size"]
+    if "expected" in c:
+        return torch.tensor(c["expected"], dtype=torch.float32)
+    if "expected_constant" in c:
+        return torch.full((P, P), c["expected_constant"])
+    return torch.tensor(c["expected_row"], dtype=torch.float32)[None, :].expand(P, P)
+
+
+@pytest.mark.parametrize("i", range(len(KA["roi_align"])))
+def test_oracle_roi_align_known_answers(oracle, i):
+    c = KA["roi_align"][i]
+    x = _roi_input(c)[None, None]
+    rois = torch.tensor([[0.0] + [float(v) for v in c["box_xyxy"]]])
+    want = _roi_expected(c)
+    for fn in (oracle.roi_align, oracle.roi_align_py):  # C statement and the slow Python statement
+        got = fn(x, rois, c["output_size"], c["spatial_scale"], c["sampling_ratio"], c["aligned"])[0, 0]
+        assert torch.allclose(got, want, atol=1e-5), (fn.__name__, got, want)
+    got64 = oracle.roi_align(x.double(), rois.double(), c["output_size"], c["spatial_scale"], c["sampling_ratio"], c["aligned"])[0, 0]
+    assert torch.allclose(got64, want.double(), atol=1e-12)  # the float64 twin used by oracle/exact.py
+
+
+def test_oracle_anchor_known_answer(oracle):
+    c = KA["anchors"][0]
+    cell = torch.cat([oracle.cell_anchors(s, c["ratios"]) for s in c["sizes"]])  # size-major, ratio-minor
+    H, W = c["grid_hw"]
+    got = torch.cat([cell + torch.tensor([x * c["stride"], y * c["stride"]] * 2, dtype=torch.float32) for y in range(H) for x in range(W)])
+    assert torch.equal(got, torch.tensor(c["expected"]))
+    # and the per-level grid function the oracle / kernels use: (y, x, anchor) order with one size per level
+    g = oracle.grid_anchors(H, W, c["stride"], c["sizes"][0], c["ratios"])
+    assert torch.equal(g, torch.tensor(c["expected"])[[0, 1, 2, 6, 7, 8]])
+
+
+def test_oracle_nms_known_answers(oracle):
+    for c in KA["nms"]:
+        b = torch.tensor(c["boxes"], dtype=torch.float32)
+        s = torch.tensor(c["scores"])
+        cats = torch.tensor(c.get("categories", [0] * len(s)))
+        assert oracle.batched_nms(b, s, cats, c["threshold"]).tolist() == c["expected_keep"], c["source"]
+        assert oracle.nms_sorted_py(b, cats, c["threshold"]).nonzero().squeeze(1).tolist() == c["expected_keep"]
+
+
+def test_oracle_apply_deltas_known_answers(oracle):
+    from oracle import train_oracle as T
+
+    c = KA["apply_deltas"][0]
+    got = oracle.apply_deltas(torch.tensor(c["deltas"]), torch.tensor(c["boxes"], dtype=torch.float32), c["weights"], c["scale_clamp"])
+    assert torch.allclose(got, torch.tensor(c["expected"]), atol=2e-4), got
+    c = KA["apply_deltas"][1]
+    src, dst = torch.tensor(c["src"]), torch.tensor(c["dst"])
+    rec = oracle.apply_deltas(T.get_deltas(src, dst, c["weights"]), src, c["weights"], 1e9)
+    assert torch.allclose(rec, dst, atol=1e-4)
+
+
+def test_oracle_level_assignment_and_matcher_known_answers(oracle):
+    from oracle import train_oracle as T
+
+    c = KA["level_assignment"][0]
+    assert oracle.assign_levels(torch.tensor(c["boxes"], dtype=torch.float32)).tolist() == c["expected"]
+    c = KA["matcher"][0]
+    m, l = T.matcher(torch.tensor(c["quality"]), c["thresholds"], c["labels"], c["allow_low_quality"])
+    assert m.tolist() == c["expected_matches"] and l.tolist() == c["expected_labels"]
+
+
+def test_oracle_axis_angle_known_answers():
+    from oracle import opt_oracle as OO
+
+    c = KA["axis_angle_to_matrix"][0]
+    got = OO.axis_angle_to_matrix(np.asarray(c["axis_angles"]))
+    assert np.allclose(got, np.asarray(c["expected"], dtype=np.float64), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ HIP kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(KA["roi_align"])))
+def test_hip_roi_align_known_answers(i):
+    from articulation3d_amd import ops
+
+    c = KA["roi_align"][i]
+    x = _roi_input(c)
+    C = 256  # lane = 4 channels: channel k carries (k+1) * map, every channel is checked
+    gain = torch.arange(1, C + 1, dtype=torch.float32)
+    feat = (x[:, :, None] * gain).contiguous()[None].cuda()  # NHWC [1,H,W,C]
+    boxes = torch.tensor([[c["box_xyxy"]]], dtype=torch.float32).cuda()
+    out = ops.roi_align_fpn([feat], [c["spatial_scale"]], boxes, None, c["output_size"], c["sampling_ratio"], c["aligned"])
+    want = _roi_expected(c)[:, :, None] * gain
+    assert torch.allclose(out[0].cpu(), want, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_nms_and_level_known_answers():
+    from articulation3d_amd import ops
+
+    for c in KA["nms"]:
+        if "categories" in c:  # groups ARE categories in the kernel: one group per category, checked through the merge in test_gpu_parity
+            continue
+        n = len(c["boxes"])
+        gb = torch.zeros(1, ops.GROUP_CAP, 4)
+        gb[0, :n] = torch.tensor(c["boxes"], dtype=torch.float32)  # already score-descending
+        gv = torch.zeros(1, ops.GROUP_CAP, dtype=torch.int32)
+        gv[0, :n] = 1
+        keep = ops.group_nms(gb.cuda(), gv.cuda(), torch.tensor([n], dtype=torch.int32).cuda(), c["threshold"])
+        assert keep[0, :n].cpu().nonzero().squeeze(1).tolist() == c["expected_keep"], c["source"]
+    c = KA["level_assignment"][0]
+    boxes = torch.tensor([c["boxes"]], dtype=torch.float32).cuda()  # [1, R, 4]
+    feats = [torch.zeros(1, 8, 8, 4).cuda() for _ in range(4)]
+    _, lvl = ops.roi_align_fpn(feats, [0.25, 0.125, 0.0625, 0.03125], boxes, None, 2, 2, True, want_level=True)
+    assert lvl.cpu().tolist() == c["expected"]

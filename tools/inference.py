@@ -67,8 +67,17 @@ def main():
     ap.add_argument("--conf-threshold", default=0.7, type=float)
     ap.add_argument("--batch", default=32, type=int, help="frames per detector batch per GPU")
     ap.add_argument("--calibrate-bn", action="store_true", help="random-init weights only: estimate batch-norm statistics on the clip")
+    ap.add_argument("--random-init", action="store_true",
+                    help="do NOT load cfg.MODEL.WEIGHTS: explicit random initialisation (plumbing runs; a missing checkpoint is otherwise an error)")
+    ap.add_argument("--dist-backend", default="nccl", help="torchrun only: nccl (= RCCL over xGMI) or gloo")
+    ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides, e.g. MODEL.DEVICE cuda:0")
     args = ap.parse_args()
-    os.makedirs(args.output, exist_ok=True)
+
+    # one process per GPU under torchrun (frames sharded by pipeline.detect_clip, ONE all-gather of the records per clip):
+    # rank / device / process group are set up before anything touches the GPU; rank 0 alone tracks, optimises and writes
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        os.makedirs(args.output, exist_ok=True)
 
     from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
     from articulation3d_amd.pipeline import detect_clip
@@ -79,7 +88,23 @@ def main():
     cfg = get_cfg()
     get_planercnn_cfg_defaults(cfg)
     cfg.merge_from_file(args.config)
-    branch = PlaneRCNN_Branch(cfg)
+    if args.opts:
+        cfg.merge_from_list(args.opts)
+    if not str(cfg.MODEL.DEVICE).startswith("cuda"):
+        raise SystemExit(f"MODEL.DEVICE={cfg.MODEL.DEVICE!r}: this package is the MI355X (HIP) implementation of the detection path and has "
+                         "no CPU fallback; the CPU statement of the same graph lives in oracle/ as the test checker")
+    if world > 1:
+        import torch.distributed as dist
+
+        n_dev = torch.cuda.device_count()  # (does not initialise HIP)
+        cfg.MODEL.DEVICE = f"cuda:{local_rank % max(n_dev, 1)}"
+        torch.cuda.set_device(local_rank % max(n_dev, 1))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(cfg.MODEL.DEVICE))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
+    branch = PlaneRCNN_Branch(cfg, load_weights=not args.random_init)
     model = branch.predictor.model
     frames_rgb = read_frames(args.input)
     frames_bgr = np.ascontiguousarray(frames_rgb[..., ::-1])
@@ -88,6 +113,13 @@ def main():
 
         calibrate_batchnorm(model, torch.from_numpy(frames_bgr[:2]).to(model.device))
     preds = detect_clip(model, frames_bgr, batch=args.batch, conf_threshold=args.conf_threshold)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:  # every rank holds the gathered detections; the temporal stage and the files are rank 0's
+            return
     planes = track_planes(preds)
     opt_preds = optimize_planes(preds, planes, "3dc", frames=frames_rgb)
 
