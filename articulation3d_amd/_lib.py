@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("gate", fptr),
         ("precision", C.c_int),
         ("w_wino_x3", fptr),
+        ("w_wino_cm", fptr),
     ]
 
 
@@ -178,6 +179,8 @@ SIGNATURES = {
     "a3d_struct_size": (C.c_size_t, [C.c_int]),
     "a3d_preprocess_u8hwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
     "a3d_preprocess_f32chw": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), fptr]),
+    "a3d_preprocess_resize_u8": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),

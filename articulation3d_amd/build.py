@@ -23,6 +23,7 @@ SOURCES = {
     "conv_gemm.hip": [],
     "conv_gemm_v2.hip": [],
     "conv_wino.hip": [],
+    "conv_wino_fused.hip": [],
     "conv_pw.hip": [],
     "conv_bf16.hip": [],
     "conv_bf16x3.hip": [],

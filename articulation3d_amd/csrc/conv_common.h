@@ -117,3 +117,6 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
 int a3d_wino_eligible(const a3d_conv_desc *d);
 size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d);
 int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s);
+// One-launch Winograd (conv_wino_fused.hip): input transform inside the GEMM loader; needs a3d_conv_desc.w_wino_cm.
+int a3d_wino_fused_eligible(const a3d_conv_desc *d);
+int a3d_conv_launch_wino_fused(const a3d_conv_desc *d, hipStream_t s);

@@ -238,7 +238,8 @@ extern "C" const char *a3d_last_conv_variant(void) { return g_last_variant; }
 
 extern "C" size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d) {
     if (!d) return 0;
-    if ((d->tune == 0 || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
+    if (d->tune == 0 && a3d_wino_fused_eligible(d)) return 0;
+    if ((d->tune == 0 || d->tune == 7 || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
     if (d->splitk <= 1) return 0;
     return (size_t)d->splitk * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
@@ -275,7 +276,8 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
         return a3d_conv_launch_bf16x3(d, s);
     }
     if (d->precision != 0) return A3D_ERR_ARG;
-    if ((d->tune == 0 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+    if (d->tune == 0 && a3d_wino_fused_eligible(d)) return a3d_conv_launch_wino_fused(d, s);  // one launch, no V tensor (tune 7: the two-launch form)
+    if ((d->tune == 0 || d->tune == 7 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
     if (d->tune == 0 || d->tune == 6) {  // persistent pointwise kernel for the 1x1 layers (tune 5: never, 6: whenever eligible)
         const int r1 = a3d_conv_launch_pw(d, s, d->tune == 6);
         if (r1 != A3D_ERR_UNSUPPORTED) return r1;

@@ -52,6 +52,74 @@ extern "C" int a3d_preprocess_f32chw(const float *images, float *out, int B, int
     return a3d_check_launch();
 }
 
+// ---- input front end: cv2.resize(frame, (Wd, Hd)) + channel flip + (x - mean)/std in one pass -----------
+// Replaces the host-side `cv2.resize(im, (640, 480))` + `im[:, :, ::-1]` of the reference's frame loop
+// (tools/inference.py:216-218) together with the uint8 -> float cast and normalisation (arti_vis.py:58, planercnn.py:188-196).
+// cv2.resize on uint8 with the default INTER_LINEAR is OpenCV's fixed-point bilinear (imgproc/resize.cpp, as published):
+//   fx = (float)((dx + 0.5) * (Ws / Wd) - 0.5);  sx = floor(fx);  fx -= sx;  clamped to the image with fx = 0 at the borders;
+//   11-bit coefficients a = cvRound(w * 2048) (round half to even);  horizontal pass in int32, then
+//   dst = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+//   an exact 2x2 decimation is switched to INTER_AREA: (s00 + s01 + s10 + s11 + 2) >> 2;  equal sizes copy.
+// HBM-bound byte work: one thread per output pixel reads 4 source pixels x 3 bytes and writes one float4 (+ 3 bytes).
+__global__ __launch_bounds__(256) void preprocess_resize_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+                                                                   uint8_t *__restrict__ out_u8, int B, int Hs, int Ws, int Hd, int Wd,
+                                                                   int swap_rb, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const size_t npix = (size_t)B * Hd * Wd;
+    const double scale_x = (double)Ws / Wd, scale_y = (double)Hs / Hd;
+    const bool same = Hs == Hd && Ws == Wd, area2 = Hs == 2 * Hd && Ws == 2 * Wd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % Wd);
+        const size_t r = i / Wd;
+        const int dy = (int)(r % Hd), b = (int)(r / Hd);
+        const uint8_t *src = in + (size_t)b * Hs * Ws * 3;
+        int v[3];
+        if (same) {
+            const uint8_t *p = src + ((size_t)dy * Ws + dx) * 3;
+            v[0] = p[0], v[1] = p[1], v[2] = p[2];
+        } else if (area2) {
+            const uint8_t *p = src + ((size_t)(2 * dy) * Ws + 2 * dx) * 3, *q = p + (size_t)Ws * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (p[c] + p[3 + c] + q[c] + q[3 + c] + 2) >> 2;
+        } else {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5), fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sx = (int)floorf(fx), sy = (int)floorf(fy);
+            fx -= (float)sx;
+            fy -= (float)sy;
+            if (sx < 0) fx = 0.f, sx = 0;
+            if (sx >= Ws - 1) fx = 0.f, sx = Ws - 1;
+            if (sy < 0) fy = 0.f, sy = 0;
+            if (sy >= Hs - 1) fy = 0.f, sy = Hs - 1;
+            const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+            const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+            const int sx1 = min(sx + 1, Ws - 1), sy1 = min(sy + 1, Hs - 1);
+            const uint8_t *p00 = src + ((size_t)sy * Ws + sx) * 3, *p01 = src + ((size_t)sy * Ws + sx1) * 3;
+            const uint8_t *p10 = src + ((size_t)sy1 * Ws + sx) * 3, *p11 = src + ((size_t)sy1 * Ws + sx1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int r0 = p00[c] * a0 + p01[c] * a1, r1 = p10[c] * a0 + p11[c] * a1;
+                v[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            }
+        }
+        if (out_u8) {  // the resized frame in the SOURCE channel order (what the reference keeps in `frames`, inference.py:217)
+            uint8_t *o = out_u8 + i * 3;
+            o[0] = (uint8_t)v[0], o[1] = (uint8_t)v[1], o[2] = (uint8_t)v[2];
+        }
+        const int c0 = swap_rb ? v[2] : v[0], c2 = swap_rb ? v[0] : v[2];
+        f32x4 o4 = {((float)c0 - m0) / s0, ((float)v[1] - m1) / s1, ((float)c2 - m2) / s2, 0.f};
+        *reinterpret_cast<f32x4 *>(out + i * 4) = o4;
+    }
+}
+
+extern "C" int a3d_preprocess_resize_u8(const uint8_t *frames, float *out, uint8_t *out_u8, int B, int Hs, int Ws, int Hd, int Wd,
+                                        int swap_rb, const float mean[3], const float std[3], void *stream) {
+    if (!frames || !out || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return A3D_ERR_ARG;
+    const size_t npix = (size_t)B * Hd * Wd;
+    a3d_begin();
+    hipLaunchKernelGGL(preprocess_resize_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, frames, out, out_u8, B, Hs,
+                       Ws, Hd, Wd, swap_rb, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+    return a3d_check_launch();
+}
+
 // ---- max-pool 3x3 s2 p1 -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
                                                            int H, int W, int C4, int Ho, int Wo) {

@@ -82,10 +82,19 @@ class PlaneRCNN(nn.Module):
 
     # ------------------------------------------------------------------ MI355X throughput path
     @torch.no_grad()
-    def inference_batched(self, frames: torch.Tensor, want_masks: bool = False, given_boxes=None) -> BatchedOutput:
-        """frames: uint8 [B,H,W,3] BGR (device) or float32 [B,3,H,W] 0-255 BGR."""
+    def inference_batched(self, frames: torch.Tensor, want_masks: bool = False, given_boxes=None, source_rgb: bool = False,
+                          resize_to=(480, 640)) -> BatchedOutput:
+        """frames: uint8 [B,H,W,3] BGR (device) or float32 [B,3,H,W] 0-255 BGR.
+        source_rgb=True: uint8 [B,Hs,Ws,3] straight from the reader -- RGB, any size -- and the reference loop's
+        `cv2.resize(im, (640, 480))` + `im[:, :, ::-1]` (tools/inference.py:216-218) run fused with the normalisation in
+        `a3d_preprocess_resize_u8`."""
         assert not self.training
-        if frames.dtype == torch.uint8:
+        if source_rgb:
+            assert frames.dtype == torch.uint8 and self.input_format == "BGR"
+            B = frames.shape[0]
+            H, W = int(resize_to[0]), int(resize_to[1])
+            x4 = ops.preprocess_resize_u8(frames.contiguous(), self.pixel_mean, self.pixel_std, (H, W), swap_rb=True)
+        elif frames.dtype == torch.uint8:
             B, H, W, _ = frames.shape
             x4 = ops.preprocess_u8hwc(frames.contiguous(), self.pixel_mean, self.pixel_std)
         else:

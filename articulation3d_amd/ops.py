@@ -79,6 +79,7 @@ class PackedConv:
     stem: bool = False
     w_wino: Optional[torch.Tensor] = None  # [16, cols, Cin] Winograd-domain weights (3x3 s1 p1 convs)
     w_wino_x3: Optional[torch.Tensor] = None  # [16, Cin/32, 3, cols, 32] bf16 planes of w_wino, made at the first precision-2 use
+    w_wino_cm: Optional[torch.Tensor] = None  # [Cin/8, 16, cols, 8] chunk-major copy of w_wino: the one-launch Winograd kernel
     phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
 
     @property
@@ -124,7 +125,9 @@ def pack_conv(weight: torch.Tensor, bias=None, bn=None, stride=1, pad=0, act=ACT
     dev = lambda t: None if t is None else t.contiguous().to(device)
     pk = PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 16 == 0:
-        pk.w_wino = dev(winograd_weights(_pad_rows(weight.detach().float())))
+        U = winograd_weights(_pad_rows(weight.detach().float()))
+        pk.w_wino = dev(U)
+        pk.w_wino_cm = dev(winograd_weights_chunk_major(U))
     return pk
 
 
@@ -166,6 +169,20 @@ def winograd_weights(weight: torch.Tensor) -> torch.Tensor:
     G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
     U = torch.einsum("up,ncpq,vq->uvnc", G, weight.double(), G)
     return U.reshape(16, weight.shape[0], weight.shape[1]).float().contiguous()
+
+
+def winograd_weights_chunk_major(U: torch.Tensor) -> torch.Tensor:
+    """U [16, Cout, C] -> a3d_conv_desc.w_wino_cm, the one-launch Winograd kernel's weight image:
+    [C/8][16 planes][ceil(Cout/64) tiles][k half 2][channel half 2][row 16][k pair 2][channel block 2][2], i.e. element
+    (chunk c, plane f, output channel n = 64 t + 32 ch + 16 nb + row, input channel k = 8 c + 4 h + 2 g + j).  One (chunk, plane,
+    tile) is a contiguous 2 KiB run that the kernel copies to LDS verbatim; Cout is zero-padded to a multiple of 64."""
+    f, n, c = U.shape
+    nt = (n + 63) // 64
+    Up = U.new_zeros((f, nt * 64, c))
+    Up[:, :n] = U
+    #        f   t   ch nb row  c/8   h  g  j
+    v = Up.view(f, nt, 2, 2, 16, c // 8, 2, 2, 2)
+    return v.permute(5, 0, 1, 6, 2, 4, 7, 3, 8).contiguous()
 
 
 def pack_stem(weight: torch.Tensor, bn, device="cuda") -> PackedConv:
@@ -251,7 +268,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
-    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune == 0 or tune >= 200) and not ups
+    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7) or tune >= 200) and not ups
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
         mode = DEFAULT_PRECISION if precision is None else 2
@@ -276,20 +293,33 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()
+        if p.w_wino_cm is not None and d.precision == 0 and tune == 0:
+            d.w_wino_cm = p.w_wino_cm.data_ptr()  # the library then takes the one-launch kernel where the layer qualifies
         if d.precision == 2:
             if p.w_wino_x3 is None or p.w_wino_x3.device != p.w_wino.device:  # once per layer
                 rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
                 p.w_wino_x3 = torch.empty((16, cols // 32, 3, rows, 32), device=p.w_wino.device, dtype=torch.bfloat16)
                 _lib.check(_lib.lib().a3d_split_bf16x3(p.w_wino.data_ptr(), p.w_wino_x3.data_ptr(), 16, rows, cols, _stream()), "a3d_split_bf16x3")
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
+    fused_wino = False
     if use_wino or splitk > 1:
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
-        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-        d.workspace = ws.data_ptr()
+        fused_wino = use_wino and nbytes == 0  # the one-launch Winograd kernel needs no V tensor
+        if nbytes:
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+            d.workspace = ws.data_ptr()
     if CONV_TIMING is not None:
         k_real = 147 if p.stem else p.KH * p.KW * p.Cin
         shape = f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"
         ev = lambda: torch.cuda.Event(enable_timing=True)
+        tiles = B * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+        if fused_wino:
+            e0, e1 = ev(), ev()
+            e0.record()
+            _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+            e1.record()
+            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin))
+            return out
         if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
@@ -297,7 +327,6 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             e1.record()
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()
-            tiles = B * ((Ho + 1) // 2) * ((Wo + 1) // 2)
             CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0))
             CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin))
             return out
@@ -350,6 +379,20 @@ def preprocess_u8hwc(frames: torch.Tensor, mean, std) -> torch.Tensor:
     _lib.check(_lib.lib().a3d_preprocess_u8hwc(frames.data_ptr(), out.data_ptr(), B, H, W, _f3(mean), _f3(std), _stream()),
                "a3d_preprocess_u8hwc")
     return out
+
+
+def preprocess_resize_u8(frames: torch.Tensor, mean, std, out_hw=(480, 640), swap_rb: bool = True, want_u8: bool = False):
+    """frames uint8 [B,Hs,Ws,3] in the reader's channel order (RGB from imageio) -> NHWC4 fp32 [B,Hd,Wd,4] normalised in the
+    flipped order (BGR), as cv2.resize + [:, :, ::-1] + float + (x - mean)/std (tools/inference.py:216-218); optionally also
+    the resized uint8 frames in the source order."""
+    _req(frames, torch.uint8)
+    B, Hs, Ws, _ = frames.shape
+    Hd, Wd = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((B, Hd, Wd, 4), device=frames.device, dtype=torch.float32)
+    u8 = torch.empty((B, Hd, Wd, 3), device=frames.device, dtype=torch.uint8) if want_u8 else None
+    _lib.check(_lib.lib().a3d_preprocess_resize_u8(frames.data_ptr(), out.data_ptr(), _p(u8), B, Hs, Ws, Hd, Wd, int(bool(swap_rb)),
+                                                   _f3(mean), _f3(std), _stream()), "a3d_preprocess_resize_u8")
+    return (out, u8) if want_u8 else out
 
 
 def preprocess_f32chw(images: torch.Tensor, mean, std) -> torch.Tensor:

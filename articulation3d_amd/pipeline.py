@@ -50,9 +50,13 @@ def instances_from_record(rec: torch.Tensor, image_size, conf_threshold: float =
 
 
 @torch.no_grad()
-def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, with_masks: bool = True) -> List[Instances]:
+def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, with_masks: bool = True, source_rgb: bool = False,
+                resize_to=(480, 640)) -> List[Instances]:
     """frames: uint8 [F,H,W,3] BGR (numpy or tensor).  Returns the detections of ALL F frames in temporal order on every
-    rank (single process: plain batching)."""
+    rank (single process: plain batching).
+    source_rgb=True: frames are what the video reader hands over -- RGB, any size; the reference's host-side
+    `cv2.resize(im, (640, 480))` and BGR flip (tools/inference.py:216-218) then run on the device, fused with the
+    normalisation in front of the stem (a3d_preprocess_resize_u8)."""
     if isinstance(frames, np.ndarray):
         frames = torch.from_numpy(frames)
     F_ = frames.shape[0]
@@ -61,7 +65,7 @@ def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, wit
     world = torch.distributed.get_world_size() if dist_on else 1
     per = (F_ + world - 1) // world
     lo, hi = shard_range(F_, rank, world)
-    hw = tuple(frames.shape[1:3])
+    hw = tuple(resize_to) if source_rgb else tuple(frames.shape[1:3])
     dev = model.device
     R = model.roi_heads.box_predictor.test_topk_per_image
     rec_f = ops.record_floats(28)
@@ -70,7 +74,7 @@ def detect_clip(model, frames, batch: int = 32, conf_threshold: float = 0.7, wit
     block_cnt = torch.zeros((per,), device=dev, dtype=torch.int32)
     for s in range(lo, hi, batch):
         e = min(s + batch, hi)
-        out = model.inference_batched(frames[s:e].to(dev, non_blocking=True).contiguous())
+        out = model.inference_batched(frames[s:e].to(dev, non_blocking=True).contiguous(), source_rgb=source_rgb, resize_to=resize_to)
         block_rec[s - lo:e - lo] = out.records
         block_cnt[s - lo:e - lo] = out.rec_count
     all_rec, all_cnt = gather_records(block_rec, block_cnt, rows=per)

@@ -47,6 +47,14 @@ int a3d_preprocess_u8hwc(const uint8_t *frames /*[B,H,W,3]*/, float *out, int B,
 int a3d_preprocess_f32chw(const float *images /*[B,3,H,W]*/, float *out, int B, int H, int W,
                           const float mean[3], const float std[3], void *stream);
 
+/* Input front end: frames of any size, uint8 HWC in the reader's channel order, to the detector's input in ONE
+ * pass: `cv2.resize(im, (Wd, Hd))` (tools/inference.py:216; OpenCV's fixed-point INTER_LINEAR on uint8, the 2x2 INTER_AREA
+ * switch at an exact 2x decimation, plain copy at equal sizes) + the RGB -> BGR flip `im[:, :, ::-1]` (:218, swap_rb = 1) +
+ * float cast + (x - mean[c]) / std[c] (arti_vis.py:58, planercnn.py:188-196).  out [B,Hd,Wd,4] fp32 (channel 3 = 0), mean / std in
+ * the OUTPUT channel order; out_u8 (optional) [B,Hd,Wd,3] = the resized frame in the source order (the reference's `frames` list). */
+int a3d_preprocess_resize_u8(const uint8_t *frames /*[B,Hs,Ws,3]*/, float *out, uint8_t *out_u8, int B, int Hs, int Ws, int Hd, int Wd,
+                             int swap_rb, const float mean[3], const float std[3], void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused convolution / linear as an fp32-MFMA implicit GEMM.
  * Replaces every Conv2d / Linear / ConvTranspose2d reached on the path:
@@ -103,6 +111,12 @@ typedef struct a3d_conv_desc {
     const void *w_wino_x3; /* precision 2 on a Winograd layer: w_wino split into three bf16 planes, chunk-major
                             [16][(Cin+Cin2)/32][3][Cout][32] (a3d_split_bf16x3 with outer = 16, rows = Cout, cols = Cin+Cin2);
                             the layer then runs F(2x2,3x3) with the split-operand GEMM                                */
+    const float *w_wino_cm; /* optional: the Winograd-domain weights chunk-major in the one-launch kernel's LDS-image order,
+                            [Cin/8][16][ceil(Cout/64)][2 h][2 ch][16 row][2 g][2 nb][2 j] = w_wino[f][64 t + 32 ch + 16 nb + row]
+                            [8 c + 4 h + 2 g + j], zero for channels past Cout (ops.winograd_weights_chunk_major).
+                            With it a plain 3x3 s1 p1 layer (one source, no upsampling, precision 0, tune 0) runs
+                            the ONE-launch Winograd kernel that transforms the input inside the GEMM loader
+                            (csrc/conv_wino_fused.hip): no workspace, no 16-plane tensor in HBM                          */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);

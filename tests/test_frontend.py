@@ -1,0 +1,83 @@
+"""Input front end: cv2.resize(im, (640, 480)) + BGR flip + normalise (tools/inference.py:216-218).
+CPU part: the oracle's restatement of OpenCV's published fixed-point bilinear (parity unpinned: cv2 is absent here) checked
+through properties; GPU part: `a3d_preprocess_resize_u8` bit-exact against it, edge sizes included."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.resize_oracle import cv2_resize_linear_u8, frontend
+
+MEAN, STD = (103.53, 116.28, 123.675), (1.0, 1.0, 1.0)
+SIZES = [(480, 640), (960, 1280), (720, 1280), (1080, 1920), (97, 131), (240, 320), (481, 639), (1, 1), (2, 3)]
+
+
+def _img(h, w, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def _float_bilinear(img, Wd, Hd):
+    Hs, Ws = img.shape[:2]
+    fx, fy = (np.arange(Wd) + 0.5) * Ws / Wd - 0.5, (np.arange(Hd) + 0.5) * Hs / Hd - 0.5
+    x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+    wx, wy = np.where((x0 < 0) | (x0 >= Ws - 1), 0, fx - x0), np.where((y0 < 0) | (y0 >= Hs - 1), 0, fy - y0)
+    x0c, x1c, y0c, y1c = np.clip(x0, 0, Ws - 1), np.clip(x0 + 1, 0, Ws - 1), np.clip(y0, 0, Hs - 1), np.clip(y0 + 1, 0, Hs - 1)
+    I = img.astype(np.float64)
+    top = I[y0c][:, x0c] * (1 - wx)[None, :, None] + I[y0c][:, x1c] * wx[None, :, None]
+    bot = I[y1c][:, x0c] * (1 - wx)[None, :, None] + I[y1c][:, x1c] * wx[None, :, None]
+    return top * (1 - wy)[:, None, None] + bot * wy[:, None, None]
+
+
+@pytest.mark.parametrize("hw", SIZES)
+def test_resize_oracle_properties(hw):
+    im = _img(*hw)
+    out = cv2_resize_linear_u8(im, (640, 480))
+    assert out.shape == (480, 640, 3) and out.dtype == np.uint8
+    if hw == (480, 640):
+        assert np.array_equal(out, im)  # equal sizes: copy
+    elif hw == (960, 1280):  # exact 2x: INTER_AREA fast path = rounded 2x2 mean
+        assert np.array_equal(out, np.floor(im.reshape(480, 2, 640, 2, 3).astype(np.float64).mean((1, 3)) + 0.5).astype(np.uint8))
+    else:  # fixed-point bilinear stays within one grey level of the real-valued bilinear interpolation
+        assert np.abs(out.astype(np.float64) - _float_bilinear(im, 640, 480)).max() <= 1.0
+    const = np.full(hw + (3,), 137, dtype=np.uint8)
+    assert (cv2_resize_linear_u8(const, (640, 480)) == 137).all()  # partition of unity survives the 11-bit coefficients
+    assert out.min() >= im.min() and out.max() <= im.max()
+
+
+def test_frontend_oracle_layout():
+    x, res = frontend(_img(97, 131)[None], MEAN, STD)
+    assert x.shape == (1, 480, 640, 3) and res.shape == (1, 480, 640, 3)
+    assert np.array_equal(x[0, ..., 0] + np.float32(MEAN[0]), res[0, ..., 2].astype(np.float32))  # output channel 0 = B = source channel 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", SIZES)
+def test_hip_resize_frontend_bit_exact(hw):
+    from articulation3d_amd import ops
+
+    frames = np.stack([_img(*hw, seed=s) for s in (1, 2)])
+    x4, u8 = ops.preprocess_resize_u8(torch.from_numpy(frames).cuda(), MEAN, STD, (480, 640), swap_rb=True, want_u8=True)
+    want_x, want_u8 = frontend(frames, MEAN, STD)
+    assert torch.equal(u8.cpu(), torch.from_numpy(want_u8))  # integer arithmetic: bit-exact
+    assert torch.equal(x4[..., :3].cpu(), torch.from_numpy(want_x)) and float(x4[..., 3].abs().sum()) == 0
+    # equal size + no swap == the plain normalisation kernel
+    if hw == (480, 640):
+        a = ops.preprocess_resize_u8(torch.from_numpy(frames).cuda(), MEAN, STD, (480, 640), swap_rb=False)
+        assert torch.equal(a, ops.preprocess_u8hwc(torch.from_numpy(frames).cuda(), MEAN, STD))
+
+
+@pytest.mark.gpu
+def test_detect_clip_from_reader_frames_equals_host_side_resize(hip_model, oracle):
+    """The fused front end changes nothing downstream: raw RGB 720p frames through detect_clip(source_rgb=True) == the same frames
+    resized + flipped on the host (oracle restatement of cv2.resize) through the uint8 BGR entry."""
+    from articulation3d_amd.pipeline import detect_clip
+
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.0
+    raw = np.stack([_img(720, 1280, seed=s) for s in (5, 6, 7)])
+    a = detect_clip(model, raw, batch=2, conf_threshold=0.35, source_rgb=True)
+    host = np.ascontiguousarray(np.stack([cv2_resize_linear_u8(f, (640, 480)) for f in raw])[..., ::-1])
+    b = detect_clip(model, host, batch=2, conf_threshold=0.35)
+    assert len(a) == len(b) == 3
+    for p, q in zip(a, b):
+        assert len(p) == len(q) > 0 and torch.equal(p.pred_boxes.tensor, q.pred_boxes.tensor) and torch.equal(p.pred_masks, q.pred_masks)
+        assert torch.equal(p.pred_planes, q.pred_planes)

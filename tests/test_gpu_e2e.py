@@ -79,7 +79,7 @@ def test_matched_detections_end_to_end(hip_model, oracle, oracle_params, golden_
     for s, m in zip(report["seeds"], vs32):  # discrete identity + boxes / scores, frame by frame
         assert m["same_count"], (s, m)
         assert m["classes_equal"], (s, m)
-        assert m["box_err_px"] <= M.TOL["box_px"] and m["score_err"] <= M.TOL["score"], (s, m)
+        assert m["box_err_px"] <= M.TOL["box_px"] and m["score_err"] <= M.TOL["score"] and m["matched"], (s, m)
     for k in CONT[2:]:  # the yardstick: as close to the exact evaluation as the reference's own fp32 arithmetic
         hip, cpu = sh["max_" + k], sc["max_" + k]
         assert hip <= max(1e-4, K_YARD * cpu), (k, hip, cpu)

@@ -271,3 +271,20 @@ def test_checkpoint_loading_is_never_silent(tmp_path):
     torch.save({"model": {"weight": torch.ones(2, 4)}}, bad)
     with pytest.raises(RuntimeError):
         load_checkpoint(m, str(bad))
+
+
+def test_torch_ops_are_registered_without_a_cpu_kernel():
+    """north_star: the kernels are PyTorch custom ops.  Schemas exist on import; there is no CPU implementation to fall back to."""
+    import pytest
+    import torch
+
+    import articulation3d_amd  # noqa: F401
+    from articulation3d_amd import torch_ops
+
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.a3d, name), name
+    schema = str(torch.ops.a3d.roi_align_fpn.default._schema)
+    assert "Tensor[] feats" in schema and "bool aligned" in schema
+    with pytest.raises((NotImplementedError, RuntimeError)) as e:
+        torch.ops.a3d.group_nms(torch.zeros(1, 1024, 4), torch.zeros(1, 1024, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), 0.5)
+    assert "CPU" in str(e.value)

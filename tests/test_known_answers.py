@@ -130,3 +130,37 @@ def test_hip_nms_and_level_known_answers():
     feats = [torch.zeros(1, 8, 8, 4).cuda() for _ in range(4)]
     _, lvl = ops.roi_align_fpn(feats, [0.25, 0.125, 0.0625, 0.03125], boxes, None, 2, 2, True, want_level=True)
     assert lvl.cpu().tolist() == c["expected"]
+
+
+@pytest.mark.gpu
+def test_torch_ops_give_the_same_bits_as_the_ctypes_wrappers():
+    """torch.ops.a3d.* are the same launches as articulation3d_amd.ops.* (VERDICT r1 item 8)."""
+    import articulation3d_amd  # noqa: F401
+    from articulation3d_amd import ops
+
+    torch.manual_seed(3)
+    feats = [torch.randn(2, 120 >> l, 160 >> l, 256).cuda() for l in range(4)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    xy = torch.rand(2, 50, 2) * torch.tensor([400.0, 300.0])
+    wh = torch.rand(2, 50, 2) * 200 + 4
+    boxes = torch.cat([xy, xy + wh], -1).cuda()
+    count = torch.tensor([50, 31], dtype=torch.int32).cuda()
+    a = torch.ops.a3d.roi_align_fpn(feats, scales, boxes, count, 7, 0, True)
+    b = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True)
+    live = torch.cat([torch.arange(50), 50 + torch.arange(31)])
+    assert torch.equal(a[live], b[live])
+    gb = torch.zeros(2, ops.GROUP_CAP, 4).cuda()
+    gb[:, :50] = boxes
+    gv = torch.zeros(2, ops.GROUP_CAP, dtype=torch.int32).cuda()
+    gv[:, :50] = 1
+    gn = torch.tensor([50, 50], dtype=torch.int32).cuda()
+    assert torch.equal(torch.ops.a3d.group_nms(gb, gv, gn, 0.5), ops.group_nms(gb, gv, gn, 0.5))
+    x = torch.randn(2, 24, 40, 64).cuda()
+    w = torch.randn(256, 64, 1, 1) / 8
+    pk = ops.pack_conv(w, torch.randn(256), None, 1, 0, ops.ACT_RELU)
+    y = torch.ops.a3d.conv2d_fused(x, pk.w, pk.scale, pk.shift, None, None, 1, 1, 1, 0, ops.ACT_RELU)
+    assert torch.equal(y, ops.conv2d(x, pk))
+    w3 = torch.randn(64, 64, 3, 3) / 24
+    pk3 = ops.pack_conv(w3, None, None, 1, 1, ops.ACT_NONE)
+    y3 = torch.ops.a3d.conv2d_fused(x, pk3.w, None, None, None, pk3.w_wino, 3, 3, 1, 1, ops.ACT_NONE)  # Winograd-domain weights -> Winograd path
+    assert torch.equal(y3, ops.conv2d(x, pk3)) and ops.last_conv_variant().startswith("wino_gemm")

@@ -10,9 +10,10 @@ optimiser's sweeps run on the GPU.  `random.seed(2020)` / `np.random.seed(2020)`
 
 Input (this image has no video decoder: cv2 / imageio are absent, so .mp4 is refused with a clear message):
   * a .npy / .npz file with uint8 frames [F,H,W,3] in RGB order (what imageio would hand over), or
-  * a directory of .png / .jpg frames (read with PIL, sorted by name), or
-  * `synthetic:N` -- N seeded random frames (plumbing check).
-Frames are resized to 640x480 (bilinear) and flipped to BGR like the reference (:216-218).
+  * a directory of .png / .jpg frames (decoded with PIL, sorted by name), or
+  * `synthetic:N` / `synthetic:NxHxW` -- N seeded random frames (plumbing check), optionally at a source size H x W.
+The frames go to the GPU as they come from the reader (uint8 RGB, any size): the reference's `cv2.resize(im, (640, 480))` and
+BGR flip (:216-218) run on the device, fused with the normalisation in front of the stem (a3d_preprocess_resize_u8).
 Output: <output>/predictions.json -- per frame the optimised detections (bbox xyxy, score, class, plane, rotation /
 translation axis, RLE mask) and <output>/tracks.json (tracked planes, has_rot, consensus axis).  The 2-D / 3-D
 visualisations of the reference (imageio video, pytorch3d meshes) are out of scope.
@@ -33,12 +34,15 @@ sys.path.insert(0, ROOT)
 
 
 def read_frames(path: str) -> np.ndarray:
+    """-> uint8 [F,Hs,Ws,3] RGB at the SOURCE size (no host-side resize)."""
     from PIL import Image
 
     if path.startswith("synthetic:"):
         from articulation3d_amd.utils.synthetic import synthetic_frames
 
-        return synthetic_frames(int(path.split(":")[1]))[..., ::-1].copy()  # stored BGR -> RGB, flipped back below
+        spec = path.split(":")[1].split("x")
+        n, h, w = int(spec[0]), (int(spec[1]) if len(spec) == 3 else 480), (int(spec[2]) if len(spec) == 3 else 640)
+        return synthetic_frames(n, h=h, w=w)[..., ::-1].copy()  # generated BGR -> RGB, flipped back on the device
     if path.endswith((".mp4", ".avi", ".mov")):
         raise SystemExit("no video decoder in this environment (cv2 / imageio absent): pass a .npy of RGB frames or a directory of images")
     if path.endswith(".npy"):
@@ -52,9 +56,7 @@ def read_frames(path: str) -> np.ndarray:
     else:
         frames = np.asarray(Image.open(path).convert("RGB"))[None]
     assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8, "frames must be uint8 [F,H,W,3]"
-    if frames.shape[1:3] != (480, 640):
-        frames = np.stack([np.asarray(Image.fromarray(f).resize((640, 480), Image.BILINEAR)) for f in frames])
-    return frames
+    return np.ascontiguousarray(frames)
 
 
 def main():
@@ -107,12 +109,13 @@ def main():
     branch = PlaneRCNN_Branch(cfg, load_weights=not args.random_init)
     model = branch.predictor.model
     frames_rgb = read_frames(args.input)
-    frames_bgr = np.ascontiguousarray(frames_rgb[..., ::-1])
     if args.calibrate_bn:
+        from articulation3d_amd import ops
         from articulation3d_amd.utils.synthetic import calibrate_batchnorm
 
-        calibrate_batchnorm(model, torch.from_numpy(frames_bgr[:2]).to(model.device))
-    preds = detect_clip(model, frames_bgr, batch=args.batch, conf_threshold=args.conf_threshold)
+        _x4, head = ops.preprocess_resize_u8(torch.from_numpy(frames_rgb[:2]).to(model.device), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), want_u8=True)
+        calibrate_batchnorm(model, head.flip(-1).contiguous())  # resized RGB -> BGR uint8
+    preds = detect_clip(model, frames_rgb, batch=args.batch, conf_threshold=args.conf_threshold, source_rgb=True)
     if world > 1:
         import torch.distributed as dist
 
@@ -139,7 +142,7 @@ def main():
     with open(os.path.join(args.output, "tracks.json"), "w") as f:
         json.dump(tracks, f)
     kept = sum(len(p.pred_boxes) for p in opt_preds)
-    print(f"{len(frames_bgr)} frames, {kept} detections above {args.conf_threshold}, "
+    print(f"{len(frames_rgb)} frames, {kept} detections above {args.conf_threshold}, "
           f"{len(planes['rot'])} rotation / {len(planes['trans'])} translation tracks -> {args.output}")
 
 
