@@ -76,7 +76,7 @@ class RoiAlignDesc(C.Structure):
         ("boxes", fptr), ("count", fptr), ("row_offset", fptr),
         ("B", C.c_int), ("R", C.c_int),
         ("P", C.c_int), ("sampling_ratio", C.c_int), ("aligned", C.c_int),
-        ("out", fptr), ("out_level", fptr),
+        ("out", fptr), ("out_level", fptr), ("order_ws", fptr),
     ]
 
 

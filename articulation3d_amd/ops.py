@@ -173,16 +173,16 @@ def winograd_weights(weight: torch.Tensor) -> torch.Tensor:
 
 def winograd_weights_chunk_major(U: torch.Tensor) -> torch.Tensor:
     """U [16, Cout, C] -> a3d_conv_desc.w_wino_cm, the one-launch Winograd kernel's weight image:
-    [C/8][16 planes][ceil(Cout/64) tiles][k half 2][channel half 2][row 16][k pair 2][channel block 2][2], i.e. element
-    (chunk c, plane f, output channel n = 64 t + 32 ch + 16 nb + row, input channel k = 8 c + 4 h + 2 g + j).  One (chunk, plane,
-    tile) is a contiguous 2 KiB run that the kernel copies to LDS verbatim; Cout is zero-padded to a multiple of 64."""
+    [C/8][16 planes][ceil(Cout/64) tiles][k half 2][channel 64][4], i.e. element (chunk c, plane f, output channel n = 64 t + r,
+    input channel k = 8 c + 4 h + j).  One (chunk, plane, tile, k half) is a contiguous 1 KiB run that the kernel moves to LDS
+    verbatim with one LDS-DMA instruction; Cout is zero-padded to a multiple of 64."""
     f, n, c = U.shape
     nt = (n + 63) // 64
     Up = U.new_zeros((f, nt * 64, c))
     Up[:, :n] = U
-    #        f   t   ch nb row  c/8   h  g  j
-    v = Up.view(f, nt, 2, 2, 16, c // 8, 2, 2, 2)
-    return v.permute(5, 0, 1, 6, 2, 4, 7, 3, 8).contiguous()
+    #        f   t   r  c/8   h  j
+    v = Up.view(f, nt, 64, c // 8, 2, 4)
+    return v.permute(3, 0, 1, 4, 2, 5).contiguous()
 
 
 def pack_stem(weight: torch.Tensor, bn, device="cuda") -> PackedConv:
@@ -546,6 +546,9 @@ def group_nms(g_boxes: torch.Tensor, g_valid: torch.Tensor, g_n: torch.Tensor, t
     return keep
 
 
+ROI_SPATIAL_ORDER = True  # walk every image's boxes in (level, y, x) order (schedule only: same output rows, same bits)
+
+
 def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor,
                   count: Optional[torch.Tensor], P: int, sampling_ratio: int, aligned: bool, *,
                   row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, want_level: bool = False,
@@ -570,6 +573,9 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     d.boxes, d.count, d.row_offset = boxes.data_ptr(), _p(count), _p(row_offset)
     d.B, d.R, d.P, d.sampling_ratio, d.aligned = B, R, int(P), int(sampling_ratio), int(bool(aligned))
     d.out, d.out_level = out.data_ptr(), _p(lvl)
+    # (measured, tools/roi_bench.py: -7 % on the 1000-proposal box pooler; the 100-detection poolers lose 3-5 % to the sort launch)
+    order = torch.empty((B * R,), device=dev, dtype=torch.int32) if (512 <= R <= 1024 and ROI_SPATIAL_ORDER) else None
+    d.order_ws = _p(order)
     _lib.check(_lib.lib().a3d_roi_align_fpn(C.byref(d), _stream()), "a3d_roi_align_fpn")
     return (out, lvl) if want_level else out
 

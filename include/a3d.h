@@ -112,8 +112,8 @@ typedef struct a3d_conv_desc {
                             [16][(Cin+Cin2)/32][3][Cout][32] (a3d_split_bf16x3 with outer = 16, rows = Cout, cols = Cin+Cin2);
                             the layer then runs F(2x2,3x3) with the split-operand GEMM                                */
     const float *w_wino_cm; /* optional: the Winograd-domain weights chunk-major in the one-launch kernel's LDS-image order,
-                            [Cin/8][16][ceil(Cout/64)][2 h][2 ch][16 row][2 g][2 nb][2 j] = w_wino[f][64 t + 32 ch + 16 nb + row]
-                            [8 c + 4 h + 2 g + j], zero for channels past Cout (ops.winograd_weights_chunk_major).
+                            [Cin/8][16][ceil(Cout/64)][2 h][64 r][4 j] = w_wino[f][64 t + r][8 c + 4 h + j], zero for channels
+                            past Cout (ops.winograd_weights_chunk_major).
                             With it a plain 3x3 s1 p1 layer (one source, no upsampling, precision 0, tune 0) runs
                             the ONE-launch Winograd kernel that transforms the input inside the GEMM loader
                             (csrc/conv_wino_fused.hip): no workspace, no 16-plane tensor in HBM                          */
@@ -225,6 +225,10 @@ typedef struct a3d_roialign_desc {
     int P, sampling_ratio, aligned;
     float *out;
     int *out_level; /* optional [rows] */
+    int *order_ws;  /* optional [B*R] int32 workspace (R <= 1024): the library first sorts every image's live boxes by (level, y, x)
+                       into it and walks them in that order, with each XCD taking whole images, so that workgroups running
+                       side by side touch neighbouring feature cells (L2 hits instead of re-fetches).  The OUTPUT rows do not
+                       move and the values are bit-identical to the unsorted walk: only the schedule changes. */
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);

@@ -63,6 +63,30 @@ def test_conv_gemm_vs_torch_fp32(ops, c):
     assert rel(y[..., : c["Cout"]].permute(0, 3, 1, 2), ref) < 5e-6  # fp32 MFMA vs fp32 oneDNN
 
 
+@pytest.mark.parametrize("shape", [(3, 60, 80, 64, 64), (2, 120, 160, 128, 256), (2, 61, 79, 32, 36), (5, 60, 80, 256, 96)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_winograd_is_bit_identical_to_the_two_launch_form(ops, shape):
+    """csrc/conv_wino_fused.hip (input transform inside the GEMM loader, 2-D tile blocks staged by LDS-DMA, 16 plane accumulators)
+    runs the same k order and the same transform expressions as wino_input_kernel + wino_gemm_kernel: equal bits, incl. odd image
+    sizes (partial tiles / blocks), Cout that is not a multiple of 64, every block shape, ReLU gate and LeakyReLU epilogues."""
+    B, H, W, Cin, Cout = shape
+    torch.manual_seed(5)
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-5)
+    pk = ops.pack_conv(w, None, bn, 1, 1, ops.ACT_LEAKY)
+    y1 = ops.conv2d(x, pk, precision=0)
+    assert ops.last_conv_variant().startswith("wino_fused_kernel"), ops.last_conv_variant()
+    y2 = ops.conv2d(x, pk, tune=7, precision=0)
+    assert ops.last_conv_variant().startswith("wino_gemm_kernel"), ops.last_conv_variant()
+    assert torch.equal(y1, y2)
+    ref = F.leaky_relu(F.batch_norm(F.conv2d(x.permute(0, 3, 1, 2).cpu(), w, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5), 0.01)
+    assert rel(y1[..., :Cout].permute(0, 3, 1, 2), ref) < 5e-6
+    gate = torch.randn(B, H, W, pk.cols, device="cuda")
+    pk.act = ops.ACT_RELU
+    assert torch.equal(ops.conv2d(x, pk, gate=gate, precision=0), ops.conv2d(x, pk, gate=gate, tune=7, precision=0))
+
+
 def test_conv_fused_epilogues(ops):
     torch.manual_seed(2)
     x = torch.randn(2, 64, 24, 40)

@@ -149,6 +149,22 @@ def test_torch_ops_give_the_same_bits_as_the_ctypes_wrappers():
     b = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True)
     live = torch.cat([torch.arange(50), 50 + torch.arange(31)])
     assert torch.equal(a[live], b[live])
+    # schedule-only options of the pooler leave every bit in place: spatial (level, y, x) walk of 600 boxes per image, and the
+    # one-load-at-a-time bin walk the batched form replaced
+    xy = torch.rand(2, 600, 2) * torch.tensor([560.0, 420.0])
+    wh = torch.rand(2, 600, 2) * torch.tensor([300.0, 220.0]) + 2
+    big = torch.cat([xy, xy + wh], -1).cuda()
+    cnt = torch.tensor([600, 333], dtype=torch.int32).cuda()
+    live = torch.cat([torch.arange(600), 600 + torch.arange(333)])
+    ref = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
+    ops.ROI_SPATIAL_ORDER = False
+    os.environ["A3D_ROI_SERIAL"] = "1"
+    try:
+        plain = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
+    finally:
+        ops.ROI_SPATIAL_ORDER = True
+        os.environ["A3D_ROI_SERIAL"] = "0"
+    assert torch.equal(ref[live], plain[live])
     gb = torch.zeros(2, ops.GROUP_CAP, 4).cuda()
     gb[:, :50] = boxes
     gv = torch.zeros(2, ops.GROUP_CAP, dtype=torch.int32).cuda()
