@@ -114,6 +114,11 @@ class CfgNode(dict):
 
 
 def _coerce(old: Any, new: Any) -> Any:
+    if isinstance(new, str) and isinstance(old, (tuple, list)):  # yacs decodes "(210000, 250000)" (step1_bbox.yaml:37) with literal_eval
+        try:
+            new = literal_eval(new)
+        except (ValueError, SyntaxError):
+            pass
     if isinstance(old, float) and isinstance(new, int) and not isinstance(new, bool):
         return float(new)
     if isinstance(old, tuple) and isinstance(new, list):
@@ -237,6 +242,18 @@ def get_cfg() -> CfgNode:
     _C.SOLVER = CN()
     _C.SOLVER.IMS_PER_BATCH = 16
     _C.SOLVER.BASE_LR = 0.001
+    # detectron2 defaults of the keys the training step reads (tools/train_net.py -> DefaultTrainer.build_optimizer / build_lr_scheduler)
+    _C.SOLVER.LR_SCHEDULER_NAME = "WarmupMultiStepLR"
+    _C.SOLVER.MAX_ITER = 40000
+    _C.SOLVER.MOMENTUM = 0.9
+    _C.SOLVER.NESTEROV = False
+    _C.SOLVER.WEIGHT_DECAY = 0.0001
+    _C.SOLVER.GAMMA = 0.1
+    _C.SOLVER.STEPS = (30000,)
+    _C.SOLVER.WARMUP_FACTOR = 0.001
+    _C.SOLVER.WARMUP_ITERS = 1000
+    _C.SOLVER.WARMUP_METHOD = "linear"
+    _C.SOLVER.CHECKPOINT_PERIOD = 5000
     _C.TEST = CN()
     _C.TEST.DETECTIONS_PER_IMAGE = 100
     _C.TEST.EVAL_PERIOD = 0

@@ -13,14 +13,16 @@
 #include "../../include/a3d.h"
 
 // masks [n,H,W] uint8 (non-zero = set) -> bits [n, words], words = ceil(H*W/32); bit i of word w = pixel 32w+i
-__global__ void pack_bits_kernel(const unsigned char *__restrict__ m, unsigned int *__restrict__ bits, size_t npix, int words) {
-    const int n = blockIdx.y;
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
-        unsigned int v = 0;
-        const size_t base = (size_t)n * npix + (size_t)w * 32;
-        for (int i = 0; i < 32; ++i)
-            if ((size_t)w * 32 + i < npix && m[base + i]) v |= 1u << i;
-        bits[(size_t)n * words + w] = v;
+// (gridDim.y is capped at 65535 masks: the kernels stride over n, so a long clip's detections pack in one call)
+__global__ void pack_bits_kernel(const unsigned char *__restrict__ m, unsigned int *__restrict__ bits, size_t npix, int words, int count) {
+    for (int n = blockIdx.y; n < count; n += gridDim.y) {
+        for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) {
+            unsigned int v = 0;
+            const size_t base = (size_t)n * npix + (size_t)w * 32;
+            for (int i = 0; i < 32; ++i)
+                if ((size_t)w * 32 + i < npix && m[base + i]) v |= 1u << i;
+            bits[(size_t)n * words + w] = v;
+        }
     }
 }
 
@@ -29,22 +31,23 @@ extern "C" int a3d_masks_pack_bits(const unsigned char *masks, unsigned int *bit
     const size_t npix = (size_t)H * W;
     const int words = (int)((npix + 31) / 32);
     a3d_begin();
-    hipLaunchKernelGGL(pack_bits_kernel, dim3((words + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, masks, bits, npix, words);
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((words + 255) / 256, n < 65535 ? n : 65535), dim3(256), 0, (hipStream_t)stream, masks, bits, npix,
+                       words, n);
     return a3d_check_launch();
 }
 
-__global__ void unpack_bits_kernel(const unsigned int *__restrict__ bits, unsigned char *__restrict__ m, size_t npix, int words) {
-    const int n = blockIdx.y;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x)
-        m[(size_t)n * npix + p] = (bits[(size_t)n * words + (p >> 5)] >> (p & 31)) & 1u;
+__global__ void unpack_bits_kernel(const unsigned int *__restrict__ bits, unsigned char *__restrict__ m, size_t npix, int words, int count) {
+    for (int n = blockIdx.y; n < count; n += gridDim.y)
+        for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x)
+            m[(size_t)n * npix + p] = (bits[(size_t)n * words + (p >> 5)] >> (p & 31)) & 1u;
 }
 
 extern "C" int a3d_masks_unpack_bits(const unsigned int *bits, unsigned char *masks, int n, int H, int W, void *stream) {
     if (!masks || !bits || n <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
     const size_t npix = (size_t)H * W;
     a3d_begin();
-    hipLaunchKernelGGL(unpack_bits_kernel, dim3((int)((npix + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, bits, masks, npix,
-                       (int)((npix + 31) / 32));
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3((int)((npix + 255) / 256), n < 65535 ? n : 65535), dim3(256), 0, (hipStream_t)stream, bits, masks,
+                       npix, (int)((npix + 31) / 32), n);
     return a3d_check_launch();
 }
 

@@ -159,7 +159,49 @@ class PlaneRCNN(nn.Module):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
-        raise NotImplementedError("training forward (losses) is outside the inference hot path (SURVEY.md 8f-1)")
+        return self.training_forward(batched_inputs)
+
+    # ------------------------------------------------------------------ training branch (planercnn.py:83-123)
+    def trainer(self, solver=None, precision: str = "fp32"):
+        """The hand-written training step behind the reference's training-mode call: created on first use (it copies every
+        trainable parameter into its flat buffer).  `articulation3d_amd.engine.build_optimizer` returns the optimiser bound to it."""
+        if getattr(self, "_trainer", None) is None:
+            from ..training import DetectorTrainer
+
+            self._trainer = DetectorTrainer(self, solver, precision=precision)
+        return self._trainer
+
+    def training_forward(self, batched_inputs):
+        """`model(batched_inputs)` in training mode, as detectron2's SimpleTrainer.run_step calls it (tools/train_net.py:84-104 ->
+        planercnn.py:83-123): list of {"image": CHW uint8 BGR, "instances": Instances(gt_boxes, gt_classes)} -> the loss dict
+        {loss_cls, loss_box_reg, loss_rpn_cls, loss_rpn_loc}.  There is no autograd graph: the call runs forward AND backward
+        (DetectorTrainer.forward_backward) and leaves the gradients of the summed loss in the trainer's flat buffer; the returned
+        scalars accept `.backward()` so the reference's loop body stays as it is, and `engine.build_optimizer(cfg, model).step()`
+        applies the fused all-reduce + SGD launch.  Only the step1_bbox configuration (BASELINE configs[4]: box branch; mask /
+        plane / axis / depth heads off) has a training path."""
+        rh = self.roi_heads
+        if self.depth_head_on or getattr(rh, "mask_on", False) or getattr(rh, "plane_on", False) or getattr(rh, "axis_on", False):
+            raise NotImplementedError("training is implemented for config/step1_bbox.yaml (MASK_ON / PLANE_ON / AXIS_ON / DEPTH_ON false): "
+                                      "the mask, plane, axis and depth losses of the later training stages are outside SURVEY.md 8f-1")
+        assert "instances" in batched_inputs[0], "training needs ground-truth instances (planercnn.py:84-85)"
+        imgs = [x["image"] for x in batched_inputs]
+        assert all(tuple(t.shape) == tuple(imgs[0].shape) for t in imgs), "one image size per batch (the reference trains on 480x640 frames)"
+        frames = torch.stack([t.to(self.device) for t in imgs]).permute(0, 2, 3, 1).contiguous()
+        if frames.dtype != torch.uint8:
+            frames = frames.round().clamp(0, 255).to(torch.uint8)  # (detectron2's mapper hands over uint8; tolerate float 0-255)
+        gt_boxes = [x["instances"].gt_boxes.tensor.float() for x in batched_inputs]
+        gt_classes = [x["instances"].gt_classes.long() for x in batched_inputs]
+        tr = self.trainer()
+        losses, _aux = tr.forward_backward(frames, gt_boxes, gt_classes)
+        names = list(losses)
+        outs = _StepLosses.apply(tr.autograd_anchor(), *[losses[k] for k in names])
+        return dict(zip(names, outs))
+
+    def train(self, mode: bool = True):
+        """Leaving training mode writes the trainer's parameters back into the modules (inference packs its weights from them)."""
+        if not mode and getattr(self, "_trainer", None) is not None and self.training:
+            self.load_state_dict(self._trainer.export_state_dict(), strict=False)
+        return super().train(mode)
 
     small_batch_overlap = 16  # batches up to this size run the depth decoder on a second HIP stream (0 disables)
     fast_reference_path = True  # route uniform batches of the reference-signature call through inference_batched
@@ -272,6 +314,23 @@ class PlaneRCNN(nn.Module):
             r = detector_postprocess(results_per_image, height, width, mask_threshold, box_score_threshold=POST_SCORE_THRESH, nms=nms)
             processed_results.append({"instances": r})
         return processed_results
+
+
+class _StepLosses(torch.autograd.Function):
+    """Gives the loss scalars of `training_forward` a `.backward()`: the gradients already sit in the trainer's flat buffer
+    (computed for d(sum of the four losses)/d(parameters)), so backward only has to exist.  A caller that re-weights the losses
+    before calling backward would silently not get what it asked for, hence the check that every upstream gradient is 1."""
+
+    @staticmethod
+    def forward(ctx, anchor, *losses):
+        return tuple(l.detach().clone() for l in losses)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        for g in grads:
+            if g is not None and float(g) != 1.0:
+                raise RuntimeError("the hand-written backward computes the gradient of the plain SUM of the losses; re-weighted losses are not supported")
+        return (None,) * (1 + len(grads))
 
 
 def build_model(cfg):

@@ -30,7 +30,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import ops, train_ops as T
+from . import _lib, ops, train_ops as T
 from .parallel import allreduce_gradients
 from .ops import ACT_NONE, ACT_RELU, PackedConv
 
@@ -101,6 +101,8 @@ class _Layer:
     wt: torch.Tensor = None  # transposed filter scratch [cin, k*k*rows]
     U: Optional[torch.Tensor] = None   # Winograd-domain forward filter (3x3 only)
     Ut: Optional[torch.Tensor] = None  # Winograd-domain data-gradient filter
+    U3: Optional[torch.Tensor] = None   # precision "bf16x3": U / Ut split into three bf16 planes, refreshed once per step by
+    Ut3: Optional[torch.Tensor] = None  # _prepare_filters (a fresh PackedConv per launch would otherwise re-split on every call)
     scale: Optional[torch.Tensor] = None  # folded FrozenBN (constants)
     shift: Optional[torch.Tensor] = None
     sources: List[Tuple[str, int, int]] = field(default_factory=list)  # (state_dict prefix, first row, rows) fused heads
@@ -111,6 +113,7 @@ class _Layer:
                        self.rows, K, self.act)
         if self.U is not None:
             p.w_wino = self.U
+            p.w_wino_x3 = self.U3
         return p
 
     def bwd(self) -> PackedConv:
@@ -119,6 +122,7 @@ class _Layer:
         p = PackedConv(self.wt, None, None, self.k, self.k, 1, self.k - 1 - self.pad, self.rows, self.cin, K, ACT_NONE)
         if self.Ut is not None:
             p.w_wino = self.Ut
+            p.w_wino_x3 = self.Ut3
         return p
 
 
@@ -133,8 +137,9 @@ class DetectorTrainer:
         multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
         weights, activations, gradients, losses and the optimiser stay fp32."""
         assert precision in ("fp32", "bf16", "bf16x3")
-        # "bf16x3": fp32-grade arithmetic on the bf16 pipe (csrc/conv_bf16x3.hip) for the forward / data-gradient launches of the
-        # non-Winograd layers and for every weight gradient; the Winograd launches stay on the fp32 MFMA
+        # "bf16x3": fp32-grade arithmetic on the bf16 pipe for every forward / data-gradient launch -- csrc/conv_bf16x3.hip for the
+        # direct layers, the split-operand Winograd GEMM (csrc/conv_wino.hip 2x) for the 3x3 ones, whose filters are split once per
+        # step in _prepare_filters -- and for every weight gradient
         self.prec = {"fp32": 0, "bf16": 1, "bf16x3": "bf16x3"}[precision]
         self.wgrad_prec = {"fp32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self.s = solver or SolverCfg()
@@ -283,6 +288,17 @@ class DetectorTrainer:
             if ly.k == 3 and self.prec != 1:  # (the bf16 step runs its 3x3 layers as direct convolutions)
                 T.wino_weight_transform(ly.w, ly.U, ly.rows, ly.cin)
                 T.wino_weight_transform(ly.wt, ly.Ut, ly.cin, ly.rows)
+                if self.prec == "bf16x3":  # split ONCE per step into preallocated planes (ops.conv2d would re-split per launch)
+                    for src, name in ((ly.U, "U3"), (ly.Ut, "Ut3")):
+                        rows, cols = src.shape[1], src.shape[2]
+                        if cols % 32:
+                            continue
+                        dst = getattr(ly, name)
+                        if dst is None:
+                            dst = torch.empty((16, cols // 32, 3, rows, 32), device=src.device, dtype=torch.bfloat16)
+                            setattr(ly, name, dst)
+                        _lib.check(_lib.lib().a3d_split_bf16x3(src.data_ptr(), dst.data_ptr(), 16, rows, cols, torch.cuda.current_stream().cuda_stream),
+                                   "a3d_split_bf16x3")
 
     def _conv(self, x, pk, **kw):
         """A trainable layer's forward / data-gradient launch in the step's precision."""
@@ -451,6 +467,12 @@ class DetectorTrainer:
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))
         return losses, aux
+
+    def autograd_anchor(self) -> torch.Tensor:
+        """A leaf that requires grad, so that the loss scalars handed out by PlaneRCNN.training_forward can be `.backward()`-ed."""
+        if getattr(self, "_anchor", None) is None:
+            self._anchor = torch.zeros((), device=self.dev, requires_grad=True)
+        return self._anchor
 
     def optimizer_step(self):
         s = self.s

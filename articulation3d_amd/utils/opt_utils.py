@@ -132,7 +132,9 @@ TRANS_STEPS = torch.arange(-1, 1, 0.1)                                          
 class _MaskBank:
     """The tracked detections' masks of one clip, bit-packed on the device once (9 600 words per 480x640 mask)."""
 
-    def __init__(self, preds, device):
+    def __init__(self, preds, device, wanted=None):
+        """`wanted`: set of (frame index, box id) to pack -- the detections that belong to a track; None packs everything.
+        (A long clip keeps one 307 KB mask per kept detection on the device otherwise: only tracked ones are ever read.)"""
         from .. import opt_ops
 
         self.dev, self.index, chunks = device, {}, []
@@ -141,10 +143,13 @@ class _MaskBank:
             m = inst.pred_masks
             if m is None or len(m) == 0:
                 continue
-            for b in range(len(m)):
-                self.index[(idx, b)] = n + b
-            n += len(m)
-            chunks.append((m > 0.5).to(torch.uint8))
+            keep = [b for b in range(len(m)) if wanted is None or (idx, b) in wanted]
+            if not keep:
+                continue
+            for j, b in enumerate(keep):
+                self.index[(idx, b)] = n + j
+            n += len(keep)
+            chunks.append((m[keep] > 0.5).to(torch.uint8))
         self.H, self.W = (chunks[0].shape[1], chunks[0].shape[2]) if chunks else (480, 640)
         self.u8 = torch.cat(chunks).to(device) if chunks else torch.zeros((0, self.H, self.W), dtype=torch.uint8, device=device)
         self.bits = opt_ops.pack_masks(self.u8) if n else None
@@ -266,7 +271,8 @@ def optimize_planes(preds: List[Instances], planes: Dict[str, list], method: str
     """pkg/utils/opt_utils.py:962-975, method '3dc': translation tracks first, then rotation tracks."""
     if method != "3dc":
         raise NotImplementedError("only the '3dc' method the reference's tools call (tools/inference.py:250) is provided")
-    bank = _MaskBank(preds, device)
+    wanted = {(idx, b) for kind in ("trans", "rot") for plane in planes[kind] for idx, b in plane["ids"].items()}
+    bank = _MaskBank(preds, device, wanted)  # only tracked detections are ever projected or compared
     for plane in planes["trans"]:
         _optimize_track(preds, plane, "trans", bank)
     preds = _reweight(preds, planes["trans"], "trans")

@@ -801,11 +801,13 @@ def test_forward_with_given_boxes_ragged(hip_model, oracle, oracle_params, stage
     assert rel(out[0].pred_rot_axis, ora) < 1e-4 and rel(out[0].pred_tran_axis, ota) < 1e-4
 
 
-def test_full_batch_properties(hip_model, oracle):
-    """BASELINE-size batch (32 frames): size-independent properties instead of an oracle run."""
+@pytest.mark.parametrize("nframes", [32, 64], ids=["configs1-batch32", "configs2-clip64"])
+def test_full_batch_properties(hip_model, oracle, nframes):
+    """BASELINE-size batches (configs[1]: 32 frames, configs[2]: the 64-frame clip): size-independent properties instead of an
+    oracle run."""
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.0
-    frames = oracle.synthetic_frames(32, seed=21)
+    frames = oracle.synthetic_frames(nframes, seed=21)
     fr = torch.from_numpy(frames).cuda()
     out = model.inference_batched(fr)
     out2 = model.inference_batched(fr)
