@@ -21,20 +21,27 @@ GROUP_CAP = 1024
 
 # Optional per-launch timing of the conv-GEMM kernel (bench.py's roofline leg): when a list is installed
 # here, conv2d() brackets its launch with HIP events on the launch stream and appends
-# (kernel variant as recorded by the dispatcher, algorithmic_flops, start_event, end_event, shape, executed_flops).
-# executed_flops = multiply-adds the kernel actually issues on the matrix pipe x2 (Winograd F(2x2,3x3): 16 per 2x2 output
-# tile and channel pair instead of 36; phase convs of an upsampled 3x3: 4 taps instead of 9).
+# (kernel variant as recorded by the dispatcher, algorithmic_flops, start_event, end_event, shape, executed_flops, pipe).
+# executed_flops = fp32 multiply-adds the kernel's contraction performs x2 (Winograd F(2x2,3x3): 16 per 2x2 output tile and channel
+# pair instead of 36; phase convs of an upsampled 3x3: 4 taps instead of 9); pipe = "f32" (fp32-input MFMA), "bf16" (one bf16 MFMA
+# per product) or "bf16x6" (bf16x3 mode: SIX bf16 MFMA products per fp32 multiply-add).
 CONV_TIMING: Optional[list] = None
 
-# Arithmetic of conv2d() calls that do not ask for one: 0 = fp32 MFMA (the parity path, default), 1 = bf16 MFMA with fp32
-# accumulation on the layer kinds csrc/conv_bf16.hip covers (plain convolutions / linears); the rest stay fp32.  An opt-in
-# throughput mode for deployments that accept autocast-level error -- never used by the parity tests or the headline bench.
-# 2 = "bf16x3": fp32-grade arithmetic on the bf16 matrix pipe (csrc/conv_bf16x3.hip: every fp32 operand split exactly into
-# three bf16 terms, six MFMAs per k step, fp32 accumulate; measured error against float64 is slightly BELOW the fp32
-# MFMA's, tools/x3_bench.py) on the direct layers (1x1 convs, linears, strided 3x3, phase / concat convs); the Winograd layers
-# keep the Winograd form with the split-operand GEMM of csrc/conv_wino.hip.  Opt-in as well (A3D_PRECISION=2 / bench.py
-# --precision bf16x3); the whole fp32 parity suite passes under it.
-DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "0"))
+# Arithmetic of conv2d() calls that do not ask for one (a3d_conv_desc.precision):
+#   2 = "bf16x3", THE DEFAULT since round 2: fp32-grade arithmetic on the bf16 matrix pipe.  Every fp32 operand is split exactly
+#       into three bf16 terms (x = hi + mid + lo, round-to-nearest at each level; bf16 x bf16 is exact in fp32) and six MFMAs
+#       per k step (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) accumulate in fp32: the dropped terms are <= 2^-24 relative,
+#       the rounding of one fp32 FMA.  Tensors, accumulation and every non-GEMM kernel stay fp32.  Measured error against float64
+#       is slightly BELOW the fp32 MFMA's on every layer shape (tools/x3_bench.py, tests: test_bf16x3_kernel_is_fp32_grade,
+#       test_winograd_split_operand_gemm_is_fp32_grade) and the WHOLE GPU suite -- oracle tolerances, golden fixtures, bit-exact
+#       discrete stages, end-to-end matched detections with the float64 yardstick -- passes under it (114 tests, round 2).
+#       Direct layers: csrc/conv_bf16x3.hip; Winograd layers: the split-operand 16-plane GEMM of csrc/conv_wino.hip.  gfx950's
+#       fp32-input MFMA runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 pipe) and, as the one-launch Winograd kernel's
+#       ablations showed, shares that datapath with the VALU; six bf16 MFMAs per step are 2.67x faster on paper, 1.2-1.6x delivered.
+#   0 = fp32-input MFMA (A3D_PRECISION=0 / bench.py --precision fp32): the round-1 default, bit-compatible with it; the
+#       one-launch Winograd kernel (csrc/conv_wino_fused.hip) belongs to this mode.
+#   1 = bf16 MFMA with fp32 accumulation on plain convolutions / linears: autocast-level error, opt-in, never a parity mode.
+DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "2"))
 
 
 def last_conv_variant() -> str:
@@ -318,7 +325,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             e0.record()
             _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
             e1.record()
-            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin))
+            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin, "f32"))
             return out
         if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
             e0, e1, e2 = ev(), ev(), ev()
@@ -327,8 +334,9 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             e1.record()
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()
-            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0))
-            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin))
+            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none"))
+            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin,
+                                "bf16x6" if d.precision == 2 else "f32"))
             return out
         e0, e1 = ev(), ev()
         e0.record()
@@ -337,7 +345,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         executed = 2.0 * B * Ho * Wo * p.cols * k_real
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
-        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed))
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6"}[int(d.precision)]))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

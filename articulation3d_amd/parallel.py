@@ -60,6 +60,10 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
         return GatherHandle(records, rec_count, [], None)
     G = dist.get_world_size()
     rec, cnt = records.contiguous(), rec_count.contiguous()
+    back = None
+    if rec.is_cuda and dist.get_backend() == "gloo":  # test rigs (several ranks on one GPU): gloo moves host memory
+        back = rec.device
+        rec, cnt = rec.cpu(), cnt.cpu()
     if rows is not None:
         if rec.shape[0] > rows:
             raise ValueError(f"block of {rec.shape[0]} frames does not fit rows={rows}")
@@ -77,6 +81,10 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
         _blocks_verified = True
     all_rec = torch.empty((G * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
     all_cnt = torch.empty((G * cnt.shape[0],), device=cnt.device, dtype=cnt.dtype)
+    if back is not None:
+        dist.all_gather_into_tensor(all_cnt, cnt)
+        dist.all_gather_into_tensor(all_rec, rec)
+        return GatherHandle(all_rec.to(back), all_cnt.to(back), [], None)
     w1 = dist.all_gather_into_tensor(all_cnt, cnt, async_op=True)
     w2 = dist.all_gather_into_tensor(all_rec, rec, async_op=True)
     return GatherHandle(all_rec, all_cnt, [w1, w2], (rec, cnt))  # inputs stay referenced until the collective is waited for

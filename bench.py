@@ -33,6 +33,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; never the 2:1-sparsity figure)
+PIPE_PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x6": BF16_MFMA_PEAK_TFLOPS}
+PIPE_FLOPS_PER_FMA = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "none": 0.0}  # matrix-pipe products issued per fp32 multiply-add
+
+
+DTYPES = {
+    "bf16x3": "f32 (fp32 tensors and accumulation; every product formed from exact 3-way bf16 operand splits, six bf16 MFMAs per k step: "
+              "error vs float64 <= the fp32-input MFMA's, the whole parity suite runs in this arithmetic)",
+    "fp32": "f32 (fp32-input MFMA)",
+    "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in autocast mode, not comparable with the f32 figures",
+}
 
 
 def parse_args():
@@ -45,11 +56,12 @@ def parse_args():
                     help="MODEL.ROI_HEADS.SCORE_THRESH_TEST of the headline; 0.5 gives a realistic handful of detections per frame "
                          "on random-init weights (0.7, the reference default, gives none; 0.0 gives 100: both are in operating_points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt-modes", action="store_true", help="skip the secondary timed loop in the opt-in bf16x3 mode")
+    ap.add_argument("--no-alt-modes", action="store_true", help="skip the secondary timed loop in the other arithmetic (fp32-input MFMA)")
     ap.add_argument("--no-operating-points", action="store_true", help="skip the A / B / C operating points and the transfer-inclusive loop")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
-                    help="fp32 (default; the parity path and the headline number) or bf16: opt-in autocast arithmetic (bf16 MFMA, fp32 "
-                         "accumulate) on the plain conv / linear layers -- reported with its own dtype, not comparable with the headline")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
+                    help="bf16x3 (default: fp32-grade products from exact 3-way bf16 operand splits on the bf16 MFMA, fp32 tensors and "
+                         "accumulation; the arithmetic the package and its parity suite run in), fp32 (fp32-input MFMA, the round-1 default) "
+                         "or bf16 (opt-in autocast arithmetic -- reported with its own dtype, not comparable)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="timed frames of the bounded CPU-baseline sample (~10-20 s of host work)")
     return ap.parse_args()
@@ -183,23 +195,19 @@ def main():
     from articulation3d_amd.utils.synthetic import synthetic_frames
 
     model, cfg = build_detector(args.score_thresh, dev)
-    if args.precision == "bf16":
-        ops.DEFAULT_PRECISION = 1
-    elif args.precision == "bf16x3":  # fp32-grade arithmetic on the bf16 pipe for the non-Winograd layers (csrc/conv_bf16x3.hip)
-        ops.DEFAULT_PRECISION = 2
+    ops.DEFAULT_PRECISION = {"fp32": 0, "bf16": 1, "bf16x3": 2}[args.precision]
     B = args.batch
     # contiguous block of the synthetic clip per rank (temporal order is restored by rank order)
     frames_np = synthetic_frames(B, seed=2020 + rank)
     frames = torch.from_numpy(frames_np).to(dev)  # resident in HBM before the timed region
 
     pending = []  # the all-gather of batch i travels while batch i+1 is computed; it is waited for one step later
-    gloo_cpu = use_dist and args.dist_backend != "nccl"  # gloo test rigs gather host copies of the records
+    gloo_cpu = use_dist and args.dist_backend != "nccl"  # (gloo test rigs: parallel.gather_records_async stages through the host)
 
     def step(given=None, src=frames):
         out = model.inference_batched(src, given_boxes=given)
         if use_dist:
-            rec, cnt = (out.records.cpu(), out.rec_count.cpu()) if gloo_cpu else (out.records, out.rec_count)
-            pending.append(gather_records_async(rec, cnt))
+            pending.append(gather_records_async(out.records, out.rec_count))
             if len(pending) > 1:
                 pending.pop(0).wait()
         return out
@@ -291,18 +299,19 @@ def main():
                                    "mask / plane / axis heads, no RPN / box head"}
         extra["operating_points"] = pts
 
-    # Secondary figure, same clip, same timing discipline: the opt-in fp32-grade bf16x3 mode.  Reported
-    # beside the headline, never as it: `value` is plain fp32-MFMA arithmetic.
+    # Secondary figure, same clip, same timing discipline: the other fp32-grade arithmetic (fp32-input MFMA when the headline runs
+    # bf16x3, and vice versa).  Reported beside the headline, never as it.
     alt = None
-    if args.precision == "fp32" and not args.no_alt_modes:
-        ops.DEFAULT_PRECISION = 2
+    if args.precision in ("fp32", "bf16x3") and not args.no_alt_modes:
+        other = "fp32" if args.precision == "bf16x3" else "bf16x3"
+        saved = ops.DEFAULT_PRECISION
+        ops.DEFAULT_PRECISION = {"fp32": 0, "bf16x3": 2}[other]
         try:
             el, _ = timed(args.steps, max(1, min(args.warmup, 2)), step)
         finally:
-            ops.DEFAULT_PRECISION = 0
-        alt = {"bf16x3": {"value": round(B * world * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / args.steps, 3),
-                          "dtype": "f32 via exact 3-way bf16 operand split on the bf16 MFMA, direct and Winograd layers (error vs float64 <= the "
-                                   "fp32 MFMA's; the fp32 parity suite passes under it) -- opt-in (--precision bf16x3), NOT the headline"}}
+            ops.DEFAULT_PRECISION = saved
+        alt = {other: {"value": round(B * world * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / args.steps, 3),
+                       "dtype": DTYPES[other], "note": "python bench.py --precision " + other}}
 
     dets = out.rec_count.float().mean().item()
     raw = out.det.count.float().mean().item()
@@ -310,48 +319,48 @@ def main():
     # roofline of the dominant kernel: per kernel sums of FLOPs and HIP-event durations over the timed steps.  Names are the
     # dispatcher's own record of what it launched (a3d_last_conv_variant), not a host-side mirror of its rules.
     per = {}
-    for name, flops, e0, e1, _shape, executed in timing:
-        d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
+    for name, flops, e0, e1, _shape, executed, pipe in timing:
+        d = per.setdefault(name, [0.0, 0.0, 0, 0.0, pipe])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
         d[3] += executed
     dom = max(per.items(), key=lambda kv: kv[1][1])
-    dname, (dflops, dsec, dn, dexec) = dom
+    dname, (dflops, dsec, dn, dexec, dpipe) = dom
     conv_sec = sum(v[1] for v in per.values())
-    peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else None
-    achieved = dexec / dsec / 1e12
+    peak = PIPE_PEAK.get(dpipe, FP32_MFMA_PEAK_TFLOPS)
+    issued = dexec * PIPE_FLOPS_PER_FMA[dpipe]  # FLOPs the matrix pipe actually executes
+    achieved = issued / dsec / 1e12
     roofline = {
-        "kernel": dname, "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "flops_counted": "EXECUTED on the matrix pipe (Winograd F(2x2,3x3) issues 16 multiply-adds per 2x2 output tile and channel pair "
-                         "where the direct form issues 36)",
+        "kernel": dname, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None, "pipe": dpipe,
+        "flops_counted": "EXECUTED on the matrix pipe: bf16x3 issues SIX bf16 MFMA products per fp32 multiply-add (peak = dense bf16 MFMA); "
+                         "Winograd F(2x2,3x3) performs 16 multiply-adds per 2x2 output tile and channel pair where the direct form performs 36",
+        "fp32_equivalent_tflops": round(dexec / dsec / 1e12, 2),
         "algorithmic_tflops": round(dflops / dsec / 1e12, 2), "algorithmic_speedup": round(dflops / dexec, 4) if dexec else None,
-        "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed": round(dexec / dn / 1e9, 3),
+        "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed_fp32_equivalent": round(dexec / dn / 1e9, 3),
         "avg_launch_gflop_algorithmic": round(dflops / dn / 1e9, 3), "share_of_step_time": round(dsec / elapsed, 3),
     }
-    if peak is None:
-        roofline["note"] = "opt-in precision mode: `peak` is still the fp32-MFMA figure, the kernels run on the bf16 pipe"
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
-        k = tr.get("kernels", {}).get(dname.split("<")[0])
+        stem = dname.split("<")[0].split(" ")[0]
+        k = next((v for n, v in tr.get("kernels", {}).items() if n.split("<")[0] == stem), None)
         if k:
             roofline["traffic"] = k["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "committed " + os.path.relpath(tpath, ROOT) + ": separate rocprofv3 --pmc passes of this command, NOT measured in this run"
-    roofline["all_conv_kernels"] = {k: {"executed_tflops": round(v[3] / v[1] / 1e12, 2) if v[3] else 0.0,
+    roofline["all_conv_kernels"] = {k: {"pipe": v[4], "fp32_equivalent_tflops": round(v[3] / v[1] / 1e12, 2) if v[3] else 0.0,
+                                        "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None,
                                         "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
                                         "launches_per_step": v[2] // args.steps} for k, v in sorted(per.items())}
     roofline["conv_kernels_share_of_step_time"] = round(conv_sec / elapsed, 3)
-    roofline["whole_step_executed_tflops"] = round(sum(v[3] for v in per.values()) / elapsed / 1e12, 2)
+    roofline["whole_step_fp32_equivalent_tflops"] = round(sum(v[3] for v in per.values()) / elapsed / 1e12, 2)
 
     result = {
         "metric": "frames/sec through PlaneRCNN detector at 480x640",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in, NOT the headline",
-                  "bf16x3": "f32 via exact 3-way bf16 operand split on the bf16 MFMA (fp32-grade error, fp32 tensors / accumulate), "
-                            "direct and Winograd layers -- opt-in, NOT the headline"}[args.precision], "data": "synthetic",
+        "dtype": DTYPES[args.precision], "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: full PlaneRCNN detector (ResNet50-FPN + RPN + ROIAlign + box/mask/plane/axis heads "
                                "+ depth head + NMS + mask paste + plane-offset LSQ + record pack), fp32, random-init weights with "
                                "calibrated BN, synthetic 480x640 uint8 frames resident in HBM",

@@ -106,6 +106,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device(cfg.MODEL.DEVICE))
         else:
             dist.init_process_group(backend=args.dist_backend)
+    if args.random_init:
+        torch.manual_seed(2020)  # every rank (and every run) draws the same initialisation
     branch = PlaneRCNN_Branch(cfg, load_weights=not args.random_init)
     model = branch.predictor.model
     frames_rgb = read_frames(args.input)

@@ -29,7 +29,7 @@ def main():
     marks = sorted(t for t, _ in per[[k for k in per if k.startswith("preprocess_u8_kernel")][0]])
     t_begin = marks[-steps]
     lines = ["# rocprofv3 kernel summary", "",
-             f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes`", "",
+             f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes --no-operating-points`", "",
              f"bench line of the profiled run: value={bench['value']} {bench['unit']}, ms_per_step={bench['ms_per_step']}, "
              f"roofline={json.dumps({k: bench['roofline'][k] for k in ('kernel', 'achieved', 'peak', 'frac', 'launches', 'avg_launch_ms')})}", "",
              "## timed region only (last %d steps), per kernel" % steps, "",
