@@ -21,6 +21,7 @@ from torch import nn
 
 from .. import ops
 from ..registry import META_ARCH_REGISTRY
+from ..streams import SMALL_BATCH
 from ..structures import Boxes, ImageList, Instances
 from .backbone import build_backbone
 from .depth_head import build_depth_head
@@ -104,6 +105,13 @@ class PlaneRCNN(nn.Module):
             "batched path expects frames already a multiple of 32 (the reference feeds 480x640)"
         hw = (H, W)
         feats = self.backbone.forward_nhwc(x4)
+        # the RPN conv and the depth head's lateral conv read the same pyramid level: one Winograd input transform for both
+        # (bit-identical results; -1.8 ms per 64 frames).  Not for 1-2 frame batches, whose RPN levels fork onto side streams.
+        share = [f for f in feats.values() if f.is_cuda] if (self.depth_head_on and given_boxes is None and B > SMALL_BATCH) else []
+        with ops.share_wino_input(share):
+            return self._detect_on_features(feats, frames, B, hw, want_masks, given_boxes)
+
+    def _detect_on_features(self, feats, frames, B, hw, want_masks, given_boxes) -> BatchedOutput:
         proposals = None
         if given_boxes is None:
             pb, pl, plv, ppos, pc = self.proposal_generator.forward_batched(feats, hw)

@@ -128,7 +128,10 @@ class PlaneRCNNROIHeads(nn.Module):
         if self.axis_on:
             names.append("axis")
             fns.append(lambda: self.axis_head.forward_rows(shared if same_pool else pool(self.axis_pooler)))
-        outs = dict(zip(names, run_branches(fns, concurrent=det.boxes.is_cuda and det.boxes.shape[0] <= SMALL_BATCH)))
+        concurrent = det.boxes.is_cuda and det.boxes.shape[0] <= SMALL_BATCH
+        # plane and axis heads read the same pooled tensor: their first 3x3 layers share one Winograd input transform
+        with ops.share_wino_input([shared] if same_pool and not concurrent and shared.is_cuda else []):
+            outs = dict(zip(names, run_branches(fns, concurrent=concurrent)))
         if "mask" in outs:
             det.mask_prob = outs["mask"]
         if "plane" in outs:

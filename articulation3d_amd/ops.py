@@ -240,6 +240,32 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 # --------------------------------------------------------------------------------------------------
 # kernels
 # --------------------------------------------------------------------------------------------------
+_WINO_SHARE: Optional[dict] = None
+WINO_SHARE_ENABLED = os.environ.get("A3D_WINO_SHARE", "1") != "0"  # schedule-only switch (tests compare both settings bit for bit)
+
+
+class share_wino_input:
+    """Scope in which the Winograd input transform of each listed tensor is computed once and reused by every 3x3 layer
+    that reads it (the RPN conv and the depth head's lateral conv both read the same FPN level; the plane and axis heads
+    read the same pooled ROI tensor).  V = B^T d B depends on the input only, so the layers' results are bit-identical to
+    the unshared form; the saving is one wino_input_kernel launch (a full read of the level + a 4x-sized write) per reuse.
+    The V tensors live until the scope exits -- exit it only after every stream that consumed them has been joined."""
+
+    def __init__(self, tensors: Sequence[torch.Tensor]):
+        self.map = {t.data_ptr(): [t, None] for t in tensors} if WINO_SHARE_ENABLED else {}
+
+    def __enter__(self):
+        global _WINO_SHARE
+        self.prev, _WINO_SHARE = _WINO_SHARE, self.map
+        return self
+
+    def __exit__(self, *exc):
+        global _WINO_SHARE
+        _WINO_SHARE = self.prev
+        self.map = {}
+        return False
+
+
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
@@ -309,12 +335,30 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                 _lib.check(_lib.lib().a3d_split_bf16x3(p.w_wino.data_ptr(), p.w_wino_x3.data_ptr(), 16, rows, cols, _stream()), "a3d_split_bf16x3")
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
     fused_wino = False
+    shared = None  # [input tensor, its transformed tiles V or None]: see share_wino_input
     if use_wino or splitk > 1:
+        if use_wino and _WINO_SHARE is not None and x2 is None:
+            shared = _WINO_SHARE.get(x.data_ptr())
+            if shared is not None and (shared[0].shape != x.shape or d.tune != 0):
+                shared = None
+        if shared is not None:
+            d.w_wino_cm = None  # consumers of a shared input take the two-launch form so that V exists once for all of them
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
         fused_wino = use_wino and nbytes == 0  # the one-launch Winograd kernel needs no V tensor
-        if nbytes:
+        if shared is not None and shared[1] is not None:
+            ws = shared[1]
+            assert ws.numel() * 4 == nbytes
+            d.workspace = ws.data_ptr()
+        elif nbytes:
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
             d.workspace = ws.data_ptr()
+    if shared is not None:
+        have_v, shared[1] = shared[1] is not None, ws
+        if CONV_TIMING is None:
+            if not have_v:
+                _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+            _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
+            return out
     if CONV_TIMING is not None:
         k_real = 147 if p.stem else p.KH * p.KW * p.Cin
         shape = f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"
@@ -330,7 +374,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
             e0, e1, e2 = ev(), ev(), ev()
             e0.record()
-            _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+            if shared is None or not have_v:
+                _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
             e1.record()
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()

@@ -87,6 +87,46 @@ def test_one_launch_winograd_is_bit_identical_to_the_two_launch_form(ops, shape)
     assert torch.equal(ops.conv2d(x, pk, gate=gate, precision=0), ops.conv2d(x, pk, gate=gate, tune=7, precision=0))
 
 
+@pytest.mark.parametrize("precision", [0, 2])
+def test_shared_winograd_input_transform_is_bit_identical(ops, precision):
+    """ops.share_wino_input: two 3x3 layers reading one tensor (RPN conv + depth lateral conv per FPN level; plane + axis head
+    conv1) run ONE wino_input_kernel; V depends on the input only, so each layer's output equals its unshared output bit for bit."""
+    torch.manual_seed(11)
+    x = torch.randn(3, 60, 80, 256, device="cuda")
+    other = torch.randn(3, 60, 80, 256, device="cuda")
+    pks = [ops.pack_conv(torch.randn(co, 256, 3, 3) / 48, torch.randn(co) * 0.1, None, 1, 1, ops.ACT_RELU) for co in (256, 96)]
+    alone = [ops.conv2d(x, pk, precision=precision) for pk in pks]
+    two_launch = [ops.conv2d(x, pk, precision=precision, tune=7 if precision == 0 else 0) for pk in pks]
+    ops.CONV_TIMING = []
+    try:
+        with ops.share_wino_input([x]):
+            shared = [ops.conv2d(x, pk, precision=precision) for pk in pks]
+            unlisted = ops.conv2d(other, pks[0], precision=precision)  # a tensor that is not in the scope is untouched by it
+        torch.cuda.synchronize()
+        names = [t[0] for t in ops.CONV_TIMING]
+    finally:
+        ops.CONV_TIMING = None
+    for a, b, c in zip(alone, two_launch, shared):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(unlisted, ops.conv2d(other, pks[0], precision=precision))
+    gemm = "wino_gemm_x3_kernel" if precision == 2 else "wino_gemm_kernel"
+    assert sum(n.startswith(gemm) for n in names) >= 2
+
+
+def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
+    model = hip_model
+    model.roi_heads.box_predictor.test_score_thresh = 0.3
+    frames = torch.from_numpy(oracle.synthetic_frames(4, seed=77)).cuda()  # > streams.SMALL_BATCH frames: the sharing scope is on
+    a = model.inference_batched(frames, want_masks=True)
+    ops.WINO_SHARE_ENABLED = False
+    try:
+        b = model.inference_batched(frames, want_masks=True)
+    finally:
+        ops.WINO_SHARE_ENABLED = True
+    for k in ("depth", "records", "rec_count", "masks", "planes", "boxes"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
 def test_conv_fused_epilogues(ops):
     torch.manual_seed(2)
     x = torch.randn(2, 64, 24, 40)

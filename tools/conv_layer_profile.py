@@ -25,9 +25,9 @@ e1.record()
 torch.cuda.synchronize()
 t, ops.CONV_TIMING = ops.CONV_TIMING, None
 tot = 0.0
-print(f"{'cfg':28s} {'shape':44s} {'GFLOP':>9s} {'ms':>8s} {'TF/s':>7s}")
-for name, fl, a, b, shape in t:
+print(f"{'kernel':36s} {'shape':44s} {'GFLOP exec':>10s} {'ms':>8s} {'fp32-eq TF/s':>12s}")
+for name, fl, a, b, shape, ex, pipe in t:
     ms = a.elapsed_time(b)
     tot += ms
-    print(f"{name:28s} {shape:44s} {fl / 1e9:9.2f} {ms:8.3f} {fl / ms / 1e9:7.1f}")
+    print(f"{name[:36]:36s} {shape:44s} {ex / 1e9:10.2f} {ms:8.3f} {ex / ms / 1e9:12.1f}")
 print(f"conv total {tot:.2f} ms of step {e0.elapsed_time(e1):.2f} ms")
