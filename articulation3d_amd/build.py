@@ -38,6 +38,7 @@ SOURCES = {
     "train_ops.hip": ["-ffp-contract=off"],  # matcher IoU / box deltas round like the reference's separate mul, add, div
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("A3D_HIPCC_FLAGS", "").split()  # developer builds only (e.g. -DA3D_ABLATIONS: timing-only kernel variants)
 
 
 def _hipcc() -> str:

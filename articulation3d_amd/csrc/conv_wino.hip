@@ -16,6 +16,7 @@
 //     never written to memory.  Epilogue: folded BN scale/shift + activation, float4 NHWC stores.
 // Weights are transformed once on the host side at pack time (U = G g G^T, [16][Cout][Cin]).
 #include "conv_common.h"
+#include <stdlib.h>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -499,6 +500,246 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_x3_kernel(const WinoArgs a, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2x-wide.  wino_gemm_x3_kernel above is LDS-bound (per workgroup-chunk ~490 LDS cycles -- one ds_read_b128 per MFMA plus the
+// register-path writes of both operands -- against 384 MFMA cycles per SIMD; 0.45 matrix-pipe occupancy measured).  This form
+// widens the workgroup to 64 tiles x 128 channels (wave tile 32 tiles x 64 channels, 24 MFMAs per wave-chunk) and moves the
+// pre-split weight planes global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPRs, no VGPR -> LDS store path, the
+// XOR slot swizzle applied on the global side of each lane's address):
+//   fragment reads per MFMA 1 -> 0.75, register-path LDS stores per MFMA 0.75 -> 0.25 (V's three planes only), V is split by
+//   Cout/128 workgroups instead of Cout/64.  Per workgroup-chunk: ~290 read + ~145 store + ~100 DMA LDS cycles against 768 MFMA
+//   cycles per SIMD.  160 accumulator registers (mf[2] + the 4 x 2 folded outputs) -> two workgroups per CU, 72 KiB of LDS each.
+// The per-output operation order (planes, k chunks, 16-deep steps, the six product terms) is that of wino_gemm_x3_kernel: the two
+// kernels agree bit for bit (tests/test_gpu_parity.py).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wuni_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t r, __bf16 *lds_dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, soff, 0, 0);
+}
+
+constexpr int X3W_BN = 128, X3W_LKB = 32;
+constexpr int x3w_buf(int WM) { return 3 * (32 * WM + X3W_BN) * X3W_LKB; }  // bf16 elements of one stage: X and W, 3 planes each
+constexpr int x3w_lds_bytes(int WM) { return 2 * x3w_buf(WM) * 2 + 2 * X3W_BN * 4; }
+
+// WM = wave rows: 2 -> 64 tiles x 128 channels, 256 threads, two workgroups per CU; 4 -> 128 tiles x 128 channels, 512 threads, one
+// workgroup per CU (every 64-tile block streams all of U3 -- 6 B per weight -- from L2: 30 GB per p2 layer; 128-tile blocks halve it)
+template <int WM, int ABL>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+    constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
+    constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
+    constexpr int PLX = BM * LKB, PLW = BN * LKB, BUF = x3w_buf(WM);
+    constexpr int DPW = 24 / NW;  // weight DMA instructions per wave and chunk
+    static_assert(XR == 2, "the counted vmcnt waits below assume two V loads per chunk");
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    float *ss = reinterpret_cast<float *>(lds + 2 * BUF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int t0 = mt * BM, n0 = nt * BN;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    const size_t vplane = (size_t)a.T * a.C;
+    const unsigned vbytes = (unsigned)(vplane * 4);
+    const int KC = a.C / BKT;
+    const int NIT = 16 * KC;
+
+    int xoff[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int t = t0 + lr + RPP * i;
+        xoff[i] = t < a.T ? (t * a.C + lc) * 4 : -1;
+    }
+    const int lcs = ((((lc >> 3) ^ (lr >> 2)) & 3) << 3) | (lc & 7);  // (RPP is a multiple of 16: both passes share the swizzle)
+    // weights: U3 [16][C/32][3][Cout][32] bf16; one (f, chunk, plane) tile of this workgroup's 128 rows is an 8 KiB run = 8 DMA
+    // wave-instructions of 16 rows.  Lane i of an instruction lands at LDS byte 16 i of its 1 KiB = row i/4, slot i%4, and
+    // fetches the k slot that the image keeps there: slot ^ ((row >> 2) & 3)  (row base is a multiple of 16)
+    const __amdgpu_buffer_rsrc_t ru = wuni_rsrc(a.U3, (unsigned)((size_t)16 * a.Cout * a.C * 2 * 3));
+    const int wvoff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    const int u3tile = a.Cout * 64;  // bytes of one (f, chunk, plane) tile
+    int dma_c = 0;                   // flat (f, kc) index of the next weight chunk to fetch
+    auto dma_w = [&](const int buf) {
+        // 24 instructions per chunk: instruction j = plane j/8, row group j%8
+        __bf16 *Wt = lds + buf * BUF + 3 * PLX;
+        const int base = __builtin_amdgcn_readfirstlane(min(dma_c, NIT - 1) * 3 * u3tile + n0 * 64);
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int j = wave * DPW + i;
+            const int p = j >> 3, g = j & 7;
+            wdma16(ru, Wt + p * PLW + g * 16 * LKB, wvoff, base + __builtin_amdgcn_readfirstlane(p * u3tile + g * 1024));
+        }
+        ++dma_c;
+    };
+    f32x4 xsA[XR], xsB[XR];
+    int ld_f = 0, ld_kc = 0;
+    auto load_chunk = [&](f32x4 (&xs)[XR]) {
+        const int f = min(ld_f, 15);
+        const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(a.V + (size_t)f * vplane, vbytes);
+        const int soff = ld_kc * BKT * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = wbuf_load4(rv, xoff[i], soff);
+        if (++ld_kc == KC) {
+            ld_kc = 0;
+            ++ld_f;
+        }
+    };
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR]) {
+        __bf16 *X = lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            wbf16x4 h, m, l;
+            if (ABL == 2) h = m = l = __builtin_convertvector(xs[i], wbf16x4);
+            else wsplit3(xs[i], h, m, l);
+            __bf16 *p = X + (lr + RPP * i) * LKB + lcs;
+            if (ABL == 6) continue;
+            *reinterpret_cast<wbf16x4 *>(p) = h;
+            *reinterpret_cast<wbf16x4 *>(p + PLX) = m;
+            *reinterpret_cast<wbf16x4 *>(p + 2 * PLX) = l;
+        }
+    };
+
+    f32x16 mf[TN];
+    f32x16 yy[4][TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mf[n][r] = 0.f;
+            yy[0][n][r] = yy[1][n][r] = yy[2][n][r] = yy[3][n][r] = 0.f;
+        }
+    if (tid < BN) {
+        const int n = n0 + tid;
+        ss[tid] = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        ss[BN + tid] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    }
+    dma_w(0);
+    load_chunk(xsA);
+    store_chunk(0, xsA);
+    load_chunk(xsB);
+    load_chunk(xsA);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fsw = (frow >> 2) & 3;
+    auto fold = [&](f32x16 (&m)[TN], const int f) {
+        const int u = f >> 2, v = f & 3;
+        const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
+        const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
+        const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = m[n][r];
+                yy[0][n][r] = __builtin_fmaf(c00, x, yy[0][n][r]);
+                yy[1][n][r] = __builtin_fmaf(c01, x, yy[1][n][r]);
+                yy[2][n][r] = __builtin_fmaf(c10, x, yy[2][n][r]);
+                yy[3][n][r] = __builtin_fmaf(c11, x, yy[3][n][r]);
+                m[n][r] = 0.f;
+            }
+        }
+    };
+    // one chunk: the weight DMA of chunk it+1 first (it is the oldest vector-memory operation of the iteration, so the counted
+    // wait before the barrier leaves the XR register loads of chunk it+3 in flight), then 2 k steps x 6 terms x 2 channel blocks
+    auto mma = [&](const int cur, f32x4 (&xs)[XR]) {
+        if (ABL != 4) dma_w(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const __bf16 *X = lds + cur * BUF + (wm * 32 + frow) * LKB;
+        const __bf16 *Wt = lds + cur * BUF + 3 * PLX + (wn * 64 + frow) * LKB;
+        wbf16x8 fa[3][TN], fb[3];
+        auto frags = [&](const int st) {
+            const int slot = (((2 * st + (lane >> 5)) ^ fsw) & 3) << 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int n = 0; n < TN; ++n) fa[p][n] = *reinterpret_cast<const wbf16x8 *>(Wt + p * PLW + n * 32 * LKB + slot);
+                fb[p] = *reinterpret_cast<const wbf16x8 *>(X + p * PLX + slot);
+            }
+        };
+#define WX3(PA, PB)                                                                         \
+    mf[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][0], fb[PB], mf[0], 0, 0, 0); \
+    mf[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][1], fb[PB], mf[1], 0, 0, 0);
+#define WX3_STEP WX3(0, 0) WX3(0, 1) WX3(1, 0) WX3(1, 1) WX3(2, 0) WX3(0, 2)
+        frags(0);
+        store_chunk(cur ^ 1, xs);
+        if (ABL != 3) load_chunk(xs);
+        WX3_STEP
+        frags(1);
+        WX3_STEP
+#undef WX3_STEP
+#undef WX3
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    int cf = 0, ckc = 0;
+    for (int it = 0; it < NIT; it += 2) {
+        mma(0, xsB);
+        if (++ckc == KC) {
+            ckc = 0;
+            fold(mf, cf++);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");  // all but the two youngest (chunk it+3's V loads): the weight DMA has landed
+        if (ABL != 1) __syncthreads();
+        mma(1, xsA);
+        if (++ckc == KC) {
+            ckc = 0;
+            fold(mf, cf++);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (ABL != 1) __syncthreads();
+    }
+
+    const int t = t0 + wm * 32 + (lane & 31);
+    if (t >= a.T) return;
+    const int tx = t % a.Tx;
+    const int r = t / a.Tx;
+    const int ty = r % a.Ty, b = r / a.Ty;
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+        const int oy = 2 * ty + (ij >> 1), ox = 2 * tx + (ij & 1);
+        if (oy >= a.Hl || ox >= a.Wl) continue;
+        const size_t ooff = (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
+        float *orow = a.y + ooff;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = wn * 64 + ni * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
+                if (n >= a.Cout) continue;
+                f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+                if (a.act == A3D_ACT_RELU) {
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                } else if (a.act == A3D_ACT_LEAKY) {
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
+                }
+                if (a.gate) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
+                    for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(orow + n) = v;
+            }
+        }
+    }
+}
+
 // src [outer][rows][cols] fp32 -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly: the chunk-major
 // plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a
 // plain [rows][cols] plane layout a lane's 16-byte piece of a row is a 64-byte-strided access and the kernel runs 2x slower).
@@ -581,6 +822,48 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
+        // 128 tiles x 128 channels with DMA-staged weights (one 512-thread workgroup per CU) where the second 64 channels are not
+        // padding and the 128-tile blocks fill the chip for >= 3 rounds; measured per shape (tools/x3w_check.py): p2 256->256 layer
+        // 4.27 -> 3.80 ms, 14x14 ROI-head layers 1.30 -> 1.07 ms, 60x80 level equal, 30x40 and below slower (tail) -> 64-wide form.
+        // tune 8: the 64-wide form everywhere; A3D_X3W_WM=2|4 forces a wide form (A/B runs and the bit-equality test).
+        static int wm_force = -1;
+        if (wm_force < 0) wm_force = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
+        const int ntw = (d->Cout + X3W_BN - 1) / X3W_BN;
+        const long blocks128 = (long)((T + 127) / 128) * ntw;
+        const bool wide = d->tune != 8 && ((d->Cout + 63) / 64) % 2 == 0 && (size_t)16 * d->Cout * a.C * 6 < ((size_t)1 << 32) &&
+                          (wm_force || blocks128 >= 3 * 256);
+        if (wide) {
+            const int nt = ntw;
+            const int wmx = wm_force ? wm_force : 4;
+            static bool attr_set = false;
+            if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+                if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2)) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4)) != hipSuccess)
+                    return A3D_ERR_LAUNCH;
+                attr_set = true;
+            }
+            a3d_note_variant("wino_gemm_x3w_kernel<%d>", wmx);
+#ifdef A3D_ABLATIONS
+            static int abl = -1;
+            if (abl < 0) abl = getenv("A3D_X3W_ABL") ? atoi(getenv("A3D_X3W_ABL")) : 0;
+#define ABL_CASE(N)                                                                                                                          \
+    if (abl == N && wmx == 4) {                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, N>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4));   \
+        const int m4 = (int)((T + 127) / 128);                                                                                               \
+        hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, N>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4), s, a, nt, m4 * nt);                     \
+        return A3D_OK;                                                                                                                       \
+    }
+            ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(6)
+#undef ABL_CASE
+#endif
+            if (wmx == 4) {
+                const int m4 = (int)((T + 127) / 128);
+                hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, 0>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4), s, a, nt, m4 * nt);
+            } else {
+                hipLaunchKernelGGL((wino_gemm_x3w_kernel<2, 0>), dim3(mtiles * nt), dim3(256), x3w_lds_bytes(2), s, a, nt, mtiles * nt);
+            }
+            return A3D_OK;
+        }
         const int nt = (d->Cout + 63) / 64;
         a3d_note_variant("wino_gemm_x3_kernel");
         hipLaunchKernelGGL(wino_gemm_x3_kernel, dim3(mtiles * nt), dim3(256), 0, s, a, nt, mtiles * nt);

@@ -301,7 +301,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
-    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7) or tune >= 200) and not ups
+    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7, 8) or tune >= 200) and not ups
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
         mode = DEFAULT_PRECISION if precision is None else 2
@@ -322,7 +322,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
-    use_wino = wino_ok and (precision == 0 or (precision == 2 and tune == 0 and (Cin + Cin2) % 32 == 0))
+    use_wino = wino_ok and (precision == 0 or (precision == 2 and tune in (0, 8) and (Cin + Cin2) % 32 == 0))
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()

@@ -113,6 +113,26 @@ def test_shared_winograd_input_transform_is_bit_identical(ops, precision):
     assert sum(n.startswith(gemm) for n in names) >= 2
 
 
+@pytest.mark.parametrize("shape", [(64, 60, 80, 256, 256), (330, 30, 40, 128, 128), (2100, 14, 14, 256, 256), (21, 121, 159, 64, 128)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_wide_split_operand_winograd_gemm_is_bit_identical_to_the_64_wide_form(ops, shape):
+    """wino_gemm_x3w_kernel<4> (128 tiles x 128 channels, pre-split weight planes global -> LDS by LDS-DMA, 512 threads) keeps the
+    per-output operation order of wino_gemm_x3_kernel: equal bits, so the launcher may choose between them by problem size
+    (ragged tile / channel edges included)."""
+    B, H, W, Cin, Cout = shape
+    torch.manual_seed(3)
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
+    pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_LEAKY)
+    y_wide = ops.conv2d(x, pk, precision=2)
+    assert ops.last_conv_variant().startswith("wino_gemm_x3w_kernel<4>"), ops.last_conv_variant()
+    y_64 = ops.conv2d(x, pk, precision=2, tune=8)
+    assert ops.last_conv_variant() == "wino_gemm_x3_kernel", ops.last_conv_variant()
+    assert torch.equal(y_wide, y_64)
+    ref = F.leaky_relu(F.conv2d(x[-2:].permute(0, 3, 1, 2).double().cpu(), w.double(), pk.shift[:Cout].double().cpu(), padding=1), 0.01)
+    assert rel(y_wide[-2:, :, :, :Cout].permute(0, 3, 1, 2).double(), ref) < 2e-6  # (the last images: the ragged tile block is there)
+
+
 def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.3
