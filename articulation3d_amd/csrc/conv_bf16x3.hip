@@ -259,6 +259,8 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
 }  // namespace
 
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
+    const int rw = a3d_conv_launch_bf16x3_wide(d, s);  // wide and large layers with pre-split weights (bit-identical results)
+    if (rw != A3D_ERR_UNSUPPORTED) return rw;
     if (d->stem || d->ups || d->pixshuf || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
     if (d->phase && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->res)) return A3D_ERR_UNSUPPORTED;
     if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_UNSUPPORTED;

@@ -1,0 +1,366 @@
+// fp32-grade convolution / linear kernel on the bf16 matrix pipe, WIDE form (a3d_conv_desc.precision == 2 with w_x3 given).
+//
+// Same arithmetic as conv_bf16x3.hip (every fp32 operand split exactly into hi | mid | lo bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 per 16-deep k step, fp32 accumulation) and the same per-output operation order -- the two kernels
+// agree bit for bit (tests/test_gpu_parity.py), so the launcher chooses by problem size.  What differs is the data movement,
+// shaped by what the split-operand Winograd GEMM taught (conv_wino.hip, "2x-wide"): these loops are bound by the issue cost of
+// their vector-memory instructions (~100 cycles each inside an MFMA stream, 1 KiB per instruction) and by the VALU / VGPR -> LDS
+// work of the in-kernel split, i.e. by operand bytes per MFMA, not by the matrix pipe.
+//
+//   conv_x3_kernel<2>: 128 px x 128 ch per 256-thread workgroup, both operands fp32 through registers, split in the kernel:
+//       16 KiB-loads and 1024 split float4 per 96 MFMAs, fragment reads 0.5 per MFMA.
+//   this kernel:       256 px x 256 ch per 512-thread workgroup (8 waves as 4 x 2, wave tile 64 px x 128 ch = 8 accumulators):
+//       16 activation loads + 24 weight DMA pieces and 1024 split float4 per 384 MFMAs (0.10 vector-memory instructions per
+//       MFMA instead of 0.17, a quarter of the split work), fragment reads 0.375 per MFMA.
+//       WEIGHTS are pre-split once per layer into bf16 planes in chunk-major LDS-image order (a3d_conv_desc.w_x3, a3d_split_bf16x3_chunk
+//       with chunk = 16) and go global -> LDS by LDS-DMA: no registers, no VALU, no VGPR -> LDS stores for that operand.
+//
+// Schedule.  One 16-deep chunk per iteration = 48 MFMAs per wave in four channel blocks n = 0..3 of 12 (six terms x two pixel
+// blocks); ONE barrier per iteration, after block 1:
+//   n = 0, 1 : fragments b(c) (activations, all three planes) and a(c)[n] in registers; the staged activation chunk c+1 is split
+//              into X stage (c+1) % 2; a(c)[n+1] is read one block ahead
+//   -- wait: weight DMA of chunk c+1 landed (counted vmcnt), own LDS traffic drained; barrier --
+//   n = 2    : weight DMA of chunk c+2 into W stage (c+2) % 3 (three weight stages: the fragments a(c)[n] are read block by
+//              block, so stage c % 3 stays in use to the end of the iteration), activation loads of chunk c+3 (two register
+//              sets), a(c)[3] read
+//   n = 3    : b(c+1) and a(c+1)[0] read from the stages the barrier has just completed
+// Registers: 8 x 16 accumulators + two b sets (24 each) + two a sets (12 each) + 16 staging = 216 of the 256 that two waves per
+// SIMD leave each wave.  LDS: 2 x 24 KiB (X) + 3 x 24 KiB (W) + scale | shift.
+#include "conv_common.h"
+
+namespace {
+typedef __bf16 wx_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wx_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 wx_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void wx_dma16(__amdgpu_buffer_rsrc_t r, __bf16 *lds_dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, soff, 0, 0);
+}
+// x = h + m + l exactly (round-to-nearest-even at each level): conv_bf16x3.hip's split3
+__device__ __forceinline__ void wx_split3(const f32x4 v, wx_bf16x4 &h, wx_bf16x4 &m, wx_bf16x4 &l) {
+    h = __builtin_convertvector(v, wx_bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, wx_bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, wx_bf16x4);
+}
+
+constexpr int XW_BM = 256, XW_BN = 256, XW_BK = 16;
+constexpr int XW_PX = XW_BM * XW_BK, XW_PW = XW_BN * XW_BK;  // one operand plane of one stage (bf16 elements; 32-byte rows)
+constexpr int XW_XST = 3 * XW_PX, XW_WST = 3 * XW_PW;        // one stage
+constexpr int XW_LDS_BYTES = (2 * XW_XST + 3 * XW_WST) * 2 + 2 * XW_BN * 4;
+
+__global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    constexpr int TM = 2, TN = 4, BM = XW_BM, BN = XW_BN, BKT = XW_BK, LKB = XW_BK;
+    constexpr int TPR = BKT / 4, RPP = 512 / TPR, XR = BM / RPP;  // 4 lanes x float4 per row, 128 rows per pass, 2 passes
+    constexpr int PX = XW_PX, PW = XW_PW;
+    static_assert(XR == 2, "the counted vmcnt waits below assume two activation loads per chunk");
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 *const Xs = lds;                  // [2][3][256][16]
+    __bf16 *const Ws = lds + 2 * XW_XST;     // [3][3][256][16]
+    float *const ss = reinterpret_cast<float *>(lds + 2 * XW_XST + 3 * XW_WST);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int logical = a3d_xcd_remap(blockIdx.x, nblk);
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int nk = d.Kpad / BKT;
+    const int lr = tid / TPR, lc = (tid % TPR) * 4;
+    // LDS image (both operands): [plane][row][16 k] bf16, 32-byte rows; the 16-byte half holding k = 8h..8h+7 of row r sits at slot
+    // h ^ ((r >> 3) & 1) -- conv_bf16x3.hip's image (conflict-free ds_read_b128 and ds_write_b64)
+    const int lcs = (lc & 7) | ((((lc >> 3) ^ (lr >> 3)) & 1) << 3);
+    const int cs4 = d.Cin * 4;
+    const int CinT = d.Cin + d.Cin2;
+    const __amdgpu_buffer_rsrc_t rx = wx_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const __amdgpu_buffer_rsrc_t rx2 = wx_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const unsigned w3chunk = (unsigned)d.Cout * 96u;  // bytes of one chunk of w_x3: 3 planes x Cout rows x 32 B
+    const __amdgpu_buffer_rsrc_t rw = wx_rsrc(d.w_x3, (unsigned)((size_t)nk * w3chunk));
+
+    int rowoff[XR];
+    unsigned vmask[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = m0 + lr + RPP * i;
+        const bool rok = m < M;
+        const int mm = rok ? m : 0;
+        const int hw = d.Ho * d.Wo;
+        const int b = mm / hw, r = mm - b * hw;
+        const int oh = r / d.Wo, ow = r - oh * d.Wo;
+        int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        if (d.phase) {  // 2x2 taps of output phase (dy,dx) of an upsampled 3x3 conv, on the source grid (conv_gemm_v2.hip)
+            ih0 = oh - 1 + ((d.phase - 1) >> 1);
+            iw0 = ow - 1 + ((d.phase - 1) & 1);
+        }
+        unsigned mask = 0;
+        for (int kh = 0; kh < d.KH; ++kh)
+            for (int kw = 0; kw < d.KW; ++kw)
+                mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
+        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        vmask[i] = mask;
+    }
+    int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next activation chunk to load inside the filter
+    f32x4 xsA[XR], xsB[XR];
+    auto load_chunk = [&](f32x4 (&xs)[XR]) {
+        const int tap = kh * d.KW + kw;
+        const unsigned livebit = (kc < nk) ? 1u : 0u;
+        const bool second = c0 >= d.Cin;  // channel concat: the second source supplies channels Cin .. Cin+Cin2-1 of every tap
+        const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
+        const int tapoff = (kh * d.W + kw) * cs4 + (second ? c0 - d.Cin : c0) * 4;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) xs[i] = wx_load4(r, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+        ++kc;
+        c0 += BKT;
+        if (c0 >= CinT) {
+            c0 = 0;
+            if (++kw == d.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    struct Split {
+        wx_bf16x4 h, m, l;
+    };
+    auto put = [&](const int xst, const int i, const Split &v) {  // the three planes of loader row lr + RPP i
+        __bf16 *p = Xs + xst * XW_XST + (lr + RPP * i) * LKB + lcs;
+        *reinterpret_cast<wx_bf16x4 *>(p) = v.h;
+        *reinterpret_cast<wx_bf16x4 *>(p + PX) = v.m;
+        *reinterpret_cast<wx_bf16x4 *>(p + 2 * PX) = v.l;
+    };
+    // weights: w_x3 [Kpad/16][3][Cout][16] bf16; one (chunk, plane) tile of this workgroup's 256 rows is an 8 KiB run = 8 DMA
+    // wave-instructions of 32 rows.  Lane i of an instruction lands at LDS byte 16 i of its 1 KiB = row i/2, half i%2, and fetches
+    // the k half that the image keeps there: half ^ ((row >> 3) & 1)  (row base is a multiple of 32).  Rows past Cout read the
+    // next plane's rows or, past the end of w_x3, zeros: their accumulators are never stored.
+    const int wvoff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    int dma_c = 0, dma_st = 0;  // chunk and W stage of the next weight DMA (chunks past nk lie past the end of w_x3: zeros)
+    auto dma_w = [&]() {
+        __bf16 *Wt = Ws + dma_st * XW_WST;
+        const int base = __builtin_amdgcn_readfirstlane(dma_c * (int)w3chunk + n0 * 32);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave * 3 + i;  // 24 instructions per chunk: plane j/8, row group j%8
+            const int p = j >> 3, g = j & 7;
+            wx_dma16(rw, Wt + p * PW + g * 32 * LKB, wvoff, base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + g * 1024));
+        }
+        ++dma_c;
+        dma_st = dma_st == 2 ? 0 : dma_st + 1;
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    a3d_stage_scale_shift(ss, d, n0, BN, tid);
+
+    // fragments: row = lane % 32 of a 32-row block, k = 8 * (lane / 32) .. + 7
+    const int frow = lane & 31;
+    const int frag_off = frow * LKB + ((((lane >> 5) ^ (frow >> 3)) & 1) << 3);
+    const __bf16 *const fX = Xs + (wm * TM * 32) * LKB + frag_off;
+    const __bf16 *const fW = Ws + (wn * TN * 32) * LKB + frag_off;
+    struct FragA {
+        wx_bf16x8 p[3];  // weights of one 32-channel block, hi | mid | lo
+    };
+    struct FragB {
+        wx_bf16x8 p[3][TM];  // activations of the wave's two 32-pixel blocks
+    };
+    auto rdA = [&](FragA &A, const int wst, const int n) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) A.p[p] = *reinterpret_cast<const wx_bf16x8 *>(fW + wst * XW_WST + p * PW + n * 32 * LKB);
+    };
+    auto rdB = [&](FragB &Bf, const int xst, const int p) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) Bf.p[p][mi] = *reinterpret_cast<const wx_bf16x8 *>(fX + xst * XW_XST + p * PX + mi * 32 * LKB);
+    };
+
+#define XW_FENCE __builtin_amdgcn_sched_barrier(0);
+#define XW_TERM(N, A, Bf, PA, PB)                                                                     \
+    acc[N][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.p[PA], Bf.p[PB][0], acc[N][0], 0, 0, 0); \
+    acc[N][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.p[PA], Bf.p[PB][1], acc[N][1], 0, 0, 0);
+// (one MFMA, then its share of the block's other instructions: the wave issues in order, so what follows an MFMA runs in its shadow)
+#define XW_MIX(NV)                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+// the tail of a channel block: the four terms that carry no other work
+#define XW_REST(N, A, Bf) \
+    XW_TERM(N, A, Bf, 1, 1) XW_FENCE XW_TERM(N, A, Bf, 2, 0) XW_FENCE XW_TERM(N, A, Bf, 0, 2) XW_FENCE
+
+    int wst = 0;  // W stage of the chunk being multiplied
+    // one iteration; xst = X stage of chunk c (compile-time), Bc / Bn = the b sets of chunk c / c+1, xs = the staged chunk c+1
+    auto iteration = [&](const int xst, FragA &A0, FragA &A1, FragB &Bc, FragB &Bn, f32x4 (&xs)[XR]) {
+        const int wnext = wst == 2 ? 0 : wst + 1;
+        Split s;
+        // ---- n = 0
+        XW_TERM(0, A0, Bc, 0, 0)
+        wx_split3(xs[0], s.h, s.m, s.l);
+        XW_MIX(12)
+        XW_FENCE
+        XW_TERM(0, A0, Bc, 0, 1)
+        put(xst ^ 1, 0, s);
+        XW_MIX(4)
+        XW_FENCE
+        XW_TERM(0, A0, Bc, 1, 0)
+        rdA(A1, wst, 1);
+        XW_MIX(4)
+        XW_FENCE
+        XW_REST(0, A0, Bc)
+        // ---- n = 1
+        XW_TERM(1, A1, Bc, 0, 0)
+        wx_split3(xs[1], s.h, s.m, s.l);
+        XW_MIX(12)
+        XW_FENCE
+        XW_TERM(1, A1, Bc, 0, 1)
+        put(xst ^ 1, 1, s);
+        XW_MIX(4)
+        XW_FENCE
+        XW_TERM(1, A1, Bc, 1, 0)
+        rdA(A0, wst, 2);
+        XW_MIX(4)
+        XW_FENCE
+        XW_REST(1, A1, Bc)
+        __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");  // all but the two youngest (activation loads): the weight DMA of chunk c+1 has landed
+        __syncthreads();
+        // ---- n = 2
+        XW_TERM(2, A0, Bc, 0, 0)
+        dma_w();
+        XW_MIX(6)
+        XW_FENCE
+        XW_TERM(2, A0, Bc, 0, 1)
+        load_chunk(xs);
+        XW_MIX(8)
+        XW_FENCE
+        XW_TERM(2, A0, Bc, 1, 0)
+        rdA(A1, wst, 3);
+        XW_MIX(4)
+        XW_FENCE
+        XW_REST(2, A0, Bc)
+        // ---- n = 3
+        XW_TERM(3, A1, Bc, 0, 0)
+        rdB(Bn, xst ^ 1, 0);
+        rdB(Bn, xst ^ 1, 1);
+        XW_MIX(4)
+        XW_FENCE
+        XW_TERM(3, A1, Bc, 0, 1)
+        rdB(Bn, xst ^ 1, 2);
+        rdA(A0, wnext, 0);
+        XW_MIX(4)
+        XW_FENCE
+        XW_TERM(3, A1, Bc, 1, 0)
+        XW_FENCE
+        XW_REST(3, A1, Bc)
+        wst = wnext;
+    };
+
+    // prologue: W(0), W(1) by DMA; X(0) split into X stage 0; X(1), X(2) staged in registers; b(0), a(0)[0] read
+    FragA A0, A1;
+    FragB B0, B1;
+    dma_w();
+    dma_w();
+    load_chunk(xsA);
+    {
+        Split s0, s1;
+        wx_split3(xsA[0], s0.h, s0.m, s0.l);
+        wx_split3(xsA[1], s1.h, s1.m, s1.l);
+        put(0, 0, s0);
+        put(0, 1, s1);
+    }
+    load_chunk(xsB);
+    load_chunk(xsA);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rdB(B0, 0, p);
+    rdA(A0, 0, 0);
+    XW_FENCE
+
+    for (int it = 0; it < nk; it += 2) {  // (Kpad % 32 == 0 on every packed layer; an odd chunk count would multiply one all-zero chunk: loads / DMA past nk read 0)
+        iteration(0, A0, A1, B0, B1, xsB);
+        iteration(1, A0, A1, B1, B0, xsA);
+    }
+#undef XW_REST
+#undef XW_MIX
+#undef XW_TERM
+#undef XW_FENCE
+
+    const bool has_res = d.res != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
+        if (m >= M) continue;
+        size_t res_row;
+        int b, oh, ow;
+        out_rows(d, m, res_row, b, oh, ow);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            f32x4 rv[4];
+            if (has_res) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    rv[rg] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + min(n, d.Cout - 4));
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                const int n = n0 + nl;
+                if (n >= d.Cout) continue;
+                f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                store_out(d, v, m, n, b, oh, ow);
+            }
+        }
+    }
+}
+}  // namespace
+
+// Returns A3D_ERR_UNSUPPORTED when the layer should take conv_x3_kernel (conv_bf16x3.hip): no pre-split weights, a shallow reduction,
+// a narrow or small problem (256-wide channel tiles mostly padding, or too few 256 x 256 tiles to fill the 256 CUs twice), 32-bit
+// offset limits.
+int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
+    if (!d->w_x3 || d->tune == 8) return A3D_ERR_UNSUPPORTED;
+    if (d->stem || d->ups || d->pixshuf || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->phase && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->res)) return A3D_ERR_UNSUPPORTED;
+    if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_UNSUPPORTED;
+    if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * (d->Cin + d->Cin2) || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 6 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + XW_BM - 1) / XW_BM, ntiles = (d->Cout + XW_BN - 1) / XW_BN;
+    if (d->tune != 9) {  // (tune 9 forces this kernel: A/B runs and the bit-equality test)
+        // Measured per layer shape (tools/x3_wide_check.py, 64 frames): the box head's fc1 (K = 12544) 8.32 -> 6.99 ms (235 fp32-
+        // equivalent TFLOP/s); K = 2048 equal; K <= 1024 equal to 15 % slower -- with ONE workgroup per CU nothing overlaps the
+        // prologue and the 256 x 256 epilogue (residual reads, stores), which a 16..64-iteration loop does not amortise, where
+        // the narrow kernel's three workgroups per CU cover each other's.  Hence deep reductions only.
+        if (d->Kpad < 4096) return A3D_ERR_UNSUPPORTED;
+        if (d->Cout < 192 || ntiles * XW_BN > d->Cout + d->Cout / 4) return A3D_ERR_UNSUPPORTED;
+        if ((long)mtiles * ntiles < 2 * 256) return A3D_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+        if (hipFuncSetAttribute((const void *)conv_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XW_LDS_BYTES) != hipSuccess) return A3D_ERR_LAUNCH;
+        attr_set = true;
+    }
+    a3d_note_variant("conv_x3w_kernel");
+    hipLaunchKernelGGL(conv_x3w_kernel, dim3(mtiles * ntiles), dim3(512), XW_LDS_BYTES, s, *d, M, ntiles, mtiles * ntiles);
+    return a3d_check_launch();
+}

@@ -112,6 +112,8 @@ int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s);
 // fp32-grade 3-way bf16 split on the bf16 matrix pipe (conv_bf16x3.hip), selected by a3d_conv_desc.precision == 2.
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
+// its wide form (conv_bf16x3_wide.hip: 256 x 256 tiles, pre-split weights by LDS-DMA); A3D_ERR_UNSUPPORTED -> the kernel above
+int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s);
 
 // Winograd F(2x2,3x3) path (conv_wino.hip).  eligible() ignores the workspace pointer (used for sizing).
 int a3d_wino_eligible(const a3d_conv_desc *d);

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 // plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a
 // plain [rows][cols] plane layout a lane's 16-byte piece of a row is a 64-byte-strided access and the kernel runs 2x slower).
 // a3d_conv_desc.w_wino_x3: outer = 16, rows = Cout, cols = Cin + Cin2.
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int rows, int cols, size_t total) {
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int rows, int cols, int chunk, size_t total) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     const size_t per = (size_t)rows * cols;
@@ -842,18 +842,23 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
     const int n = (int)(r / cols), c = (int)(r - (size_t)n * cols);
     wbf16x4 h, m, l;
     wsplit3(*reinterpret_cast<const f32x4 *>(src + i), h, m, l);
-    __bf16 *d = dst + o * 3 * per + ((size_t)(c >> 5) * 3 * rows + n) * 32 + (c & 31);
+    __bf16 *d = dst + o * 3 * per + ((size_t)(c / chunk) * 3 * rows + n) * chunk + (c % chunk);
     *reinterpret_cast<wbf16x4 *>(d) = h;
-    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * 32) = m;
-    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * 64) = l;
+    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * chunk) = m;
+    *reinterpret_cast<wbf16x4 *>(d + (size_t)rows * chunk * 2) = l;
+}
+
+extern "C" int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, void *stream) {
+    if (!src || !dst || outer <= 0 || rows <= 0 || cols <= 0 || (chunk != 16 && chunk != 32) || cols % chunk) return A3D_ERR_ARG;
+    a3d_begin();
+    const size_t total = (size_t)outer * rows * cols;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16 *)dst, rows, cols, chunk,
+                       total);
+    return a3d_check_launch();
 }
 
 extern "C" int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream) {
-    if (!src || !dst || outer <= 0 || rows <= 0 || cols <= 0 || (cols & 31)) return A3D_ERR_ARG;
-    a3d_begin();
-    const size_t total = (size_t)outer * rows * cols;
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16 *)dst, rows, cols, total);
-    return a3d_check_launch();
+    return a3d_split_bf16x3_chunk(src, dst, outer, rows, cols, 32, stream);
 }
 
 int a3d_wino_eligible(const a3d_conv_desc *d) {

@@ -88,6 +88,8 @@ class PackedConv:
     w_wino_x3: Optional[torch.Tensor] = None  # [16, Cin/32, 3, cols, 32] bf16 planes of w_wino, made at the first precision-2 use
     w_wino_cm: Optional[torch.Tensor] = None  # [Cin/8, 16, cols, 8] chunk-major copy of w_wino: the one-launch Winograd kernel
     phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
+    presplit: bool = False  # set by the pack_* functions (module-cached weights): precision-2 launches may cache w_x3 below
+    w_x3: Optional[torch.Tensor] = None  # [Kpad/16, 3, cols, 16] bf16 planes of w (a3d_conv_desc.w_x3), made at the first such use
 
     @property
     def out_channels(self) -> int:
@@ -130,7 +132,7 @@ def pack_conv(weight: torch.Tensor, bias=None, bn=None, stride=1, pad=0, act=ACT
     if shift is not None:
         shift = _pad_rows(shift)
     dev = lambda t: None if t is None else t.contiguous().to(device)
-    pk = PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act)
+    pk = PackedConv(dev(w), dev(scale), dev(shift), KH, KW, stride, pad, Cin, cols, KH * KW * Cin, act, presplit=True)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 16 == 0:
         U = winograd_weights(_pad_rows(weight.detach().float()))
         pk.w_wino = dev(U)
@@ -163,7 +165,7 @@ def pack_conv_ups_phases(weight: torch.Tensor, bias=None, bn=None, act=ACT_NONE,
                         for kw in kws:
                             wp[:, :, a, b] += w[:, :, kh, kw]
             wk = _pad_rows(wp.float().permute(0, 2, 3, 1).reshape(Cout, 4 * Cin))
-            out.append(PackedConv(dev(wk), scale_d, shift_d, 2, 2, 1, 0, Cin, wk.shape[0], 4 * Cin, act, phase=1 + dy * 2 + dx))
+            out.append(PackedConv(dev(wk), scale_d, shift_d, 2, 2, 1, 0, Cin, wk.shape[0], 4 * Cin, act, phase=1 + dy * 2 + dx, presplit=True))
     return out
 
 
@@ -216,7 +218,7 @@ def pack_linear(weight: torch.Tensor, bias=None, chw: Optional[Tuple[int, int, i
     w = _pad_rows(w)
     shift = None if bias is None else _pad_rows(bias.detach().float())
     dev = lambda t: None if t is None else t.contiguous().to(device)
-    return PackedConv(dev(w), None, dev(shift), 1, 1, 1, 0, K, w.shape[0], K, act)
+    return PackedConv(dev(w), None, dev(shift), 1, 1, 1, 0, K, w.shape[0], K, act, presplit=True)
 
 
 def pack_deconv2x2(weight: torch.Tensor, bias, act=ACT_RELU, device="cuda") -> PackedConv:
@@ -334,6 +336,13 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                 p.w_wino_x3 = torch.empty((16, cols // 32, 3, rows, 32), device=p.w_wino.device, dtype=torch.bfloat16)
                 _lib.check(_lib.lib().a3d_split_bf16x3(p.w_wino.data_ptr(), p.w_wino_x3.data_ptr(), 16, rows, cols, _stream()), "a3d_split_bf16x3")
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
+    if (d.precision == 2 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
+            and not (p.stem or p.pixshuf)):
+        # wide layers: weight planes pre-split once per packed layer, streamed by LDS-DMA (csrc/conv_bf16x3_wide.hip)
+        if p.w_x3 is None or p.w_x3.device != p.w.device:
+            p.w_x3 = torch.empty((p.Kpad // 16, 3, p.w.shape[0], 16), device=p.w.device, dtype=torch.bfloat16)
+            _lib.check(_lib.lib().a3d_split_bf16x3_chunk(p.w.data_ptr(), p.w_x3.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, _stream()), "a3d_split_bf16x3_chunk")
+        d.w_x3 = p.w_x3.data_ptr()
     fused_wino = False
     shared = None  # [input tensor, its transformed tiles V or None]: see share_wino_input
     if use_wino or splitk > 1:

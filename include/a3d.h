@@ -88,7 +88,9 @@ typedef struct a3d_conv_desc {
                          so ragged per-ROI batches need no host synchronisation                      */
     int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel;
                          2 = direct implicit GEMM even when w_wino is given; 5 / 6 = never / always use the persistent
-                         pointwise kernel on eligible 1x1 layers; >= 100: explicit tile variant */
+                         pointwise kernel on eligible 1x1 layers; 7 = two-launch Winograd where the one-launch kernel would
+                         run; precision 2: 8 = the narrow split-operand kernels (64-wide Winograd GEMM, 128 x 128 direct),
+                         9 = the wide direct kernel whatever the problem size; >= 100: explicit tile variant */
     int phase;        /* 0, or 1..4 = output phase (dy,dx) = ((phase-1)>>1, (phase-1)&1) of a 3x3 pad-1 convolution over a
                          nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
                          taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
@@ -117,6 +119,11 @@ typedef struct a3d_conv_desc {
                             With it a plain 3x3 s1 p1 layer (one source, no upsampling, precision 0, tune 0) runs
                             the ONE-launch Winograd kernel that transforms the input inside the GEMM loader
                             (csrc/conv_wino_fused.hip): no workspace, no 16-plane tensor in HBM                          */
+    const void *w_x3;    /* optional, precision 2 on a direct (non-Winograd) layer: w split into three bf16 planes in 16-deep
+                            chunk-major order [Kpad/16][3][Cout][16] (a3d_split_bf16x3_chunk with outer = 1, rows = Cout,
+                            cols = Kpad, chunk = 16).  With it, wide and large layers run the 256 x 256-tile kernel that
+                            moves the weight planes global -> LDS by LDS-DMA (csrc/conv_bf16x3_wide.hip); results are
+                            bit-identical to the kernel that splits w on the fly                                       */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -124,6 +131,8 @@ int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
 /* src [outer][rows][cols] fp32 (cols % 32 == 0) -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly
  * (round-to-nearest-even at each level). */
 int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream);
+/* The same with `chunk`-deep column chunks (16 or 32; cols % chunk == 0): dst [outer][cols/chunk][3][rows][chunk]. */
+int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, void *stream);
 
 /* The two launches of the Winograd form, individually (a3d_conv2d_nhwc_f32 issues both when d->w_wino is set):
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */

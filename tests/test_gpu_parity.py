@@ -133,6 +133,38 @@ def test_wide_split_operand_winograd_gemm_is_bit_identical_to_the_64_wide_form(o
     assert rel(y_wide[-2:, :, :, :Cout].permute(0, 3, 1, 2).double(), ref) < 2e-6  # (the last images: the ragged tile block is there)
 
 
+@pytest.mark.parametrize("case", [dict(B=33000, H=1, W=1, Cin=4096, Cout=1024, k=1, s=1, res=False),  # default dispatch: deep reduction
+                                  dict(B=3, H=30, W=40, Cin=256, Cout=1000, k=1, s=1, res=True),     # ragged channel tile, residual
+                                  dict(B=2, H=33, W=41, Cin=64, Cout=256, k=3, s=2, res=False),      # taps, stride, ragged pixel tile
+                                  dict(B=2, H=16, W=24, Cin=96, Cout=512, k=1, s=1, res=False)],     # six-chunk loop: mostly prologue / epilogue
+                         ids=lambda c: f"{c['B']}x{c['H']}x{c['W']}x{c['Cin']}->{c['Cout']}k{c['k']}s{c['s']}")
+def test_wide_split_operand_direct_kernel_is_bit_identical_to_the_narrow_one(ops, case):
+    """conv_x3w_kernel (256 x 256 tiles, weight planes pre-split once per layer and moved global -> LDS by LDS-DMA, one barrier per
+    16-deep chunk) keeps conv_x3_kernel's per-output operation order: equal bits, so the launcher may choose by problem shape."""
+    c = case
+    torch.manual_seed(9)
+    x = torch.randn(c["B"], c["H"], c["W"], c["Cin"], device="cuda")
+    w = torch.randn(c["Cout"], c["Cin"], c["k"], c["k"]) / (c["k"] * c["Cin"] ** 0.5)
+    pk = ops.pack_conv(w, torch.randn(c["Cout"]) * 0.1, None, c["s"], c["k"] // 2, ops.ACT_RELU)
+    Ho = (c["H"] + 2 * (c["k"] // 2) - c["k"]) // c["s"] + 1
+    Wo = (c["W"] + 2 * (c["k"] // 2) - c["k"]) // c["s"] + 1
+    res = torch.randn(c["B"], Ho, Wo, pk.cols, device="cuda") if c["res"] else None
+    wide = ops.conv2d(x, pk, precision=2, tune=9, res=res)
+    assert ops.last_conv_variant() == "conv_x3w_kernel", ops.last_conv_variant()
+    narrow = ops.conv2d(x, pk, precision=2, tune=8, res=res)
+    assert ops.last_conv_variant().startswith("conv_x3_kernel"), ops.last_conv_variant()
+    assert torch.equal(wide, narrow)
+    if c["Cin"] >= 4096:
+        ops.conv2d(x, pk, precision=2, res=res)
+        assert ops.last_conv_variant() == "conv_x3w_kernel", ops.last_conv_variant()
+    nb = min(c["B"], 64)  # (the float64 reference on the leading images / rows only)
+    ref = F.conv2d(x[:nb].permute(0, 3, 1, 2).double().cpu(), w.double(), pk.shift[:c["Cout"]].double().cpu(), stride=c["s"], padding=c["k"] // 2)
+    if res is not None:
+        ref = ref + res[:nb, :, :, :c["Cout"]].permute(0, 3, 1, 2).double().cpu()
+    # fp32 accumulation over K terms: ~sqrt(K) * 2^-24 of the output scale (4e-6 at K = 4096)
+    assert rel(wide[:nb, :, :, :c["Cout"]].permute(0, 3, 1, 2).double(), F.relu(ref)) < 5e-6
+
+
 def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.3
