@@ -251,7 +251,12 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float *__restric
     f32x4 k[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const f32x4 *>(w + t * C + sub * 4);
-    for (size_t r = (size_t)blockIdx.x * grp_per_blk + threadIdx.x / lanes_per_pix; r < nruns; r += (size_t)gridDim.x * grp_per_blk) {
+    // one block = grp_per_blk consecutive runs; the blocks of an XCD are a contiguous band of rows (a3d_xcd_remap), so the two
+    // neighbour rows a block reads come from the same L2 that the neighbouring blocks filled (round-robin placement put the three
+    // readers of a row on three XCDs: 3.07x the input fetched, 3.9 GB per launch)
+    {
+        const size_t r = (size_t)a3d_xcd_remap(blockIdx.x, gridDim.x) * grp_per_blk + threadIdx.x / lanes_per_pix;
+        if (r >= nruns) return;
         const int ow0 = (int)(r % Wr) * 4;
         const size_t t = r / Wr;
         const int oh = (int)(t % H);
@@ -292,8 +297,8 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
     if ((C & 3) || lpp > 64 || (lpp & (lpp - 1))) return A3D_ERR_UNSUPPORTED;
     const size_t nruns = (size_t)B * H * ((W + 3) / 4);
     const int gpb = 256 / lpp;
-    size_t blocks = (nruns + gpb - 1) / gpb;
-    if (blocks > 16384) blocks = 16384;
+    const size_t blocks = (nruns + gpb - 1) / gpb;
+    if (blocks >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
     a3d_begin();
     hipLaunchKernelGGL(conv3x3_to1_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, H, W,
                        C);
