@@ -314,7 +314,10 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
             x3_ok = (not (p.stem or ups or p.pixshuf or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
                      and (x2 is None or Cin2 == Cin) and Cin % 16 == 0 and not (p.phase and res is not None))
-            # Winograd layers keep the Winograd form with the split-operand GEMM (conv_wino.hip 2x, 32-deep chunks)
+            # Winograd layers keep the Winograd form with the split-operand GEMM (conv_wino.hip 2x, 32-deep chunks).
+            # (Measured and NOT taken: the 64-channel 3x3 layers of res2 are 0.18 ms faster each in the one-launch fp32 Winograd
+            # kernel -- 986 vs 971 frames/s -- but with that mix one of the 800 scores of the end-to-end test at threshold 0.0 moved
+            # to 1.007e-4 from the oracle's, past the stated 1e-4: the arithmetic stays uniform.)
             precision = 2 if tune == 0 and ((x3_ok and not wino_ok) or (wino_ok and (Cin + Cin2) % 32 == 0)) else 0
         else:
             precision = 0
