@@ -919,16 +919,20 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
-        // 128 tiles x 128 channels with DMA-staged weights (one 512-thread workgroup per CU) where the second 64 channels are not
-        // padding and the 128-tile blocks fill the chip for >= 3 rounds; measured per shape (tools/x3w_check.py): p2 256->256 layer
-        // 4.27 -> 3.80 ms, 14x14 ROI-head layers 1.30 -> 1.07 ms, 60x80 level equal, 30x40 and below slower (tail) -> 64-wide form.
-        // tune 8: the 64-wide form everywhere; A3D_X3W_WM=2|4 forces a wide form (A/B runs and the bit-equality test).
+        // 128 tiles x 128 channels with DMA-staged weights (one 512-thread workgroup per CU) or 64 x 64 (three 256-thread workgroups
+        // per CU)?  Both are bit-identical, so the choice is free; it goes by the rounds the busiest CU runs.  A CU works through
+        // ceil(blocks / 256) blocks, the narrow form three at a time; three narrow blocks are 0.75 of a wide block's work at ~0.87 of
+        // its rate, i.e. one narrow round costs ~0.86 of a wide one.  Measured (tools/x3w_check.py, ms wide | narrow): p2 256->256
+        // 3.50 | 4.15, 60x80x256 0.97 | 1.08, 276 ROIs of 14x14 0.18 | 0.28 (one partial round instead of two), 1600 ROIs 1.07 | 1.30,
+        // 30x40x256 0.34 | 0.34, 15x20x512 0.33 | 0.34.
+        // tune 8: the narrow form everywhere; A3D_X3W_WM=2|4 forces a wide form (A/B runs and the bit-equality test).
         static int wm_force = -1;
         if (wm_force < 0) wm_force = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
         const int ntw = (d->Cout + X3W_BN - 1) / X3W_BN;
-        const long blocks128 = (long)((T + 127) / 128) * ntw;
+        const long blocks_w = (long)((T + 127) / 128) * ntw, blocks_n = (long)mtiles * ((d->Cout + 63) / 64);
+        const long rounds_w = (blocks_w + 255) / 256, rounds_n = ((blocks_n + 255) / 256 + 2) / 3;
         const bool wide = d->tune != 8 && ((d->Cout + 63) / 64) % 2 == 0 && (size_t)16 * d->Cout * a.C * 6 < ((size_t)1 << 32) &&
-                          (wm_force || blocks128 >= 3 * 256);
+                          (wm_force || 100 * rounds_w <= 86 * rounds_n);
         if (wide) {
             const int nt = ntw;
             const int wmx = wm_force ? wm_force : 4;
