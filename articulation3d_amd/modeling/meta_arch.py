@@ -13,6 +13,7 @@ Two entry points share the same kernels:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -211,7 +212,7 @@ class PlaneRCNN(nn.Module):
             self.load_state_dict(self._trainer.export_state_dict(), strict=False)
         return super().train(mode)
 
-    small_batch_overlap = 16  # batches up to this size run the depth decoder on a second HIP stream (0 disables)
+    small_batch_overlap = int(os.environ.get("A3D_DEPTH_OVERLAP", "16"))  # batches up to this size run the depth decoder on a second HIP stream (0 disables)
     fast_reference_path = True  # route uniform batches of the reference-signature call through inference_batched
 
     def _fast_path_ok(self, batched_inputs, do_postprocess) -> bool:
