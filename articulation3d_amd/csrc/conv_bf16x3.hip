@@ -38,7 +38,10 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16
     l = __builtin_convertvector(r2, bf16x4);
 }
 
-template <int TN>
+// STEM: the 7x7 s2 p3 stem on the NHWC4 input (a3d_conv_desc.stem; w packed [Cout][7][8][4], Kpad = 224): a 16-deep chunk is 4
+// consecutive filter columns x 4 channels of one filter row, i.e. loader lane j = tid % 4 fetches pixel (ih0 + kh, iw0 + 4 (c & 1) + j)
+// whole -- the float4 it would fetch anyway -- with kh = c >> 1; validity is a row bit and a column-half bit instead of a tap bit.
+template <int TN, bool STEM = false>
 __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
     constexpr int TM = 2, BKT = 16;
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // (32-bank rule, 16 contiguous lanes = 4 rows) are both conflict-free with it; a padded 48-byte pitch made the
     // writes 2-way conflicted (SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles).
     const int lcs = (lc & 7) | ((((lc >> 3) ^ (lr >> 3)) & 1) << 3);
-    const int cs4 = d.Cin * 4;
+    const int cs4 = STEM ? 16 : d.Cin * 4;
     const int CinT = d.Cin + d.Cin2;  // (a second source has the same channel count: checked by the launcher)
     const __amdgpu_buffer_rsrc_t rx = x3_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rx2 = x3_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
@@ -85,10 +88,18 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             iw0 = ow - 1 + ((d.phase - 1) & 1);
         }
         unsigned mask = 0;
-        for (int kh = 0; kh < d.KH; ++kh)
-            for (int kw = 0; kw < d.KW; ++kw)
-                mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
-        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        if (STEM) {
+            const int j = tid & 3;
+            for (int kh = 0; kh < 7; ++kh) mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H) ? (1u << kh) : 0u;
+            mask |= ((unsigned)(iw0 + j) < (unsigned)d.W) ? (1u << 8) : 0u;               // filter columns 0..3
+            mask |= (j < 3 && (unsigned)(iw0 + 4 + j) < (unsigned)d.W) ? (1u << 9) : 0u;  // filter columns 4..6 (7 is padding)
+            rowoff[i] = ((b * d.H + ih0) * d.W + iw0 + j) * 16;
+        } else {
+            for (int kh = 0; kh < d.KH; ++kh)
+                for (int kw = 0; kw < d.KW; ++kw)
+                    mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
+            rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        }
         vmask[i] = mask;
     }
     int woff[WR];
@@ -102,6 +113,19 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // multiplied at iteration c, so a buffer load has two full iterations (2 x 6*TN*2 MFMAs per wave) to land.
     f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
     auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
+        if (STEM) {
+            const unsigned livebit = (kc < nk) ? 1u : 0u;
+            const int skh = kc >> 1, half = kc & 1;
+            const int tapoff = (skh * d.W + half * 4) * 16;
+#pragma unroll
+            for (int i = 0; i < XR; ++i)
+                xs[i] = x3_load4(rx, ((vmask[i] >> skh) & (vmask[i] >> (8 + half)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+            const int soff = kc * (BKT * 4);
+#pragma unroll
+            for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+            ++kc;
+            return;
+        }
         const int tap = kh * d.KW + kw;
         const unsigned livebit = (kc < nk) ? 1u : 0u;
         const bool second = c0 >= d.Cin;  // channel concat: the second source supplies channels Cin .. Cin+Cin2-1 of every tap
@@ -248,27 +272,38 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     }
 }
 
-template <int TN>
+template <int TN, bool STEM = false>
 void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = 128, BN = 64 * TN;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
-    a3d_note_variant("conv_x3_kernel<%d>", TN);
-    hipLaunchKernelGGL((conv_x3_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    a3d_note_variant(STEM ? "conv_x3_kernel<%d> stem" : "conv_x3_kernel<%d>", TN);
+    hipLaunchKernelGGL((conv_x3_kernel<TN, STEM>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
 }
 }  // namespace
 
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
     const int rw = a3d_conv_launch_bf16x3_wide(d, s);  // wide and large layers with pre-split weights (bit-identical results)
     if (rw != A3D_ERR_UNSUPPORTED) return rw;
-    if (d->stem || d->ups || d->pixshuf || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->stem) {  // the 7x7 stem (x is [B,H,W,4]): its own loader, 128 x 64 tiles
+        if (d->KH != 7 || d->KW != 7 || d->stride != 2 || d->pad != 3 || d->Kpad != 224 || d->x2 || d->res || d->ups || d->pixshuf || d->phase ||
+            d->splitk != 1 || d->m_dev || (size_t)d->B * d->H * d->W * 16 >= ((size_t)1 << 32))
+            return A3D_ERR_UNSUPPORTED;
+        if (d->Cout <= 64) launch_x3<1, true>(d, s);
+        else launch_x3<2, true>(d, s);
+        return a3d_check_launch();
+    }
+    if (d->ups || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->pixshuf && (d->res || d->phase || d->gate)) return A3D_ERR_UNSUPPORTED;  // (ConvTranspose2d k2 s2: scatter in store_out only)
     if (d->phase && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->res)) return A3D_ERR_UNSUPPORTED;
     if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_UNSUPPORTED;
     if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * (d->Cin + d->Cin2) || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
     const int M = d->B * d->Ho * d->Wo;
     const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
-    if (d->Cout <= 64 || n128 <= 500) launch_x3<1>(d, s);
+    if (d->tune == 10) launch_x3<1>(d, s);  // (tune 10 / 11: explicit tile width, A/B runs)
+    else if (d->tune == 11) launch_x3<2>(d, s);
+    else if (d->Cout <= 64 || n128 <= 500) launch_x3<1>(d, s);
     else launch_x3<2>(d, s);
     return a3d_check_launch();
 }

@@ -74,7 +74,12 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     const int logical = a3d_xcd_remap(blockIdx.x, nblk);
     const int mt = logical / ntiles, nt = logical - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = d.Kpad / BKT;
+    const int nk_all = d.Kpad / BKT;
+    // split-K (a3d_conv_desc.splitk > 1, the 50176-deep head FCs): blockIdx.y = z multiplies chunks [z * kps, (z + 1) * kps) and
+    // stores its raw partial sums to workspace[z]; conv_splitk_reduce_v2_kernel adds the slices in z order and applies the epilogue
+    const int kps = (nk_all + d.splitk - 1) / d.splitk;
+    const int kbeg = blockIdx.y * kps;
+    const int nk = min(nk_all, kbeg + kps);  // first chunk index past this slice
     const int lr = tid / TPR, lc = (tid % TPR) * 4;
     // LDS image (both operands): [plane][row][16 k] bf16, 32-byte rows; the 16-byte half holding k = 8h..8h+7 of row r sits at slot
     // h ^ ((r >> 3) & 1) -- conv_bf16x3.hip's image (conflict-free ds_read_b128 and ds_write_b64)
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     const __amdgpu_buffer_rsrc_t rx = wx_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rx2 = wx_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const unsigned w3chunk = (unsigned)d.Cout * 96u;  // bytes of one chunk of w_x3: 3 planes x Cout rows x 32 B
-    const __amdgpu_buffer_rsrc_t rw = wx_rsrc(d.w_x3, (unsigned)((size_t)nk * w3chunk));
+    const __amdgpu_buffer_rsrc_t rw = wx_rsrc(d.w_x3, (unsigned)((size_t)nk_all * w3chunk));
 
     int rowoff[XR];
     unsigned vmask[XR];
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
         vmask[i] = mask;
     }
-    int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next activation chunk to load inside the filter
+    // position of the next activation chunk to load inside the filter (k = (kh, kw, c): chunk kbeg starts at tap kbeg*16 / CinT)
+    int kc = kbeg, c0 = (kbeg * BKT) % CinT, kh = ((kbeg * BKT) / CinT) / d.KW, kw = ((kbeg * BKT) / CinT) % d.KW;
     f32x4 xsA[XR], xsB[XR];
     auto load_chunk = [&](f32x4 (&xs)[XR]) {
         const int tap = kh * d.KW + kw;
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     // the k half that the image keeps there: half ^ ((row >> 3) & 1)  (row base is a multiple of 32).  Rows past Cout read the
     // next plane's rows or, past the end of w_x3, zeros: their accumulators are never stored.
     const int wvoff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-    int dma_c = 0, dma_st = 0;  // chunk and W stage of the next weight DMA (chunks past nk lie past the end of w_x3: zeros)
+    // chunk and W stage of the next weight DMA (past the slice the activations are zero; past the end of w_x3 the DMA reads zeros)
+    int dma_c = kbeg, dma_st = 0;
     auto dma_w = [&]() {
         __bf16 *Wt = Ws + dma_st * XW_WST;
         const int base = __builtin_amdgcn_readfirstlane(dma_c * (int)w3chunk + n0 * 32);
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     rdA(A0, 0, 0);
     XW_FENCE
 
-    for (int it = 0; it < nk; it += 2) {  // (Kpad % 32 == 0 on every packed layer; an odd chunk count would multiply one all-zero chunk: loads / DMA past nk read 0)
+    for (int it = kbeg; it < nk; it += 2) {  // (Kpad % 32 == 0 on every packed layer; an odd chunk count would multiply one all-zero chunk: loads / DMA past nk read 0)
         iteration(0, A0, A1, B0, B1, xsB);
         iteration(1, A0, A1, B1, B0, xsA);
     }
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 #undef XW_TERM
 #undef XW_FENCE
 
-    const bool has_res = d.res != nullptr;
+    const bool has_res = d.res != nullptr && d.splitk == 1;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
@@ -326,6 +333,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                if (d.splitk > 1) {
+                    *reinterpret_cast<f32x4 *>(d.workspace + ((size_t)blockIdx.y * M + m) * d.Cout + n) = v;
+                    continue;
+                }
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
                 store_out(d, v, m, n, b, oh, ow);
             }
@@ -339,7 +350,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 // offset limits.
 int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
     if (!d->w_x3 || d->tune == 8) return A3D_ERR_UNSUPPORTED;
-    if (d->stem || d->ups || d->pixshuf || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->stem || d->ups || d->m_dev || d->splitk < 1) return A3D_ERR_UNSUPPORTED;
+    if (d->splitk > 1 && (!d->workspace || d->phase || d->gate)) return A3D_ERR_UNSUPPORTED;
+    if (d->pixshuf && (d->res || d->phase || d->gate)) return A3D_ERR_UNSUPPORTED;
     if (d->phase && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->res)) return A3D_ERR_UNSUPPORTED;
     if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_UNSUPPORTED;
     if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * (d->Cin + d->Cin2) || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
@@ -353,14 +366,15 @@ int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
         // the narrow kernel's three workgroups per CU cover each other's.  Hence deep reductions only.
         if (d->Kpad < 4096) return A3D_ERR_UNSUPPORTED;
         if (d->Cout < 192 || ntiles * XW_BN > d->Cout + d->Cout / 4) return A3D_ERR_UNSUPPORTED;
-        if ((long)mtiles * ntiles < 2 * 256) return A3D_ERR_UNSUPPORTED;
+        if (d->splitk == 1 && (long)mtiles * ntiles < 2 * 256) return A3D_ERR_UNSUPPORTED;  // (split-K launches stream the weights: any M)
     }
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
         if (hipFuncSetAttribute((const void *)conv_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XW_LDS_BYTES) != hipSuccess) return A3D_ERR_LAUNCH;
         attr_set = true;
     }
-    a3d_note_variant("conv_x3w_kernel");
-    hipLaunchKernelGGL(conv_x3w_kernel, dim3(mtiles * ntiles), dim3(512), XW_LDS_BYTES, s, *d, M, ntiles, mtiles * ntiles);
+    a3d_note_variant(d->splitk > 1 ? "conv_x3w_kernel sk%d" : "conv_x3w_kernel", d->splitk);
+    hipLaunchKernelGGL(conv_x3w_kernel, dim3(mtiles * ntiles, d->splitk), dim3(512), XW_LDS_BYTES, s, *d, M, ntiles, mtiles * ntiles);
+    if (d->splitk > 1) a3d_launch_splitk_reduce(d, M, s);
     return a3d_check_launch();
 }

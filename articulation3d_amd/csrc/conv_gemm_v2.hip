@@ -310,6 +310,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v2_kernel(const a3d_co
     }
 }
 
+// workspace [splitk][M][Cout] partial sums -> y: slices added in z order, then the fused epilogue (shared with conv_bf16x3_wide.hip)
+void a3d_launch_splitk_reduce(const a3d_conv_desc *d, int M, hipStream_t s) {
+    const size_t total = (size_t)M * (d->Cout >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_splitk_reduce_v2_kernel, dim3(blocks), dim3(256), 0, s, *d, M);
+}
+
 int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
     const size_t lim = (size_t)1 << 32;
     const size_t cs = d->stem ? 4 : (size_t)d->Cin;
@@ -358,11 +366,6 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s) {
             default: launch_v2<4, 1, 1, 1, MODE_GENERIC, 0, 32>(d, s); break;  // 128x32 tile: BK=32 only
         }
     }
-    if (d->splitk > 1) {
-        const size_t total = (size_t)M * (d->Cout >> 2);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(conv_splitk_reduce_v2_kernel, dim3(blocks), dim3(256), 0, s, *d, M);
-    }
+    if (d->splitk > 1) a3d_launch_splitk_reduce(d, M, s);
     return a3d_check_launch();
 }

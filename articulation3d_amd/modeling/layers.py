@@ -8,6 +8,7 @@ fp32 NHWC device tensors and only launches kernels through `ops`.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -55,6 +56,13 @@ def _calibrate_norm(norm, y_raw: torch.Tensor, eps_floor: float = 1e-6):
     norm.running_var.copy_(flat.var(0, unbiased=False).clamp_min(eps_floor))
 
 
+def _publish():
+    """A freshly packed weight set is computed on the CURRENT stream but read afterwards by launches on any stream (1-2 frame batches
+    run one RPN head layer on three streams, the three ROI heads side by side): drain the stream once before the cache is used."""
+    if torch.cuda.is_available() and not os.environ.get("A3D_NO_PUBLISH"):
+        torch.cuda.current_stream().synchronize()
+
+
 class _Packable(nn.Module):
     """Caches the packed weights; re-packs when a parameter/buffer was modified or moved."""
 
@@ -72,6 +80,7 @@ class _Packable(nn.Module):
         if self._pack_cache is None or key != self._pack_key:
             self._pack_cache = self._pack()
             self._pack_key = key
+            _publish()
         return self._pack_cache
 
     def _pack(self):
@@ -153,6 +162,7 @@ class BNConv2d(_Packable):
             bn = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var, self.bn.eps)
             self._phase_cache = ops.pack_conv_ups_phases(self.conv.weight, self.conv.bias, bn, self.act, device=self.conv.weight.device)
             self._phase_key = key
+            _publish()
         return self._phase_cache
 
 

@@ -312,7 +312,12 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             precision = 1 if plain and p.Cin % 32 == 0 else 0
         elif mode == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
             # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
-            x3_ok = (not (p.stem or ups or p.pixshuf or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
+            # (split-K -- the 50176-deep head FCs -- only through the wide kernel, whose conditions the last line repeats)
+            x3_ok = p.stem and not ups and splitk == 1 and m_dev is None and x2 is None and res is None
+            x3_ok = x3_ok or (not (p.stem or ups or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
+                     and not (p.pixshuf and (res is not None or gate is not None))
+                     and (splitk == 1 or (p.presplit and p.Kpad >= 4096 and p.cols >= 192 and -(-p.cols // 256) * 256 <= p.cols + p.cols // 4
+                                          and not p.phase and gate is None and not p.pixshuf))
                      and (x2 is None or Cin2 == Cin) and Cin % 16 == 0 and not (p.phase and res is not None))
             # Winograd layers keep the Winograd form with the split-operand GEMM (conv_wino.hip 2x, 32-deep chunks).
             # (Measured and NOT taken: the 64-channel 3x3 layers of res2 are 0.18 ms faster each in the one-launch fp32 Winograd
@@ -338,6 +343,10 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                 rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
                 p.w_wino_x3 = torch.empty((16, cols // 32, 3, rows, 32), device=p.w_wino.device, dtype=torch.bfloat16)
                 _lib.check(_lib.lib().a3d_split_bf16x3(p.w_wino.data_ptr(), p.w_wino_x3.data_ptr(), 16, rows, cols, _stream()), "a3d_split_bf16x3")
+                # the cache is read by later launches on ANY stream (the RPN head runs one packed layer on three streams for 1-2
+                # frame batches): it must be complete before it is published.  Once per packed layer.
+                if not os.environ.get("A3D_NO_PUBLISH"):
+                    torch.cuda.current_stream().synchronize()
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
     if (d.precision == 2 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
             and not (p.stem or p.pixshuf)):
@@ -345,6 +354,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         if p.w_x3 is None or p.w_x3.device != p.w.device:
             p.w_x3 = torch.empty((p.Kpad // 16, 3, p.w.shape[0], 16), device=p.w.device, dtype=torch.bfloat16)
             _lib.check(_lib.lib().a3d_split_bf16x3_chunk(p.w.data_ptr(), p.w_x3.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, _stream()), "a3d_split_bf16x3_chunk")
+            if not os.environ.get("A3D_NO_PUBLISH"):
+                torch.cuda.current_stream().synchronize()  # published to every stream, see w_wino_x3 above
         d.w_x3 = p.w_x3.data_ptr()
     fused_wino = False
     shared = None  # [input tensor, its transformed tiles V or None]: see share_wino_input
@@ -418,10 +429,10 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
 
 
 def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk: int = 1,
-           m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+           m_dev: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
     """x [M, K] -> [M, cols]."""
     M, K = x.shape
-    y = conv2d(x.view(M, 1, 1, K), p, act=act, splitk=splitk, m_dev=m_dev)
+    y = conv2d(x.view(M, 1, 1, K), p, act=act, splitk=splitk, m_dev=m_dev, precision=precision)
     return y.view(M, p.cols)
 
 

@@ -165,6 +165,28 @@ def test_wide_split_operand_direct_kernel_is_bit_identical_to_the_narrow_one(ops
     assert rel(wide[:nb, :, :, :c["Cout"]].permute(0, 3, 1, 2).double(), F.relu(ref)) < 5e-6
 
 
+def test_split_k_head_fc_in_the_split_operand_arithmetic(ops):
+    """The 50176-deep head FCs (plane_head.py:76, axis_head.py, split-K 32 by K alone) run the wide bf16x3 kernel with blockIdx.y =
+    K slice and the shared reduce launch: fp32-grade against float64, and -- the order of the slices being fixed -- a row's result
+    does not depend on how many rows are in the batch."""
+    torch.manual_seed(21)
+    K, N = 16384, 1024
+    x = torch.randn(300, K, device="cuda")
+    w = torch.randn(N, K) / K ** 0.5
+    b = torch.randn(N) * 0.1
+    pk = ops.pack_linear(w, b, None, ops.ACT_RELU)
+    sk = ops.choose_splitk(300, pk.cols, K)
+    assert sk == 32
+    y = ops.linear(x, pk, splitk=sk)
+    assert ops.last_conv_variant() == "conv_x3w_kernel sk32", ops.last_conv_variant()
+    ref = F.relu(x.double().cpu() @ w.double().t() + b.double())
+    assert rel(y[:, :N].double(), ref) < 5e-6
+    y0 = ops.linear(x, pk, splitk=sk, precision=0)  # the fp32-input MFMA split-K kernel: same slices, same order
+    assert rel(y0[:, :N].double(), ref) < 5e-6
+    few = ops.linear(x[:7].contiguous(), pk, splitk=sk)
+    assert torch.equal(few, y[:7])
+
+
 def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.3
@@ -348,6 +370,15 @@ def test_stem_pool_resize_small_ops(ops):
     ref = F.relu(F.batch_norm(F.conv2d(x, w, None, 2, 3), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
     y = ops.conv2d(ops.preprocess_f32chw(x.cuda(), (0, 0, 0), (1, 1, 1)), ops.pack_stem(w, bn))
     assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
+    # the stem in each arithmetic (its own loader in both GEMM kernels), odd image sizes included: against float64
+    for hw in ((96, 128), (61, 75)):
+        xs = torch.rand(2, 3, *hw) * 255 - 110
+        ref64 = F.relu(F.batch_norm(F.conv2d(xs.double(), w.double(), None, 2, 3), bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, 1e-5))
+        x4 = ops.preprocess_f32chw(xs.cuda(), (0, 0, 0), (1, 1, 1))
+        for prec, name in ((0, "conv_gemm_v2_kernel"), (2, "conv_x3_kernel<1> stem")):
+            ys = ops.conv2d(x4, ops.pack_stem(w, bn), precision=prec)
+            assert ops.last_conv_variant().startswith(name), ops.last_conv_variant()
+            assert rel(ys.permute(0, 3, 1, 2).double(), ref64) < 2e-6, (hw, prec)
     assert rel(ops.maxpool3x3s2(y).permute(0, 3, 1, 2), F.max_pool2d(ref, 3, 2, 1)) < 5e-6
     assert torch.equal(ops.subsample2(y).cpu(), y.cpu()[:, ::2, ::2])
     u8 = torch.randint(0, 256, (2, 32, 64, 3), dtype=torch.uint8)

@@ -1,0 +1,33 @@
+"""conv_x3_kernel<1> (128 x 64 tiles) vs <2> (128 x 128) per layer shape (tune 10 / 11).  shape = B x H x W x Cin x Cout x k x stride x res"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from articulation3d_amd import ops  # noqa: E402
+
+SHAPES = [(64, 120, 160, 64, 256, 1, 1, 1), (64, 120, 160, 64, 256, 1, 1, 0), (64, 60, 80, 128, 512, 1, 1, 1), (64, 120, 160, 256, 256, 1, 1, 0),
+          (64, 30, 40, 256, 1024, 1, 1, 1), (64, 60, 80, 512, 128, 1, 1, 0), (64, 30, 40, 1024, 256, 1, 1, 0)]
+if len(sys.argv) > 1:
+    SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for B, H, W, Cin, Cout, k, st, has_res in SHAPES:
+    torch.manual_seed(1)
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    pk = ops.pack_conv(torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5), torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+    Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+    res = torch.randn(B, Ho, Wo, pk.cols, device="cuda") if has_res else None
+    out = []
+    for tune in (10, 11):
+        y = ops.conv2d(x, pk, precision=2, tune=tune, res=res)
+        v = ops.last_conv_variant()
+        ops.CONV_TIMING = []
+        for _ in range(7):
+            ops.conv2d(x, pk, precision=2, tune=tune, res=res)
+        torch.cuda.synchronize()
+        t, ops.CONV_TIMING = ops.CONV_TIMING, None
+        g = sorted(a.elapsed_time(b) for (_n, _f, a, b, *_r) in t)
+        out.append((v, g[len(g) // 2], y))
+    gb = (x.numel() + (res.numel() if res is not None else 0) + out[0][2].numel()) * 4 / 1e9
+    print(f"{B}x{H}x{W}x{Cin}->{Cout}{' +res' if has_res else ''}: " + " | ".join(f"{v} {m:.3f} ms ({gb / m:.2f} TB/s alg.)" for v, m, _ in out)
+          + f" | equal {torch.equal(out[0][2], out[1][2])}", flush=True)
