@@ -35,6 +35,10 @@ class ConvDesc(C.Structure):
         ("w_wino_x3", fptr),
         ("w_wino_cm", fptr),
         ("w_x3", fptr),
+        ("in_amax", fptr),
+        ("in_amax2", fptr),
+        ("y_amax", fptr),
+        ("w_scale", C.c_float),
     ]
 
 
@@ -185,6 +189,9 @@ SIGNATURES = {
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),
+    "a3d_absmax_rows": (C.c_int, [fptr, fptr, C.c_int, C.c_size_t, fptr]),
+    "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),

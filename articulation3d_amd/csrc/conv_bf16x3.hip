@@ -29,6 +29,17 @@ __device__ __forceinline__ f32x4 x3_load4(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// fp16x2 mode (a3d_conv_desc.precision == 3): x * s = h + l with h, l fp16 and s a power of two that puts the tensor's largest
+// magnitude in [2^14, 2^15): h carries 11 significant bits, l the next 11 (2^-22 relative wherever |x| >= max / 2^18, 2^-40 of the
+// maximum below); h.h + h.l + l.h with fp32 accumulation drops only l.l (<= 2^-22 relative).  THREE MFMAs per k step.
+__device__ __forceinline__ void split2h(const f32x4 v, const float s, h16x4 &h, h16x4 &l) {
+    const f32x4 xs = v * s;
+    h = __builtin_convertvector(xs, h16x4);
+    const f32x4 r = xs - __builtin_convertvector(h, f32x4);
+    l = __builtin_convertvector(r, h16x4);
+}
 // x = h + m + l exactly (round-to-nearest-even at each level)
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
     h = __builtin_convertvector(v, bf16x4);
@@ -41,16 +52,17 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16
 // STEM: the 7x7 s2 p3 stem on the NHWC4 input (a3d_conv_desc.stem; w packed [Cout][7][8][4], Kpad = 224): a 16-deep chunk is 4
 // consecutive filter columns x 4 channels of one filter row, i.e. loader lane j = tid % 4 fetches pixel (ih0 + kh, iw0 + 4 (c & 1) + j)
 // whole -- the float4 it would fetch anyway -- with kh = c >> 1; validity is a row bit and a column-half bit instead of a tap bit.
-template <int TN, bool STEM = false>
+template <int TN, bool STEM = false, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
     constexpr int TM = 2, BKT = 16;
+    constexpr int NP = F16 ? 2 : 3;  // operand planes
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int LKB = BKT;                       // bf16 elements per LDS row (32 bytes, no padding: the two 16-B halves of
                                                    // a row are XOR-swizzled with bit 3 of the row index instead)
     constexpr int TPR = BKT / 4, RPP = 256 / TPR;  // 4 lanes x float4 per row, 64 rows per loader pass
     constexpr int XR = BM / RPP, WR = BN / RPP;
     constexpr int PX = BM * LKB, PW = BN * LKB;    // one operand plane
-    constexpr int BUF = 3 * (PX + PW);
+    constexpr int BUF = NP * (PX + PW);
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
     __shared__ __attribute__((aligned(16))) float ss[2 * BN];
 
@@ -72,6 +84,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     const __amdgpu_buffer_rsrc_t rx2 = x3_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rw = x3_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
 
+    const float sw = F16 ? d.w_scale : 1.f;  // weight scale of the fp16x2 split; the activation rows carry their image's scale:
+    float sxr[XR];
     int rowoff[XR];
     unsigned vmask[XR];
 #pragma unroll
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             ih0 = oh - 1 + ((d.phase - 1) >> 1);
             iw0 = ow - 1 + ((d.phase - 1) & 1);
         }
+        sxr[i] = (F16 && rok) ? a3d_in_scale(d, b) : 1.f;
         unsigned mask = 0;
         if (STEM) {
             const int j = tid & 3;
@@ -148,7 +163,26 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     };
     auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[WR]) {  // fp32 -> hi | mid | lo planes on the way into LDS
         __bf16 *X = lds + buf * BUF;
-        __bf16 *Wt = X + 3 * PX;
+        __bf16 *Wt = X + NP * PX;
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                h16x4 h, l;
+                split2h(xs[i], sxr[i], h, l);
+                _Float16 *p = reinterpret_cast<_Float16 *>(X) + (lr + RPP * i) * LKB + lcs;
+                *reinterpret_cast<h16x4 *>(p) = h;
+                *reinterpret_cast<h16x4 *>(p + PX) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                h16x4 h, l;
+                split2h(ws[i], sw, h, l);
+                _Float16 *p = reinterpret_cast<_Float16 *>(Wt) + (lr + RPP * i) * LKB + lcs;
+                *reinterpret_cast<h16x4 *>(p) = h;
+                *reinterpret_cast<h16x4 *>(p + PW) = l;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             bf16x4 h, m, l;
@@ -188,12 +222,12 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     const int frag_off = frow * LKB + ((((lane >> 5) ^ (frow >> 3)) & 1) << 3);  // row = lane % 32, k = 8 * (lane / 32) .. + 7
     // [hi | mid | lo] fragments: set 0 holds the chunk being multiplied in even iterations, set 1 in odd ones; the other
     // set is filled (behind the second half of the MFMAs) with the next chunk.
-    bf16x8 fa0[3][TN], fb0[3][TM], fa1[3][TN], fb1[3][TM];
-    auto read_frags = [&](int buf, bf16x8 (&fa)[3][TN], bf16x8 (&fb)[3][TM]) {
+    bf16x8 fa0[NP][TN], fb0[NP][TM], fa1[NP][TN], fb1[NP][TM];
+    auto read_frags = [&](int buf, bf16x8 (&fa)[NP][TN], bf16x8 (&fb)[NP][TM]) {
         const __bf16 *X = lds + buf * BUF + (wm * TM * 32) * LKB + frag_off;
-        const __bf16 *Wt = lds + buf * BUF + 3 * PX + (wn * TN * 32) * LKB + frag_off;
+        const __bf16 *Wt = lds + buf * BUF + NP * PX + (wn * TN * 32) * LKB + frag_off;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) fa[p][ni] = *reinterpret_cast<const bf16x8 *>(Wt + p * PW + ni * 32 * LKB);
 #pragma unroll
@@ -201,16 +235,44 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
         }
     };
     read_frags(0, fa0, fb0);
-#define X3_TERM(PA, PB)                                                                                                  \
-    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) acc[ni][mi] =  \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][ni], fb[PB][mi], acc[ni][mi], 0, 0, 0);
+#define X3_TERM(PA, PB)                                                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) {                    \
+        if constexpr (F16)                                                                                                    \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[PA][ni]),                      \
+                                                                 __builtin_bit_cast(h16x8, fb[PB][mi]), acc[ni][mi], 0, 0, 0); \
+        else                                                                                                                  \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][ni], fb[PB][mi], acc[ni][mi], 0, 0, 0);              \
+    }
     // One chunk.  A wave issues in order and an MFMA holds the matrix pipe for 8 passes, so everything else is placed in
     // the MFMAs' shadows: first half = 3 product terms + the split of the staged chunk it+1 into LDS[cur^1]; ONE barrier;
     // second half = 3 terms + the fragment reads of chunk it+1 + the buffer loads of chunk it+3.  (With the reads behind
     // the barrier and outside the MFMA stream, the two co-resident workgroups fall into lockstep and the pipe idles
     // during both their read phases: 58 % MFMA-busy measured.)
-    auto step = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR], bf16x8 (&fa)[3][TN], bf16x8 (&fb)[3][TM],
-                    bf16x8 (&fan)[3][TN], bf16x8 (&fbn)[3][TM]) {
+    auto step = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR], bf16x8 (&fa)[NP][TN], bf16x8 (&fb)[NP][TM],
+                    bf16x8 (&fan)[NP][TN], bf16x8 (&fbn)[NP][TM]) {
+        if constexpr (F16) {  // three terms: l.h and h.l (the small ones) with the split of the staged chunk, then h.h with the reads / loads
+            X3_TERM(1, 0)
+            X3_TERM(0, 1)
+            store_chunk(cur ^ 1, xs, ws);
+#pragma unroll
+            for (int g = 0; g < 2 * TN * TM; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // <= 8 VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // <= 1 LDS write
+            }
+            __syncthreads();
+            X3_TERM(0, 0)
+            read_frags(cur ^ 1, fan, fbn);
+            load_chunk(xs, ws);
+#pragma unroll
+            for (int g = 0; g < TN * TM; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);  // <= 2 LDS reads
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // <= 1 buffer load
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);  // <= 4 VALU (addresses)
+            }
+            return;
+        }
         X3_TERM(0, 0)
         X3_TERM(0, 1)
         X3_TERM(1, 0)
@@ -242,10 +304,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
 #undef X3_TERM
 
     const bool has_res = d.res != nullptr;
+    const int hwo = d.Ho * d.Wo;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
-        if (m >= M) continue;
+        const bool mok = m < M;
+        const int bimg = mok ? m / hwo : 0;  // image / ROI of this lane's output pixel
+        float vmax = 0.f;
+        if (mok) {
+        const float unscale = F16 ? 1.f / (a3d_in_scale(d, bimg) * sw) : 1.f;
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
@@ -265,10 +332,14 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                if constexpr (F16) v = v * unscale;  // exact: a power of two
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                vmax = fmaxf(vmax, a3d_absmax4(v));
                 store_out(d, v, m, n, b, oh, ow);
             }
         }
+        }
+        if (d.y_amax) a3d_note_amax(d.y_amax, bimg, vmax, mok);  // (every lane of the wave gets here)
     }
 }
 
@@ -277,12 +348,18 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = 128, BN = 64 * TN;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
+    if (d->precision == 3) {
+        a3d_note_variant(STEM ? "conv_h2_kernel<%d> stem" : "conv_h2_kernel<%d>", TN);
+        hipLaunchKernelGGL((conv_x3_kernel<TN, STEM, true>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+        return;
+    }
     a3d_note_variant(STEM ? "conv_x3_kernel<%d> stem" : "conv_x3_kernel<%d>", TN);
     hipLaunchKernelGGL((conv_x3_kernel<TN, STEM>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
 }
 }  // namespace
 
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->precision == 3 && (!d->in_amax || !(d->w_scale > 0.f))) return A3D_ERR_ARG;
     const int rw = a3d_conv_launch_bf16x3_wide(d, s);  // wide and large layers with pre-split weights (bit-identical results)
     if (rw != A3D_ERR_UNSUPPORTED) return rw;
     if (d->stem) {  // the 7x7 stem (x is [B,H,W,4]): its own loader, 128 x 64 tiles

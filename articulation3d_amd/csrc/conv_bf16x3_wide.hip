@@ -53,12 +53,25 @@ __device__ __forceinline__ void wx_split3(const f32x4 v, wx_bf16x4 &h, wx_bf16x4
     l = __builtin_convertvector(r2, wx_bf16x4);
 }
 
+typedef _Float16 wx_h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 wx_h16x8 __attribute__((ext_vector_type(8)));
+// fp16x2 (precision 3): x * s = h + l, conv_bf16x3.hip's split2h
+__device__ __forceinline__ void wx_split2h(const f32x4 v, const float s, wx_h16x4 &h, wx_h16x4 &l) {
+    const f32x4 xs = v * s;
+    h = __builtin_convertvector(xs, wx_h16x4);
+    l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wx_h16x4);
+}
+
 constexpr int XW_BM = 256, XW_BN = 256, XW_BK = 16;
 constexpr int XW_PX = XW_BM * XW_BK, XW_PW = XW_BN * XW_BK;  // one operand plane of one stage (bf16 elements; 32-byte rows)
-constexpr int XW_XST = 3 * XW_PX, XW_WST = 3 * XW_PW;        // one stage
-constexpr int XW_LDS_BYTES = (2 * XW_XST + 3 * XW_WST) * 2 + 2 * XW_BN * 4;
+constexpr int xw_lds_bytes(int NP) { return (2 * NP * XW_PX + 3 * NP * XW_PW) * 2 + 2 * XW_BN * 4; }
 
+// F16: the fp16x2 arithmetic (a3d_conv_desc.precision == 3) -- two operand planes, three product terms (h.h, h.l, l.h), activation rows
+// scaled per image from d.in_amax, w_x3 = the filter pre-split by a3d_split_f16x2_chunk with d.w_scale.
+template <bool F16>
 __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    constexpr int NP = F16 ? 2 : 3;
+    constexpr int XW_XST = NP * XW_PX, XW_WST = NP * XW_PW;  // one stage
     constexpr int TM = 2, TN = 4, BM = XW_BM, BN = XW_BN, BKT = XW_BK, LKB = XW_BK;
     constexpr int TPR = BKT / 4, RPP = 512 / TPR, XR = BM / RPP;  // 4 lanes x float4 per row, 128 rows per pass, 2 passes
     constexpr int PX = XW_PX, PW = XW_PW;
@@ -88,9 +101,11 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     const int CinT = d.Cin + d.Cin2;
     const __amdgpu_buffer_rsrc_t rx = wx_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rx2 = wx_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
-    const unsigned w3chunk = (unsigned)d.Cout * 96u;  // bytes of one chunk of w_x3: 3 planes x Cout rows x 32 B
+    const unsigned w3chunk = (unsigned)d.Cout * 32u * NP;  // bytes of one chunk of w_x3: NP planes x Cout rows x 32 B
     const __amdgpu_buffer_rsrc_t rw = wx_rsrc(d.w_x3, (unsigned)((size_t)nk_all * w3chunk));
 
+    const float sw = F16 ? d.w_scale : 1.f;
+    float sxr[XR];  // fp16x2: the scale of each loader row's image
     int rowoff[XR];
     unsigned vmask[XR];
 #pragma unroll
@@ -106,6 +121,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
             ih0 = oh - 1 + ((d.phase - 1) >> 1);
             iw0 = ow - 1 + ((d.phase - 1) & 1);
         }
+        sxr[i] = (F16 && rok) ? a3d_in_scale(d, b) : 1.f;
         unsigned mask = 0;
         for (int kh = 0; kh < d.KH; ++kh)
             for (int kw = 0; kw < d.KW; ++kw)
@@ -135,13 +151,23 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         }
     };
     struct Split {
-        wx_bf16x4 h, m, l;
+        wx_bf16x4 h, m, l;  // (fp16x2: h, m hold the two fp16 planes' bits)
     };
-    auto put = [&](const int xst, const int i, const Split &v) {  // the three planes of loader row lr + RPP i
+    auto split = [&](const f32x4 v, const int i, Split &o) {
+        if constexpr (F16) {
+            wx_h16x4 h, l;
+            wx_split2h(v, sxr[i], h, l);
+            o.h = __builtin_bit_cast(wx_bf16x4, h);
+            o.m = __builtin_bit_cast(wx_bf16x4, l);
+        } else {
+            wx_split3(v, o.h, o.m, o.l);
+        }
+    };
+    auto put = [&](const int xst, const int i, const Split &v) {  // the planes of loader row lr + RPP i
         __bf16 *p = Xs + xst * XW_XST + (lr + RPP * i) * LKB + lcs;
         *reinterpret_cast<wx_bf16x4 *>(p) = v.h;
         *reinterpret_cast<wx_bf16x4 *>(p + PX) = v.m;
-        *reinterpret_cast<wx_bf16x4 *>(p + 2 * PX) = v.l;
+        if constexpr (!F16) *reinterpret_cast<wx_bf16x4 *>(p + 2 * PX) = v.l;
     };
     // weights: w_x3 [Kpad/16][3][Cout][16] bf16; one (chunk, plane) tile of this workgroup's 256 rows is an 8 KiB run = 8 DMA
     // wave-instructions of 32 rows.  Lane i of an instruction lands at LDS byte 16 i of its 1 KiB = row i/2, half i%2, and fetches
@@ -154,8 +180,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         __bf16 *Wt = Ws + dma_st * XW_WST;
         const int base = __builtin_amdgcn_readfirstlane(dma_c * (int)w3chunk + n0 * 32);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = wave * 3 + i;  // 24 instructions per chunk: plane j/8, row group j%8
+        for (int i = 0; i < NP; ++i) {
+            const int j = wave * NP + i;  // 8 NP instructions per chunk: plane j/8, row group j%8
             const int p = j >> 3, g = j & 7;
             wx_dma16(rw, Wt + p * PW + g * 32 * LKB, wvoff, base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + g * 1024));
         }
@@ -178,14 +204,14 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     const __bf16 *const fX = Xs + (wm * TM * 32) * LKB + frag_off;
     const __bf16 *const fW = Ws + (wn * TN * 32) * LKB + frag_off;
     struct FragA {
-        wx_bf16x8 p[3];  // weights of one 32-channel block, hi | mid | lo
+        wx_bf16x8 p[NP];  // weights of one 32-channel block, hi | mid | lo
     };
     struct FragB {
-        wx_bf16x8 p[3][TM];  // activations of the wave's two 32-pixel blocks
+        wx_bf16x8 p[NP][TM];  // activations of the wave's two 32-pixel blocks
     };
     auto rdA = [&](FragA &A, const int wst, const int n) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) A.p[p] = *reinterpret_cast<const wx_bf16x8 *>(fW + wst * XW_WST + p * PW + n * 32 * LKB);
+        for (int p = 0; p < NP; ++p) A.p[p] = *reinterpret_cast<const wx_bf16x8 *>(fW + wst * XW_WST + p * PW + n * 32 * LKB);
     };
     auto rdB = [&](FragB &Bf, const int xst, const int p) {
 #pragma unroll
@@ -193,9 +219,12 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     };
 
 #define XW_FENCE __builtin_amdgcn_sched_barrier(0);
-#define XW_TERM(N, A, Bf, PA, PB)                                                                     \
-    acc[N][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.p[PA], Bf.p[PB][0], acc[N][0], 0, 0, 0); \
-    acc[N][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.p[PA], Bf.p[PB][1], acc[N][1], 0, 0, 0);
+#define XW_MFMA(C, A, Bv)                                                                                                              \
+    if constexpr (F16) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wx_h16x8, A), __builtin_bit_cast(wx_h16x8, Bv), C, 0, 0, 0); \
+    else C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, C, 0, 0, 0);
+#define XW_TERM(N, A, Bf, PA, PB)                \
+    XW_MFMA(acc[N][0], A.p[PA], Bf.p[PB][0]) \
+    XW_MFMA(acc[N][1], A.p[PA], Bf.p[PB][1])
 // (one MFMA, then its share of the block's other instructions: the wave issues in order, so what follows an MFMA runs in its shadow)
 #define XW_MIX(NV)                                         \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
@@ -209,8 +238,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);     \
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 // the tail of a channel block: the four terms that carry no other work
-#define XW_REST(N, A, Bf) \
-    XW_TERM(N, A, Bf, 1, 1) XW_FENCE XW_TERM(N, A, Bf, 2, 0) XW_FENCE XW_TERM(N, A, Bf, 0, 2) XW_FENCE
+#define XW_REST(N, A, Bf)                                                                                       \
+    if constexpr (!F16) {                                                                                        \
+        XW_TERM(N, A, Bf, 1, 1) XW_FENCE XW_TERM(N, A, Bf, 2 % NP, 0) XW_FENCE XW_TERM(N, A, Bf, 0, 2 % NP) XW_FENCE \
+    }
 
     int wst = 0;  // W stage of the chunk being multiplied
     // one iteration; xst = X stage of chunk c (compile-time), Bc / Bn = the b sets of chunk c / c+1, xs = the staged chunk c+1
@@ -219,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         Split s;
         // ---- n = 0
         XW_TERM(0, A0, Bc, 0, 0)
-        wx_split3(xs[0], s.h, s.m, s.l);
+        split(xs[0], 0, s);
         XW_MIX(12)
         XW_FENCE
         XW_TERM(0, A0, Bc, 0, 1)
@@ -233,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         XW_REST(0, A0, Bc)
         // ---- n = 1
         XW_TERM(1, A1, Bc, 0, 0)
-        wx_split3(xs[1], s.h, s.m, s.l);
+        split(xs[1], 1, s);
         XW_MIX(12)
         XW_FENCE
         XW_TERM(1, A1, Bc, 0, 1)
@@ -268,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         XW_MIX(4)
         XW_FENCE
         XW_TERM(3, A1, Bc, 0, 1)
-        rdB(Bn, xst ^ 1, 2);
+        if constexpr (!F16) rdB(Bn, xst ^ 1, 2);
         rdA(A0, wnext, 0);
         XW_MIX(4)
         XW_FENCE
@@ -286,8 +317,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     load_chunk(xsA);
     {
         Split s0, s1;
-        wx_split3(xsA[0], s0.h, s0.m, s0.l);
-        wx_split3(xsA[1], s1.h, s1.m, s1.l);
+        split(xsA[0], 0, s0);
+        split(xsA[1], 1, s1);
         put(0, 0, s0);
         put(0, 1, s1);
     }
@@ -296,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 3; ++p) rdB(B0, 0, p);
+    for (int p = 0; p < NP; ++p) rdB(B0, 0, p);
     rdA(A0, 0, 0);
     XW_FENCE
 
@@ -310,10 +341,15 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 #undef XW_FENCE
 
     const bool has_res = d.res != nullptr && d.splitk == 1;
+    const int hwo = d.Ho * d.Wo;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
-        if (m >= M) continue;
+        const bool mok = m < M;
+        const int bimg = mok ? m / hwo : 0;  // image / ROI of this lane's output pixel
+        float vmax = 0.f;
+        if (mok) {
+        const float unscale = F16 ? 1.f / (a3d_in_scale(d, bimg) * sw) : 1.f;
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
@@ -333,14 +369,18 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                if constexpr (F16) v = v * unscale;  // exact: a power of two
                 if (d.splitk > 1) {
                     *reinterpret_cast<f32x4 *>(d.workspace + ((size_t)blockIdx.y * M + m) * d.Cout + n) = v;
                     continue;
                 }
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                vmax = fmaxf(vmax, a3d_absmax4(v));
                 store_out(d, v, m, n, b, oh, ow);
             }
         }
+        }
+        if (d.y_amax && d.splitk == 1) a3d_note_amax(d.y_amax, bimg, vmax, mok);  // (every lane of the wave gets here; split-K: the reducer)
     }
 }
 }  // namespace
@@ -370,11 +410,20 @@ int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
     }
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
-        if (hipFuncSetAttribute((const void *)conv_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XW_LDS_BYTES) != hipSuccess) return A3D_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void *)conv_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(3)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(2)) != hipSuccess)
+            return A3D_ERR_LAUNCH;
         attr_set = true;
     }
+    if (d->precision == 3) {
+        if (!d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
+        a3d_note_variant(d->splitk > 1 ? "conv_h2w_kernel sk%d" : "conv_h2w_kernel", d->splitk);
+        hipLaunchKernelGGL(conv_x3w_kernel<true>, dim3(mtiles * ntiles, d->splitk), dim3(512), xw_lds_bytes(2), s, *d, M, ntiles, mtiles * ntiles);
+        if (d->splitk > 1) a3d_launch_splitk_reduce(d, M, s);
+        return a3d_check_launch();
+    }
     a3d_note_variant(d->splitk > 1 ? "conv_x3w_kernel sk%d" : "conv_x3w_kernel", d->splitk);
-    hipLaunchKernelGGL(conv_x3w_kernel, dim3(mtiles * ntiles, d->splitk), dim3(512), XW_LDS_BYTES, s, *d, M, ntiles, mtiles * ntiles);
+    hipLaunchKernelGGL(conv_x3w_kernel<false>, dim3(mtiles * ntiles, d->splitk), dim3(512), xw_lds_bytes(3), s, *d, M, ntiles, mtiles * ntiles);
     if (d->splitk > 1) a3d_launch_splitk_reduce(d, M, s);
     return a3d_check_launch();
 }

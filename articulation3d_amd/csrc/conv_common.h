@@ -95,6 +95,36 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
 }
 
 
+// ---- fp16x2 mode (a3d_conv_desc.precision == 3) and the per-image output maxima every split-operand kernel can record -------------
+// power of two s with amax * s in [2^14, 2^15)  (amax == 0 or not finite -> 1)
+__device__ __forceinline__ float a3d_pow2_scale(const float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    return ldexpf(1.f, 14 - ilogbf(amax));
+}
+// scale of the rows of input image b (both sources of a channel concat share it)
+__device__ __forceinline__ float a3d_in_scale(const a3d_conv_desc &d, const int b) {
+    float a = d.in_amax[b];
+    if (d.in_amax2) a = fmaxf(a, d.in_amax2[b]);
+    return a3d_pow2_scale(a);
+}
+// y_amax[b] = max(y_amax[b], v) for the lanes with `valid`; v >= 0.  One atomic per wave when the wave's valid lanes share b (the
+// rule: 32 consecutive pixels of one image), and none at all once the slot already holds a larger value.
+__device__ __forceinline__ void a3d_note_amax(float *y_amax, const int b, float v, const bool valid) {
+    if (!valid) v = 0.f;
+    const unsigned long long live = __ballot(valid);
+    if (!live) return;
+    const int b0 = __shfl(b, __ffsll((long long)live) - 1, 64);
+    const bool uniform = __all(!valid || b == b0);
+    if (uniform) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+        if ((threadIdx.x & 63) == 0 && v > y_amax[b0]) atomicMax(reinterpret_cast<int *>(y_amax + b0), __float_as_int(v));
+    } else if (valid && v > y_amax[b]) {
+        atomicMax(reinterpret_cast<int *>(y_amax + b), __float_as_int(v));
+    }
+}
+__device__ __forceinline__ float a3d_absmax4(const f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+
 // Every conv launcher records the kernel instantiation it dispatched (name + template arguments as they appear in a
 // rocprofv3 kernel trace) in a per-thread slot; `a3d_last_conv_variant()` (include/a3d.h) reads it back, so measurement
 // code labels launches with what the dispatcher DID, not with a host-side copy of its rules.

@@ -297,7 +297,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v2_kernel(const a3d_co
     const int M = d.m_dev ? min(Mmax, *d.m_dev) : Mmax;
     const int n4 = d.Cout >> 2;
     const size_t total = (size_t)M * n4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t span = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < total; i0 += span) {  // (whole waves iterate: a3d_note_amax is wave-wide)
+        const size_t i = i0 + threadIdx.x;
+        const bool live = i < total;
+        float amax_v = 0.f;
+        int amax_b = 0;
+        if (live) {
         const int m = (int)(i / n4);
         const int n = (int)(i - (size_t)m * n4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -307,6 +313,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v2_kernel(const a3d_co
         out_rows(d, m, res_row, b, oh, ow);
         v = apply_epilogue(d, v, n, res_row);
         store_out(d, v, m, n, b, oh, ow);
+        if (d.y_amax) amax_v = a3d_absmax4(v), amax_b = m / (d.Ho * d.Wo);
+        }
+        // (a wave's 64 quads are consecutive columns of one row unless Cout < 256: a3d_note_amax handles both)
+        if (d.y_amax) a3d_note_amax(d.y_amax, amax_b, amax_v, live);
     }
 }
 

@@ -95,6 +95,7 @@ struct WinoArgs {
     float *y;            // [B, Hl, Wl, Cout]
     int T, C, Cout, B, Hl, Wl, Ty, Tx, act;
     const __bf16 *U3;    // precision 2: U split into bf16 planes, chunk-major [16][C/32][3][Cout][32]
+    float *y_amax;       // optional [B]: raised to max |y[b]| (a3d_conv_desc.y_amax)
 };
 
 template <int TN, int BKT>
@@ -469,7 +470,10 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_x3_kernel(const WinoArgs a, 
     }
 
     const int t = t0 + wm * 32 + (lane & 31);
-    if (t >= a.T) return;
+    const bool tok = t < a.T;
+    const int bimg = tok ? t / (a.Ty * a.Tx) : 0;  // all four outputs of a tile belong to one image
+    float vmax = 0.f;
+    if (tok) {
     const int tx = t % a.Tx;
     const int r = t / a.Tx;
     const int ty = r % a.Ty, b = r / a.Ty;
@@ -497,11 +501,13 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_x3_kernel(const WinoArgs a, 
                 const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
                 for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
             }
-            *reinterpret_cast<f32x4 *>(orow + n) = v;
+            vmax = fmaxf(vmax, a3d_absmax4(v));
+                *reinterpret_cast<f32x4 *>(orow + n) = v;
         }
     }
+    }
+    if (a.y_amax) a3d_note_amax(a.y_amax, bimg, vmax, tok);  // (every lane of the wave gets here)
 }
-
 // ------------------------------------------------------------------------------------------------
 // 2x-wide.  wino_gemm_x3_kernel above moves too many operand bytes per MFMA and waits for its fragments: every 64-tile block
 // streams all of U3 (6 B per weight) from L2 -- 30 GB + 20 GB of V per p2 layer, ~15 TB/s, the rate the L2s deliver -- and reads
@@ -796,7 +802,10 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 #undef X3W_FENCE
 
     const int t = t0 + wm * 32 + (lane & 31);
-    if (t >= a.T) return;
+    const bool tok = t < a.T;
+    const int bimg = tok ? t / (a.Ty * a.Tx) : 0;  // all four outputs of a tile belong to one image
+    float vmax = 0.f;
+    if (tok) {
     const int tx = t % a.Tx;
     const int r = t / a.Tx;
     const int ty = r % a.Ty, b = r / a.Ty;
@@ -826,12 +835,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                     const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
                     for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
                 }
+                vmax = fmaxf(vmax, a3d_absmax4(v));
                 *reinterpret_cast<f32x4 *>(orow + n) = v;
             }
         }
     }
+    }
+    if (a.y_amax) a3d_note_amax(a.y_amax, bimg, vmax, tok);  // (every lane of the wave gets here)
 }
-
 // src [outer][rows][cols] fp32 -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly: the chunk-major
 // plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a
 // plain [rows][cols] plane layout a lane's 16-byte piece of a row is a 64-byte-strided access and the kernel runs 2x slower).
@@ -856,6 +867,32 @@ extern "C" int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, in
     const size_t total = (size_t)outer * rows * cols;
     hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (__bf16 *)dst, rows, cols, chunk,
                        total);
+    return a3d_check_launch();
+}
+
+// the fp16x2 counterpart (precision 3): src * scale = hi + lo in fp16, dst [outer][cols/chunk][2][rows][chunk]
+typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, int rows, int cols, int chunk, float scale,
+                                                          size_t total) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const size_t per = (size_t)rows * cols;
+    const size_t o = i / per, r = i - o * per;
+    const int n = (int)(r / cols), c = (int)(r - (size_t)n * cols);
+    const f32x4 xs = *reinterpret_cast<const f32x4 *>(src + i) * scale;
+    const wh16x4 h = __builtin_convertvector(xs, wh16x4);
+    const wh16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wh16x4);
+    _Float16 *d = dst + o * 2 * per + ((size_t)(c / chunk) * 2 * rows + n) * chunk + (c % chunk);
+    *reinterpret_cast<wh16x4 *>(d) = h;
+    *reinterpret_cast<wh16x4 *>(d + (size_t)rows * chunk) = l;
+}
+
+extern "C" int a3d_split_f16x2_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, float scale, void *stream) {
+    if (!src || !dst || outer <= 0 || rows <= 0 || cols <= 0 || (chunk != 16 && chunk != 32) || cols % chunk || !(scale > 0.f)) return A3D_ERR_ARG;
+    a3d_begin();
+    const size_t total = (size_t)outer * rows * cols;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (_Float16 *)dst, rows, cols, chunk,
+                       scale, total);
     return a3d_check_launch();
 }
 
@@ -916,6 +953,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.act = d->act;
     const int mtiles = (int)((T + 63) / 64);
     a.U3 = nullptr;
+    a.y_amax = d->y_amax;
     if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);

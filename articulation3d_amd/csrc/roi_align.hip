@@ -461,3 +461,27 @@ extern "C" int a3d_roi_align_fpn_backward(const a3d_roialign_bwd_desc *d, void *
     hipLaunchKernelGGL(roi_align_fpn_backward_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
+
+
+// ---- upper bound of max |pooled[row]| for the fp16x2 split of the layers that consume pooled ROI features ----------------------
+// A pooled value is a convex combination of cells of ONE pyramid level of the ROI's image, so max over that image's levels bounds it.
+__global__ __launch_bounds__(256) void roi_amax_kernel(const float *a0, const float *a1, const float *a2, const float *a3, const int *count,
+                                                       const int *row_offset, int B, int R, float *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * R) return;
+    const int b = i / R, r = i - b * R;
+    if (r >= (count ? min(count[b], R) : R)) return;
+    float m = a0[b];
+    if (a1) m = fmaxf(m, a1[b]);
+    if (a2) m = fmaxf(m, a2[b]);
+    if (a3) m = fmaxf(m, a3[b]);
+    out[(row_offset ? row_offset[b] : b * R) + r] = m;
+}
+
+extern "C" int a3d_roi_amax(const float *const level_amax[4], int L, const int *count, const int *row_offset, int B, int R, float *out, void *stream) {
+    if (!level_amax || L < 1 || L > 4 || !level_amax[0] || !out || B <= 0 || R <= 0) return A3D_ERR_ARG;
+    a3d_begin();
+    hipLaunchKernelGGL(roi_amax_kernel, dim3((B * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, level_amax[0], L > 1 ? level_amax[1] : nullptr,
+                       L > 2 ? level_amax[2] : nullptr, L > 3 ? level_amax[3] : nullptr, count, row_offset, B, R, out);
+    return a3d_check_launch();
+}

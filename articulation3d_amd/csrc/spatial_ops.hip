@@ -304,3 +304,31 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
                        C);
     return a3d_check_launch();
 }
+
+
+// ---- per-image maxima of a tensor no kernel of this library produced (a3d_conv_desc.in_amax) --------------------------------
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
+    const int b = blockIdx.y;
+    const float *row = x + (size_t)b * n;
+    float m = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + i * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(row[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > out[b]) atomicMax(reinterpret_cast<int *>(out + b), __float_as_int(m));
+}
+
+extern "C" int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream) {
+    if (!x || !out || B <= 0 || B > 65535 || n == 0 || (((size_t)x | (n * 4)) & 15)) return A3D_ERR_ARG;
+    a3d_begin();
+    size_t bx = (n / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return a3d_check_launch();
+}

@@ -18,6 +18,7 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401
 
 GROUP_CAP = 1024
+fptr_t = C.c_void_p
 
 # Optional per-launch timing of the conv-GEMM kernel (bench.py's roofline leg): when a list is installed
 # here, conv2d() brackets its launch with HIP events on the launch stream and appends
@@ -41,7 +42,13 @@ CONV_TIMING: Optional[list] = None
 #   0 = fp32-input MFMA (A3D_PRECISION=0 / bench.py --precision fp32): the round-1 default, bit-compatible with it; the
 #       one-launch Winograd kernel (csrc/conv_wino_fused.hip) belongs to this mode.
 #   1 = bf16 MFMA with fp32 accumulation on plain convolutions / linears: autocast-level error, opt-in, never a parity mode.
+#   3 = "fp16x2": fp32-grade products from a two-way fp16 split (x * s = h + l, s a power of two per image), THREE fp16 MFMAs per k step.
 DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "2"))
+
+
+def H3_KINDS(p, wino_ok: bool, splitk: int) -> bool:
+    """Layer kinds that have an fp16x2 kernel (the others keep bf16x3 inside mode 3)."""
+    return not wino_ok
 
 
 def last_conv_variant() -> str:
@@ -90,6 +97,7 @@ class PackedConv:
     phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
     presplit: bool = False  # set by the pack_* functions (module-cached weights): precision-2 launches may cache w_x3 below
     w_x3: Optional[torch.Tensor] = None  # [Kpad/16, 3, cols, 16] bf16 planes of w (a3d_conv_desc.w_x3), made at the first such use
+    w_h2: Optional[torch.Tensor] = None  # [Kpad/16, 2, cols, 16] fp16 planes of w * w_scale (a3d_conv_desc.w_x3 at precision 3)
 
     @property
     def out_channels(self) -> int:
@@ -242,6 +250,53 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 # --------------------------------------------------------------------------------------------------
 # kernels
 # --------------------------------------------------------------------------------------------------
+# ---- per-image maxima of activation tensors (a3d_conv_desc.in_amax / y_amax): the power-of-two scales of the fp16x2 split ------
+# A tensor [B, ...] produced by a split-operand launch carries `_a3d_amax`, a device tensor [B] with max |t[b]| (recorded by the
+# launch's epilogue into a zero-initialised slot).  Views made on the hot path hand it on with keep_amax(); any other tensor gets its
+# maxima from a3d_absmax_rows on first use.  Slots come from zeroed arena chunks (one fill per ~256k floats, freed with their tensors).
+_AMAX_CHUNK = 1 << 18
+AMAX_MISSES: Optional[list] = None  # debugging: install a list to record the tensors whose maxima had to be computed by a3d_absmax_rows
+_amax_arena: dict = {}
+
+
+def amax_slot(n: int, device) -> torch.Tensor:
+    a = _amax_arena.get(device)
+    if a is None or a[1] + n > a[0].numel():
+        a = _amax_arena[device] = [torch.zeros(max(_AMAX_CHUNK, n), device=device, dtype=torch.float32), 0]
+    t = a[0][a[1]:a[1] + n]
+    a[1] += (n + 3) // 4 * 4
+    return t
+
+
+def amax_of(x: torch.Tensor) -> torch.Tensor:
+    a = getattr(x, "_a3d_amax", None)
+    if a is not None and a.numel() == x.shape[0] and a.device == x.device:
+        return a
+    if AMAX_MISSES is not None:
+        AMAX_MISSES.append(tuple(x.shape))
+    a = amax_slot(x.shape[0], x.device)
+    _lib.check(_lib.lib().a3d_absmax_rows(x.data_ptr(), a.data_ptr(), x.shape[0], x.numel() // x.shape[0], _stream()), "a3d_absmax_rows")
+    x._a3d_amax = a
+    return a
+
+
+def keep_amax(new: torch.Tensor, old: torch.Tensor) -> torch.Tensor:
+    """`new` is a view / reshape of `old` with the same leading dimension: it keeps old's recorded maxima."""
+    a = getattr(old, "_a3d_amax", None)
+    if a is not None and new.shape[0] == old.shape[0]:
+        new._a3d_amax = a
+    return new
+
+
+def _const_amax(t: torch.Tensor, bound: float) -> None:
+    if DEFAULT_PRECISION == 3:
+        t._a3d_amax = torch.full((t.shape[0],), float(bound), device=t.device, dtype=torch.float32)
+
+
+def _pow2_scale_host(amax: float) -> float:
+    return 1.0 if not (amax > 0.0) else 2.0 ** (14 - math.frexp(amax)[1] + 1)
+
+
 _WINO_SHARE: Optional[dict] = None
 WINO_SHARE_ENABLED = os.environ.get("A3D_WINO_SHARE", "1") != "0"  # schedule-only switch (tests compare both settings bit for bit)
 
@@ -310,7 +365,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         plain = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
         if mode == 1:
             precision = 1 if plain and p.Cin % 32 == 0 else 0
-        elif mode == 2:  # a function of the layer only, like the Winograd rule (batch-size invariance)
+        elif mode in (2, 3):  # a function of the layer only, like the Winograd rule (batch-size invariance)
             # (the bf16x3 kernel also takes the phase convs of the depth decoder and their 2-source channel concat)
             # (split-K -- the 50176-deep head FCs -- only through the wide kernel, whose conditions the last line repeats)
             x3_ok = p.stem and not ups and splitk == 1 and m_dev is None and x2 is None and res is None
@@ -324,10 +379,24 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             # kernel -- 986 vs 971 frames/s -- but with that mix one of the 800 scores of the end-to-end test at threshold 0.0 moved
             # to 1.007e-4 from the oracle's, past the stated 1e-4: the arithmetic stays uniform.)
             precision = 2 if tune == 0 and ((x3_ok and not wino_ok) or (wino_ok and (Cin + Cin2) % 32 == 0)) else 0
+            if precision == 2 and mode == 3 and H3_KINDS(p, wino_ok, splitk):
+                precision = 3
         else:
             precision = 0
     d.precision = int(precision)
     d.phase = int(p.phase)
+    if d.precision == 3:  # fp16x2: per-image scales of the activations (recorded by their producers), one static scale of the filter
+        d.in_amax = amax_of(x).data_ptr()
+        if x2 is not None:
+            d.in_amax2 = amax_of(x2).data_ptr()
+        if getattr(p, "_w_scale", None) is None:
+            p._w_scale = _pow2_scale_host(float(p.w.abs().max()))
+        d.w_scale = p._w_scale
+    if d.precision in (2, 3) and (DEFAULT_PRECISION == 3 or d.precision == 3) and not p.pixshuf:
+        ya = getattr(out, "_a3d_amax", None)  # (the four phase launches of an upsampled conv share their output and its slot)
+        if ya is None or ya.numel() != out.shape[0]:
+            ya = out._a3d_amax = amax_slot(out.shape[0], out.device)
+        d.y_amax = ya.data_ptr()
     # Winograd F(2x2,3x3) for every 3x3 s1 p1 layer that has Winograd-domain weights.  The choice must not depend on the
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
@@ -348,6 +417,15 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                 if not os.environ.get("A3D_NO_PUBLISH"):
                     torch.cuda.current_stream().synchronize()
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
+    if (d.precision == 3 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
+            and not (p.stem or p.pixshuf)):
+        if p.w_h2 is None or p.w_h2.device != p.w.device:  # the fp16x2 planes of the filter, scaled by w_scale (once per packed layer)
+            p.w_h2 = torch.empty((p.Kpad // 16, 2, p.w.shape[0], 16), device=p.w.device, dtype=torch.float16)
+            _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w.data_ptr(), p.w_h2.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, d.w_scale, _stream()),
+                       "a3d_split_f16x2_chunk")
+            if not os.environ.get("A3D_NO_PUBLISH"):
+                torch.cuda.current_stream().synchronize()  # published to every stream, see w_wino_x3 below
+        d.w_x3 = p.w_h2.data_ptr()
     if (d.precision == 2 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
             and not (p.stem or p.pixshuf)):
         # wide layers: weight planes pre-split once per packed layer, streamed by LDS-DMA (csrc/conv_bf16x3_wide.hip)
@@ -404,7 +482,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
             e2.record()
             CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none"))
             CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin,
-                                "bf16x6" if d.precision == 2 else "f32"))
+                                {2: "bf16x6", 3: "f16x3"}.get(int(d.precision), "f32")))
             return out
         e0, e1 = ev(), ev()
         e0.record()
@@ -413,7 +491,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         executed = 2.0 * B * Ho * Wo * p.cols * k_real
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
-        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6"}[int(d.precision)]))
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)]))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out
@@ -432,8 +510,8 @@ def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk:
            m_dev: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
     """x [M, K] -> [M, cols]."""
     M, K = x.shape
-    y = conv2d(x.view(M, 1, 1, K), p, act=act, splitk=splitk, m_dev=m_dev, precision=precision)
-    return y.view(M, p.cols)
+    y = conv2d(keep_amax(x.view(M, 1, 1, K), x), p, act=act, splitk=splitk, m_dev=m_dev, precision=precision)
+    return keep_amax(y.view(M, p.cols), y)
 
 
 def choose_splitk(M: int, cols: int, K: int) -> int:
@@ -454,6 +532,7 @@ def preprocess_u8hwc(frames: torch.Tensor, mean, std) -> torch.Tensor:
     out = torch.empty((B, H, W, 4), device=frames.device, dtype=torch.float32)
     _lib.check(_lib.lib().a3d_preprocess_u8hwc(frames.data_ptr(), out.data_ptr(), B, H, W, _f3(mean), _f3(std), _stream()),
                "a3d_preprocess_u8hwc")
+    _const_amax(out, max(max(abs(0.0 - m), abs(255.0 - m)) / sd for m, sd in zip(mean, std)))  # u8 input: a closed-form bound
     return out
 
 
@@ -468,6 +547,7 @@ def preprocess_resize_u8(frames: torch.Tensor, mean, std, out_hw=(480, 640), swa
     u8 = torch.empty((B, Hd, Wd, 3), device=frames.device, dtype=torch.uint8) if want_u8 else None
     _lib.check(_lib.lib().a3d_preprocess_resize_u8(frames.data_ptr(), out.data_ptr(), _p(u8), B, Hs, Ws, Hd, Wd, int(bool(swap_rb)),
                                                    _f3(mean), _f3(std), _stream()), "a3d_preprocess_resize_u8")
+    _const_amax(out, max(max(abs(0.0 - m), abs(255.0 - m)) / sd for m, sd in zip(mean, std)))
     return (out, u8) if want_u8 else out
 
 
@@ -485,6 +565,7 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc = x.shape
     out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().a3d_maxpool3x3s2_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, _stream()), "a3d_maxpool3x3s2_nhwc")
+    keep_amax(out, x)  # (a max / a copy / a convex combination of x's values: x's per-image maxima bound out's)
     return out
 
 
@@ -493,6 +574,7 @@ def subsample2(x: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc = x.shape
     out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().a3d_subsample2_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, _stream()), "a3d_subsample2_nhwc")
+    keep_amax(out, x)  # (a max / a copy / a convex combination of x's values: x's per-image maxima bound out's)
     return out
 
 
@@ -502,6 +584,7 @@ def resize_bilinear(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
     out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().a3d_resize_bilinear_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, Ho, Wo, _stream()),
                "a3d_resize_bilinear_nhwc")
+    keep_amax(out, x)  # (a max / a copy / a convex combination of x's values: x's per-image maxima bound out's)
     return out
 
 
@@ -653,6 +736,11 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     order = torch.empty((B * R,), device=dev, dtype=torch.int32) if (512 <= R <= 1024 and ROI_SPATIAL_ORDER) else None
     d.order_ws = _p(order)
     _lib.check(_lib.lib().a3d_roi_align_fpn(C.byref(d), _stream()), "a3d_roi_align_fpn")
+    if DEFAULT_PRECISION == 3:  # fp16x2: per-ROI bound of the pooled magnitudes from the levels' per-image maxima (a3d_roi_amax)
+        la = (fptr_t * 4)(*([amax_of(f).data_ptr() for f in feats] + [None] * (4 - len(feats))))
+        ra = amax_slot(nrows, dev)
+        _lib.check(_lib.lib().a3d_roi_amax(la, len(feats), _p(count), _p(row_offset), B, R, ra.data_ptr(), _stream()), "a3d_roi_amax")
+        out._a3d_amax = ra
     return (out, lvl) if want_level else out
 
 

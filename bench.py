@@ -34,13 +34,15 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; never the 2:1-sparsity figure)
-PIPE_PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x6": BF16_MFMA_PEAK_TFLOPS}
-PIPE_FLOPS_PER_FMA = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "none": 0.0}  # matrix-pipe products issued per fp32 multiply-add
+PIPE_PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x6": BF16_MFMA_PEAK_TFLOPS, "f16x3": BF16_MFMA_PEAK_TFLOPS}
+PIPE_FLOPS_PER_FMA = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "f16x3": 3.0, "none": 0.0}  # matrix-pipe products issued per fp32 multiply-add
 
 
 DTYPES = {
     "bf16x3": "f32 (fp32 tensors and accumulation; every product formed from exact 3-way bf16 operand splits, six bf16 MFMAs per k step: "
               "error vs float64 <= the fp32-input MFMA's, the whole parity suite runs in this arithmetic)",
+    "fp16x2": "f32 (fp32 tensors and accumulation; every product formed from a two-way fp16 split of each operand, scaled by a power of two "
+              "per image: three fp16 MFMAs per k step, error vs float64 <= the fp32-input MFMA's)",
     "fp32": "f32 (fp32-input MFMA)",
     "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in autocast mode, not comparable with the f32 figures",
 }
@@ -58,7 +60,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the secondary timed loop in the other arithmetic (fp32-input MFMA)")
     ap.add_argument("--no-operating-points", action="store_true", help="skip the A / B / C operating points and the transfer-inclusive loop")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3", "fp16x2"],
                     help="bf16x3 (default: fp32-grade products from exact 3-way bf16 operand splits on the bf16 MFMA, fp32 tensors and "
                          "accumulation; the arithmetic the package and its parity suite run in), fp32 (fp32-input MFMA, the round-1 default) "
                          "or bf16 (opt-in autocast arithmetic -- reported with its own dtype, not comparable)")
@@ -195,7 +197,7 @@ def main():
     from articulation3d_amd.utils.synthetic import synthetic_frames
 
     model, cfg = build_detector(args.score_thresh, dev)
-    ops.DEFAULT_PRECISION = {"fp32": 0, "bf16": 1, "bf16x3": 2}[args.precision]
+    ops.DEFAULT_PRECISION = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 3}[args.precision]
     B = args.batch
     # contiguous block of the synthetic clip per rank (temporal order is restored by rank order)
     frames_np = synthetic_frames(B, seed=2020 + rank)
@@ -344,8 +346,11 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
+        # the dispatcher's variant name vs the rocprofv3 kernel name: "conv_x3_kernel<2>" <-> "conv_x3_kernel<2, false>"
+        norm = lambda n: n.replace(", false>", ">").replace(", true>", "> stem").replace(" ", "")
         stem = dname.split("<")[0].split(" ")[0]
-        k = next((v for n, v in tr.get("kernels", {}).items() if n.split("<")[0] == stem), None)
+        k = next((v for n, v in tr.get("kernels", {}).items() if norm(n) == norm(dname)), None) or \
+            next((v for n, v in tr.get("kernels", {}).items() if n.split("<")[0] == stem), None)
         if k:
             roofline["traffic"] = k["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "committed " + os.path.relpath(tpath, ROOT) + ": separate rocprofv3 --pmc passes of this command, NOT measured in this run"

@@ -124,6 +124,14 @@ typedef struct a3d_conv_desc {
                             cols = Kpad, chunk = 16).  With it, wide and large layers run the 256 x 256-tile kernel that
                             moves the weight planes global -> LDS by LDS-DMA (csrc/conv_bf16x3_wide.hip); results are
                             bit-identical to the kernel that splits w on the fly                                       */
+    /* ---- precision 3 ("fp16x2"): fp32-grade products from an exact-to-2^-22 two-way fp16 split of each operand, THREE fp16 MFMAs
+     * per k step (csrc/conv_bf16x3.hip).  fp16 has 5 exponent bits, so every operand row is scaled by a power of two taken from the
+     * largest magnitude of ITS image / ROI -- a frame's result never depends on what else is in the batch:                        */
+    const float *in_amax;  /* DEVICE [B]: max |x[b]| (an upper bound is fine) per input image b; required at precision 3            */
+    const float *in_amax2; /* DEVICE [B] for source 1 (x2), or NULL                                                                 */
+    float *y_amax;         /* optional DEVICE [B], zero-initialised by the caller: the launch raises y_amax[b] to max |y[b]| (atomic
+                              max; any precision of the split-operand kernels) so that the next layer has its in_amax for free      */
+    float w_scale;         /* precision 3: power of two that puts max |w| (Winograd layers: max |w_wino|) in [2^14, 2^15)           */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -133,6 +141,11 @@ int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
 int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream);
 /* The same with `chunk`-deep column chunks (16 or 32; cols % chunk == 0): dst [outer][cols/chunk][3][rows][chunk]. */
 int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, void *stream);
+/* The fp16x2 counterpart (precision 3): src * scale == hi + lo (fp16, to 2^-22 relative); dst [outer][cols/chunk][2][rows][chunk]. */
+int a3d_split_f16x2_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, float scale, void *stream);
+/* out[b] = max(out[b], max |x[b, 0..n)|) for b < B (out zero-initialised by the caller): the in_amax of a tensor that no kernel of
+ * this library produced. */
+int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream);
 
 /* The two launches of the Winograd form, individually (a3d_conv2d_nhwc_f32 issues both when d->w_wino is set):
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */
@@ -241,6 +254,10 @@ typedef struct a3d_roialign_desc {
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);
+
+/* out[row of (b, r)] = max over the L levels of level_amax[l][b], for the live boxes r < count[b]: an upper bound of max |pooled[row]|
+ * (a3d_conv_desc.in_amax of the layers that consume the pooled features; rows as in a3d_roi_align_fpn). */
+int a3d_roi_amax(const float *const level_amax[4], int L, const int *count, const int *row_offset, int B, int R, float *out, void *stream);
 
 /* offsets[b] = sum_{i<b} min(count[i], cap); offsets[B] = total.  (compacts ragged per-image ROI lists) */
 int a3d_count_offsets(const int *count, int *offsets, int B, int cap, void *stream);

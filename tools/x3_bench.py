@@ -26,18 +26,23 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
     ("res4 3x3 256->256", 64, 30, 40, 256, 256, 3, 1),
     ("res3 3x3 s2 128->128", 64, 120, 160, 128, 128, 3, 2),
 ]
-VARIANTS = [("default", dict()), ("direct", dict(wino=False, tune=5)), ("bf16x3", dict(precision=2)), ("bf16", dict(precision=1))]
+VARIANTS = [("default", dict()), ("direct", dict(wino=False, tune=5, precision=0)), ("bf16x3", dict(precision=2, wino=False)),
+            ("fp16x2", dict(precision=3, wino=False)), ("bf16", dict(precision=1))]
+if os.environ.get("X3_BENCH_RELU"):  # realistic activations: post-ReLU with a per-channel spread of magnitudes
+    pass
 
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
     torch.manual_seed(0)
-    print(f"{'shape':24s} {'GFLOP':>8s} " + " ".join(f"{n:>17s}" for n, _ in VARIANTS) + "   rel-L2 / max-rel error vs float64: direct | bf16x3 | bf16")
+    print(f"{'shape':24s} {'GFLOP':>8s} " + " ".join(f"{n:>17s}" for n, _ in VARIANTS) + "   rel-L2 / max-rel error vs float64: direct | bf16x3 | fp16x2 | bf16")
     for name, B, H, W, Cin, Cout, k, s in SHAPES:
         if filt not in name:
             continue
         x = torch.randn(B, H, W, Cin, device="cuda")
+        if os.environ.get("X3_BENCH_RELU"):
+            x = torch.relu(x) * torch.exp(1.5 * torch.randn(Cin, device="cuda"))
         w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
         bias = torch.randn(Cout)
         p = ops.pack_conv(w, bias, None, s, k // 2, ops.ACT_NONE)
