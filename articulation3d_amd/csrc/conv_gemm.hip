@@ -275,7 +275,10 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
         if ((d->tune == 0 || d->tune == 8) && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
         return a3d_conv_launch_bf16x3(d, s);
     }
-    if (d->precision == 3) return a3d_conv_launch_bf16x3(d, s);  // fp16x2 split (prototype: direct layers only)
+    if (d->precision == 3) {  // fp16x2 split: Winograd layers (wide kernels) when their pre-split filter is given, the rest direct
+        if (d->tune == 0 && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+        return a3d_conv_launch_bf16x3(d, s);
+    }
     if (d->precision != 0) return A3D_ERR_ARG;
     if (d->tune == 0 && a3d_wino_fused_eligible(d)) return a3d_conv_launch_wino_fused(d, s);  // one launch, no V tensor (tune 7: the two-launch form)
     if ((d->tune == 0 || d->tune == 7 || d->tune >= 200) && d->workspace && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);

@@ -96,7 +96,18 @@ struct WinoArgs {
     int T, C, Cout, B, Hl, Wl, Ty, Tx, act;
     const __bf16 *U3;    // precision 2: U split into bf16 planes, chunk-major [16][C/32][3][Cout][32]
     float *y_amax;       // optional [B]: raised to max |y[b]| (a3d_conv_desc.y_amax)
+    const float *in_amax, *in_amax2;  // precision 3: per-image maxima of the conv input(s)
+    float w_scale;                    // precision 3: scale of the pre-split filter planes in U3
 };
+
+typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 wh16x8 __attribute__((ext_vector_type(8)));
+// power-of-two scale of the V rows of image b: |B^T d B| <= 4 max |d|
+__device__ __forceinline__ float wino_v_scale(const WinoArgs &a, const int b) {
+    float m = a.in_amax[b];
+    if (a.in_amax2) m = fmaxf(m, a.in_amax2[b]);
+    return a3d_pow2_scale(4.f * m);
+}
 
 template <int TN, int BKT>
 __global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const WinoArgs a, const int ntiles, const int nblk) {
@@ -541,17 +552,20 @@ __device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t r, __bf16 *lds_dst
 }
 
 constexpr int X3W_BN = 128, X3W_LKB = 32;
-constexpr int x3w_buf(int WM) { return 3 * (32 * WM + X3W_BN) * X3W_LKB; }  // bf16 elements of one stage: X and W, 3 planes each
-constexpr int x3w_lds_bytes(int WM) { return 2 * x3w_buf(WM) * 2 + 2 * X3W_BN * 4; }
+constexpr int x3w_buf(int WM, int NP) { return NP * (32 * WM + X3W_BN) * X3W_LKB; }  // 16-bit elements of one stage: X and W, NP planes each
+constexpr int x3w_lds_bytes(int WM, int NP) { return 2 * x3w_buf(WM, NP) * 2 + 2 * X3W_BN * 4; }
 
 // WM = wave rows: 2 -> 64 tiles x 128 channels, 256 threads, two workgroups per CU; 4 -> 128 tiles x 128 channels, 512 threads, one
 // workgroup per CU (every 64-tile block streams all of U3 -- 6 B per weight -- from L2: 30 GB per p2 layer; 128-tile blocks halve it)
-template <int WM>
+// F16: the fp16x2 arithmetic (a3d_conv_desc.precision == 3): two operand planes, three product terms per step; V rows are scaled by the
+// power of two of 4 x their image's input maximum (|B^T d B| <= 4 max |d|), U3 holds the filter pre-split by a3d_split_f16x2_chunk.
+template <int WM, bool F16 = false>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+    constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
-    constexpr int PLX = BM * LKB, PLW = BN * LKB, BUF = x3w_buf(WM);
-    constexpr int DPW = 24 / NW;  // weight DMA instructions per wave and chunk
+    constexpr int PLX = BM * LKB, PLW = BN * LKB, BUF = x3w_buf(WM, NP);
+    constexpr int DPW = 8 * NP / NW;  // weight DMA instructions per wave and chunk
     static_assert(XR == 2, "the counted vmcnt waits below assume two V loads per chunk");
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     float *ss = reinterpret_cast<float *>(lds + 2 * BUF);
@@ -569,23 +583,25 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const int NIT = 16 * KC;
 
     int xoff[XR];
+    float sxr[XR];  // fp16x2: scale of each loader row (tile) = that of its image
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int t = t0 + lr + RPP * i;
         xoff[i] = t < a.T ? (t * a.C + lc) * 4 : -1;
+        sxr[i] = (F16 && t < a.T) ? wino_v_scale(a, t / (a.Ty * a.Tx)) : 1.f;
     }
     const int lcs = ((((lc >> 3) ^ (lr >> 2)) & 3) << 3) | (lc & 7);  // (RPP is a multiple of 16: both passes share the swizzle)
     // weights: U3 [16][C/32][3][Cout][32] bf16; one (f, chunk, plane) tile of this workgroup's 128 rows is an 8 KiB run = 8 DMA
     // wave-instructions of 16 rows.  Lane i of an instruction lands at LDS byte 16 i of its 1 KiB = row i/4, slot i%4, and
     // fetches the k slot that the image keeps there: slot ^ ((row >> 2) & 3)  (row base is a multiple of 16)
-    const __amdgpu_buffer_rsrc_t ru = wuni_rsrc(a.U3, (unsigned)((size_t)16 * a.Cout * a.C * 2 * 3));
+    const __amdgpu_buffer_rsrc_t ru = wuni_rsrc(a.U3, (unsigned)((size_t)16 * a.Cout * a.C * 2 * NP));
     const int wvoff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     const int u3tile = a.Cout * 64;  // bytes of one (f, chunk, plane) tile
     int dma_c = 0;                   // flat (f, kc) index of the next weight chunk to fetch
     auto dma_w = [&](const int buf) {
         // 24 instructions per chunk: instruction j = plane j/8, row group j%8
-        __bf16 *Wt = lds + buf * BUF + 3 * PLX;
-        const int base = __builtin_amdgcn_readfirstlane(min(dma_c, NIT - 1) * 3 * u3tile + n0 * 64);
+        __bf16 *Wt = lds + buf * BUF + NP * PLX;
+        const int base = __builtin_amdgcn_readfirstlane(min(dma_c, NIT - 1) * NP * u3tile + n0 * 64);
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
             const int j = wave * DPW + i;
@@ -608,13 +624,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         }
     };
     struct Split {
-        wbf16x4 h, m, l;
+        wbf16x4 h, m, l;  // (fp16x2: h, m hold the two fp16 planes' bits)
     };
-    auto put = [&](const int buf, const int i, const Split &v) {  // the three planes of loader row lr + RPP i
+    auto split = [&](const f32x4 v, const int i, Split &o) {
+        if constexpr (F16) {
+            const f32x4 xs = v * sxr[i];
+            const wh16x4 h = __builtin_convertvector(xs, wh16x4);
+            const wh16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wh16x4);
+            o.h = __builtin_bit_cast(wbf16x4, h);
+            o.m = __builtin_bit_cast(wbf16x4, l);
+        } else {
+            wsplit3(v, o.h, o.m, o.l);
+        }
+    };
+    auto put = [&](const int buf, const int i, const Split &v) {  // the planes of loader row lr + RPP i
         __bf16 *p = lds + buf * BUF + (lr + RPP * i) * LKB + lcs;
         *reinterpret_cast<wbf16x4 *>(p) = v.h;
         *reinterpret_cast<wbf16x4 *>(p + PLX) = v.m;
-        *reinterpret_cast<wbf16x4 *>(p + 2 * PLX) = v.l;
+        if constexpr (!F16) *reinterpret_cast<wbf16x4 *>(p + 2 * PLX) = v.l;
     };
 
     f32x16 mf[TN];
@@ -636,9 +663,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const int frow = lane & 31;
     const int fsw = (frow >> 2) & 3;
     const __bf16 *fX = lds + (wm * 32 + frow) * LKB;
-    const __bf16 *fW = lds + 3 * PLX + (wn * 64 + frow) * LKB;
+    const __bf16 *fW = lds + NP * PLX + (wn * 64 + frow) * LKB;
     struct Frags {
-        wbf16x8 a[3][TN], b[3];
+        wbf16x8 a[NP][TN], b[NP];
     };
     auto rdA = [&](Frags &F, const int buf, const int st, const int p) {
         const int slot = (((2 * st + (lane >> 5)) ^ fsw) & 3) << 3;
@@ -681,9 +708,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     // step could only start after its predecessor's last MFMA had issued, and the exposed LDS latency cost 29 % of the kernel
     // (timing-only ablation: 3.80 -> 2.69 ms without the reads).
 #define X3W_FENCE __builtin_amdgcn_sched_barrier(0);
-#define X3W_TERM(F, PA, PB)                                                                   \
-    mf[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[PA][0], F.b[PB], mf[0], 0, 0, 0); \
-    mf[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[PA][1], F.b[PB], mf[1], 0, 0, 0);
+#define X3W_MFMA(C, A, Bv)                                                                                                                \
+    if constexpr (F16) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wh16x8, A), __builtin_bit_cast(wh16x8, Bv), C, 0, 0, 0); \
+    else C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, C, 0, 0, 0);
+#define X3W_TERM(F, PA, PB)              \
+    X3W_MFMA(mf[0], F.a[PA][0], F.b[PB]) \
+    X3W_MFMA(mf[1], F.a[PA][1], F.b[PB])
 // (one MFMA, then its share of the block's other instructions: the wave issues in order, so what follows an MFMA runs in its shadow)
 #define X3W_MIX(NV)                                        \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
@@ -698,11 +728,31 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
     auto step0 = [&](const int cur, Frags &F, Frags &G, const f32x4 (&xs)[XR]) {
         Split s0, s1;
+        if constexpr (F16) {  // three terms: h.h, h.l, l.h
+            X3W_TERM(F, 0, 0)
+            rdA(G, cur, 1, 0);
+            rdB(G, cur, 1, 0);
+            rdB(G, cur, 1, 1);
+            split(xs[0], 0, s0);
+            X3W_MIX(10)
+            X3W_FENCE
+            X3W_TERM(F, 0, 1)
+            put(cur ^ 1, 0, s0);
+            split(xs[1], 1, s1);
+            X3W_MIX(10)
+            X3W_FENCE
+            X3W_TERM(F, 1, 0)
+            put(cur ^ 1, 1, s1);
+            rdA(G, cur, 1, 1);
+            X3W_MIX(4)
+            X3W_FENCE
+            return;
+        }
         X3W_TERM(F, 0, 0)
         rdA(G, cur, 1, 0);
         rdB(G, cur, 1, 0);
         rdB(G, cur, 1, 1);
-        wsplit3(xs[0], s0.h, s0.m, s0.l);
+        split(xs[0], 0, s0);
         X3W_MIX(12)
         X3W_FENCE
         X3W_TERM(F, 0, 1)
@@ -710,7 +760,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         X3W_MIX(4)
         X3W_FENCE
         X3W_TERM(F, 1, 0)
-        wsplit3(xs[1], s1.h, s1.m, s1.l);
+        split(xs[1], 1, s1);
         X3W_MIX(12)
         X3W_FENCE
         X3W_TERM(F, 1, 1)
@@ -728,6 +778,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         X3W_FENCE
     };
     auto step1 = [&](const int cur, Frags &F, Frags &G, f32x4 (&xs)[XR]) {
+        if constexpr (F16) {
+            X3W_TERM(F, 0, 0)
+            dma_w(cur);
+            rdA(G, cur ^ 1, 0, 0);
+            rdB(G, cur ^ 1, 0, 0);
+            rdB(G, cur ^ 1, 0, 1);
+            X3W_MIX(6)
+            X3W_FENCE
+            X3W_TERM(F, 0, 1)
+            load_chunk(xs);
+            X3W_MIX(6)
+            X3W_FENCE
+            X3W_TERM(F, 1, 0)
+            rdA(G, cur ^ 1, 0, 1);
+            X3W_MIX(4)
+            X3W_FENCE
+            return;
+        }
         X3W_TERM(F, 0, 0)
         dma_w(cur);
         rdA(G, cur ^ 1, 0, 0);
@@ -760,8 +828,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     load_chunk(xsA);
     {
         Split s0, s1;
-        wsplit3(xsA[0], s0.h, s0.m, s0.l);
-        wsplit3(xsA[1], s1.h, s1.m, s1.l);
+        split(xsA[0], 0, s0);
+        split(xsA[1], 1, s1);
         put(0, 0, s0);
         put(0, 1, s1);
     }
@@ -770,7 +838,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
         rdA(F0, 0, 0, p);
         rdB(F0, 0, 0, p);
     }
@@ -799,6 +867,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     }
 #undef X3W_MIX
 #undef X3W_TERM
+#undef X3W_MFMA
 #undef X3W_FENCE
 
     const int t = t0 + wm * 32 + (lane & 31);
@@ -806,6 +875,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const int bimg = tok ? t / (a.Ty * a.Tx) : 0;  // all four outputs of a tile belong to one image
     float vmax = 0.f;
     if (tok) {
+    const float unscale = F16 ? 1.f / (wino_v_scale(a, bimg) * a.w_scale) : 1.f;
     const int tx = t % a.Tx;
     const int r = t / a.Tx;
     const int ty = r % a.Ty, b = r / a.Ty;
@@ -823,6 +893,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 const int n = n0 + nl;
                 if (n >= a.Cout) continue;
                 f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
+                if constexpr (F16) v = v * unscale;  // exact: a power of two
                 const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
@@ -871,7 +942,6 @@ extern "C" int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, in
 }
 
 // the fp16x2 counterpart (precision 3): src * scale = hi + lo in fp16, dst [outer][cols/chunk][2][rows][chunk]
-typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, int rows, int cols, int chunk, float scale,
                                                           size_t total) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -954,6 +1024,36 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     const int mtiles = (int)((T + 63) / 64);
     a.U3 = nullptr;
     a.y_amax = d->y_amax;
+    a.in_amax = d->in_amax;
+    a.in_amax2 = d->in_amax2;
+    a.w_scale = d->w_scale;
+    if (d->precision == 3) {  // fp16x2: the wide kernels only (w_wino_x3 = the filter pre-split by a3d_split_f16x2_chunk(.., 32, w_scale))
+        if (!d->w_wino_x3 || (a.C & 31) || !d->in_amax || !(d->w_scale > 0.f) || ((d->Cout + 63) / 64) % 2 != 0 ||
+            (size_t)16 * d->Cout * a.C * 4 >= ((size_t)1 << 32))
+            return A3D_ERR_ARG;
+        a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
+        static int wm_force3 = -1;
+        if (wm_force3 < 0) wm_force3 = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
+        const int nt = (d->Cout + X3W_BN - 1) / X3W_BN;
+        const long blocks4 = (long)((T + 127) / 128) * nt;
+        // 128-tile blocks (one 512-thread workgroup per CU) once they fill the chip; below that 64-tile blocks, two per CU
+        const int wmx = wm_force3 ? wm_force3 : (blocks4 >= 192 ? 4 : 2);
+        static bool attr3 = false;
+        if (!attr3) {
+            if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess)
+                return A3D_ERR_LAUNCH;
+            attr3 = true;
+        }
+        a3d_note_variant("wino_gemm_h2w_kernel<%d>", wmx);
+        if (wmx == 4) {
+            const int m4 = (int)((T + 127) / 128);
+            hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), s, a, nt, m4 * nt);
+        } else {
+            hipLaunchKernelGGL((wino_gemm_x3w_kernel<2, true>), dim3(mtiles * nt), dim3(256), x3w_lds_bytes(2, 2), s, a, nt, mtiles * nt);
+        }
+        return A3D_OK;
+    }
     if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
@@ -976,17 +1076,17 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
             const int wmx = wm_force ? wm_force : 4;
             static bool attr_set = false;
             if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
-                if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2)) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4)) != hipSuccess)
+                if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 3)) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 3)) != hipSuccess)
                     return A3D_ERR_LAUNCH;
                 attr_set = true;
             }
             a3d_note_variant("wino_gemm_x3w_kernel<%d>", wmx);
             if (wmx == 4) {
                 const int m4 = (int)((T + 127) / 128);
-                hipLaunchKernelGGL((wino_gemm_x3w_kernel<4>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4), s, a, nt, m4 * nt);
+                hipLaunchKernelGGL((wino_gemm_x3w_kernel<4>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 3), s, a, nt, m4 * nt);
             } else {
-                hipLaunchKernelGGL((wino_gemm_x3w_kernel<2>), dim3(mtiles * nt), dim3(256), x3w_lds_bytes(2), s, a, nt, mtiles * nt);
+                hipLaunchKernelGGL((wino_gemm_x3w_kernel<2>), dim3(mtiles * nt), dim3(256), x3w_lds_bytes(2, 3), s, a, nt, mtiles * nt);
             }
             return A3D_OK;
         }

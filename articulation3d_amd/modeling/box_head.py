@@ -39,7 +39,7 @@ class FastRCNNConvFCHead(nn.Module):
 
     def forward(self, x):
         """x: [rows, P, P, C] NHWC bins (or [rows, K]) -> [rows, FC_DIM]."""
-        x = x.reshape(x.shape[0], -1)
+        x = ops.keep_amax(x.reshape(x.shape[0], -1), x)  # (a view: the recorded per-ROI maxima stay valid)
         for fc in self.fcs:
             x = fc(x)
         return x

@@ -56,7 +56,7 @@ class PlaneRCNNConvFCHead(nn.Module):
     def _tower(self, x, convs, fcs):
         for layer in convs:
             x = layer(x, wino=True)  # fixed algorithm choice: the ROI count must not change a ROI's result
-        x = x.reshape(x.shape[0], -1)
+        x = ops.keep_amax(x.reshape(x.shape[0], -1), x)  # (a view: the recorded per-ROI maxima stay valid)
         for fc in fcs:
             x = head_fc(x, fc)
         return x

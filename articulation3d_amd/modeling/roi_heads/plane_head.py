@@ -58,7 +58,7 @@ class PlaneRCNNConvFCHead(nn.Module):
         """x: [rows,14,14,C] NHWC pooled features -> [rows, 3] unit normals."""
         for layer in self.conv_norm_relus:
             x = layer(x, wino=True)  # fixed algorithm choice: the ROI count must not change a ROI's result
-        x = x.reshape(x.shape[0], -1)
+        x = ops.keep_amax(x.reshape(x.shape[0], -1), x)  # (a view: the recorded per-ROI maxima stay valid)
         for fc in self.fcs:
             x = head_fc(x, fc)
         n = self.param_pred.out_features

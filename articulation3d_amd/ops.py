@@ -48,7 +48,7 @@ DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "2"))
 
 def H3_KINDS(p, wino_ok: bool, splitk: int) -> bool:
     """Layer kinds that have an fp16x2 kernel (the others keep bf16x3 inside mode 3)."""
-    return not wino_ok
+    return True  # (Winograd layers whose channel count the wide kernels' 128-wide tiles do not fit -- res2's 64 -> 64 -- run the direct form)
 
 
 def last_conv_variant() -> str:
@@ -97,6 +97,7 @@ class PackedConv:
     phase: int = 0  # 1..4: one output phase of a conv over a nearest-x2 upsampled input (see a3d_conv_desc.phase)
     presplit: bool = False  # set by the pack_* functions (module-cached weights): precision-2 launches may cache w_x3 below
     w_x3: Optional[torch.Tensor] = None  # [Kpad/16, 3, cols, 16] bf16 planes of w (a3d_conv_desc.w_x3), made at the first such use
+    w_wino_h2: Optional[torch.Tensor] = None  # [16, Cin/32, 2, cols, 32] fp16 planes of w_wino * its scale (precision 3)
     w_h2: Optional[torch.Tensor] = None  # [Kpad/16, 2, cols, 16] fp16 planes of w * w_scale (a3d_conv_desc.w_x3 at precision 3)
 
     @property
@@ -401,12 +402,26 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
-    use_wino = wino_ok and (precision == 0 or (precision == 2 and tune in (0, 8) and (Cin + Cin2) % 32 == 0))
+    use_wino = wino_ok and (precision == 0 or (precision in (2, 3) and tune in (0, 8) and (Cin + Cin2) % 32 == 0))
+    if use_wino and precision == 3 and -(-p.cols // 64) % 2:
+        use_wino = False  # (an explicit precision=3 on a layer the wide Winograd kernels do not tile: direct form)
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()
         if p.w_wino_cm is not None and d.precision == 0 and tune == 0:
             d.w_wino_cm = p.w_wino_cm.data_ptr()  # the library then takes the one-launch kernel where the layer qualifies
+        if d.precision == 3:  # the Winograd-domain filter as two fp16 planes, scaled by the power of two of ITS maximum
+            if getattr(p, "_u_scale", None) is None:
+                p._u_scale = _pow2_scale_host(float(p.w_wino.abs().max()))
+            d.w_scale = p._u_scale
+            if p.w_wino_h2 is None or p.w_wino_h2.device != p.w_wino.device:
+                rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
+                p.w_wino_h2 = torch.empty((16, cols // 32, 2, rows, 32), device=p.w_wino.device, dtype=torch.float16)
+                _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w_wino.data_ptr(), p.w_wino_h2.data_ptr(), 16, rows, cols, 32, p._u_scale, _stream()),
+                           "a3d_split_f16x2_chunk")
+                if not os.environ.get("A3D_NO_PUBLISH"):
+                    torch.cuda.current_stream().synchronize()
+            d.w_wino_x3 = p.w_wino_h2.data_ptr()
         if d.precision == 2:
             if p.w_wino_x3 is None or p.w_wino_x3.device != p.w_wino.device:  # once per layer
                 rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
