@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // during both their read phases: 58 % MFMA-busy measured.)
     auto step = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR], bf16x8 (&fa)[NP][TN], bf16x8 (&fb)[NP][TM],
                     bf16x8 (&fan)[NP][TN], bf16x8 (&fbn)[NP][TM]) {
-        if constexpr (F16) {  // three terms: l.h and h.l (the small ones) with the split of the staged chunk, then h.h with the reads / loads
-            X3_TERM(1, 0)
+        if constexpr (F16) {  // three terms in the wide kernel's order (h.h, h.l, l.h per accumulator: the two kernels agree bit for bit)
+            X3_TERM(0, 0)
             X3_TERM(0, 1)
             store_chunk(cur ^ 1, xs, ws);
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // <= 1 LDS write
             }
             __syncthreads();
-            X3_TERM(0, 0)
+            X3_TERM(1, 0)
             read_frags(cur ^ 1, fan, fbn);
             load_chunk(xs, ws);
 #pragma unroll

@@ -91,6 +91,10 @@ class PlaneRCNN(nn.Module):
         `cv2.resize(im, (640, 480))` + `im[:, :, ::-1]` (tools/inference.py:216-218) run fused with the normalisation in
         `a3d_preprocess_resize_u8`."""
         assert not self.training
+        if frames.is_cuda and ops.DEFAULT_PRECISION == 3:
+            # slots for the per-image maxima of this batch's activations (~200 feature maps + the per-ROI tensors), taken from a
+            # chunk that is zero-filled HERE, on the main stream, before anything forks
+            ops.amax_reserve(frames.shape[0] * (512 + 8 * int(self.proposal_generator.post_nms_topk[False])), frames.device)
         if source_rgb:
             assert frames.dtype == torch.uint8 and self.input_format == "BGR"
             B = frames.shape[0]

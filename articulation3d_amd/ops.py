@@ -29,21 +29,26 @@ fptr_t = C.c_void_p
 CONV_TIMING: Optional[list] = None
 
 # Arithmetic of conv2d() calls that do not ask for one (a3d_conv_desc.precision):
-#   2 = "bf16x3", THE DEFAULT since round 2: fp32-grade arithmetic on the bf16 matrix pipe.  Every fp32 operand is split exactly
-#       into three bf16 terms (x = hi + mid + lo, round-to-nearest at each level; bf16 x bf16 is exact in fp32) and six MFMAs
-#       per k step (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) accumulate in fp32: the dropped terms are <= 2^-24 relative,
-#       the rounding of one fp32 FMA.  Tensors, accumulation and every non-GEMM kernel stay fp32.  Measured error against float64
-#       is slightly BELOW the fp32 MFMA's on every layer shape (tools/x3_bench.py, tests: test_bf16x3_kernel_is_fp32_grade,
-#       test_winograd_split_operand_gemm_is_fp32_grade) and the WHOLE GPU suite -- oracle tolerances, golden fixtures, bit-exact
-#       discrete stages, end-to-end matched detections with the float64 yardstick -- passes under it (114 tests, round 2).
-#       Direct layers: csrc/conv_bf16x3.hip; Winograd layers: the split-operand 16-plane GEMM of csrc/conv_wino.hip.  gfx950's
-#       fp32-input MFMA runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 pipe) and, as the one-launch Winograd kernel's
-#       ablations showed, shares that datapath with the VALU; six bf16 MFMAs per step are 2.67x faster on paper, 1.2-1.6x delivered.
+#   3 = "fp16x2", THE DEFAULT (round 2, late): fp32-grade arithmetic on the 16-bit matrix pipe with THREE MFMAs per k step.  Every
+#       fp32 operand, scaled by a power of two s, is split in two fp16 terms (x * s = h + l: h carries 11 significant bits, l the
+#       next 11; an fp16 x fp16 product is exact in fp32) and h.h + h.l + l.h accumulate in fp32; the dropped l.l is <= 2^-22
+#       relative.  fp16 has 5 exponent bits, hence the scale: s puts the largest magnitude of the operand in [2^14, 2^15) -- per
+#       IMAGE (or ROI) for activations, taken from maxima that the producing kernel's epilogue records (`_a3d_amax`, amax_of below),
+#       so a frame's result never depends on the rest of its batch; once per layer for the filter.  Values down to 2^-18 of the
+#       image's maximum keep the full 22 bits, smaller ones an absolute 2^-40 of it.  Measured error against float64 is BELOW
+#       bf16x3's and the fp32 MFMA's on every layer shape, also with images 10^6 apart in magnitude in one batch
+#       (tools/x3_bench.py, tools/h2_check.py; tests test_fp16x2_*), and the whole GPU suite passes under it.
+#       Kernels: the bf16x3 ones with two operand planes (template flag F16 of conv_bf16x3.hip, conv_bf16x3_wide.hip and the wide
+#       Winograd GEMM of conv_wino.hip); 3x3 layers whose channel count the wide Winograd tiles do not fit run the direct form.
+#   2 = "bf16x3" (A3D_PRECISION=2 / bench.py --precision bf16x3), the default of round 2 until fp16x2: every fp32 operand split
+#       EXACTLY into three bf16 terms (no scale needed: bf16 has fp32's exponent range), six MFMAs per k step (hi.hi, hi.mid,
+#       mid.hi, mid.mid, hi.lo, lo.hi); the dropped terms are <= 2^-24 relative.  Error against float64 at or below the fp32
+#       MFMA's (test_bf16x3_kernel_is_fp32_grade, test_winograd_split_operand_gemm_is_fp32_grade).
 #   0 = fp32-input MFMA (A3D_PRECISION=0 / bench.py --precision fp32): the round-1 default, bit-compatible with it; the
-#       one-launch Winograd kernel (csrc/conv_wino_fused.hip) belongs to this mode.
+#       one-launch Winograd kernel (csrc/conv_wino_fused.hip) belongs to this mode.  gfx950's fp32-input MFMA runs at the fp32
+#       VECTOR rate (157 TFLOP/s, 1/16 of the 16-bit pipes) and shares that datapath with the VALU.
 #   1 = bf16 MFMA with fp32 accumulation on plain convolutions / linears: autocast-level error, opt-in, never a parity mode.
-#   3 = "fp16x2": fp32-grade products from a two-way fp16 split (x * s = h + l, s a power of two per image), THREE fp16 MFMAs per k step.
-DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "2"))
+DEFAULT_PRECISION = int(os.environ.get("A3D_PRECISION", "3"))
 
 
 def H3_KINDS(p, wino_ok: bool, splitk: int) -> bool:
@@ -260,10 +265,22 @@ AMAX_MISSES: Optional[list] = None  # debugging: install a list to record the te
 _amax_arena: dict = {}
 
 
+def amax_reserve(n: int, device) -> None:
+    """Make sure the current chunk has room for `n` more floats, allocating (and zero-filling, on the CURRENT stream) a new one if
+    not.  Called at the start of a batch, before any branch forks onto a side stream: every later slot of the batch then comes from
+    a chunk whose fill is ordered before all of the batch's launches on every stream."""
+    a = _amax_arena.get(device)
+    if a is None or a[1] + n > a[0].numel():
+        _amax_arena[device] = [torch.zeros(max(_AMAX_CHUNK, n), device=device, dtype=torch.float32), 0]
+
+
 def amax_slot(n: int, device) -> torch.Tensor:
     a = _amax_arena.get(device)
     if a is None or a[1] + n > a[0].numel():
-        a = _amax_arena[device] = [torch.zeros(max(_AMAX_CHUNK, n), device=device, dtype=torch.float32), 0]
+        amax_reserve(n, device)
+        a = _amax_arena[device]
+        if not os.environ.get("A3D_NO_PUBLISH"):
+            torch.cuda.current_stream().synchronize()  # (an unreserved refill: its fill must be visible to every stream)
     t = a[0][a[1]:a[1] + n]
     a[1] += (n + 3) // 4 * 4
     return t

@@ -60,10 +60,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-modes", action="store_true", help="skip the secondary timed loop in the other arithmetic (fp32-input MFMA)")
     ap.add_argument("--no-operating-points", action="store_true", help="skip the A / B / C operating points and the transfer-inclusive loop")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3", "fp16x2"],
-                    help="bf16x3 (default: fp32-grade products from exact 3-way bf16 operand splits on the bf16 MFMA, fp32 tensors and "
-                         "accumulation; the arithmetic the package and its parity suite run in), fp32 (fp32-input MFMA, the round-1 default) "
-                         "or bf16 (opt-in autocast arithmetic -- reported with its own dtype, not comparable)")
+    ap.add_argument("--precision", default="fp16x2", choices=["fp32", "bf16", "bf16x3", "fp16x2"],
+                    help="fp16x2 (default: fp32-grade products from a two-way fp16 split of each operand, scaled per image, three fp16 MFMAs "
+                         "per k step; fp32 tensors and accumulation; the arithmetic the package and its parity suite run in), bf16x3 (exact "
+                         "3-way bf16 splits, six MFMAs), fp32 (fp32-input MFMA, the round-1 default) or bf16 (opt-in autocast arithmetic "
+                         "-- reported with its own dtype, not comparable)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (test rigs with fewer GPUs than ranks)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="timed frames of the bounded CPU-baseline sample (~10-20 s of host work)")
     return ap.parse_args()
@@ -304,16 +305,17 @@ def main():
     # Secondary figure, same clip, same timing discipline: the other fp32-grade arithmetic (fp32-input MFMA when the headline runs
     # bf16x3, and vice versa).  Reported beside the headline, never as it.
     alt = None
-    if args.precision in ("fp32", "bf16x3") and not args.no_alt_modes:
-        other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-        saved = ops.DEFAULT_PRECISION
-        ops.DEFAULT_PRECISION = {"fp32": 0, "bf16x3": 2}[other]
-        try:
-            el, _ = timed(args.steps, max(1, min(args.warmup, 2)), step)
-        finally:
-            ops.DEFAULT_PRECISION = saved
-        alt = {other: {"value": round(B * world * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / args.steps, 3),
-                       "dtype": DTYPES[other], "note": "python bench.py --precision " + other}}
+    if args.precision in ("fp32", "bf16x3", "fp16x2") and not args.no_alt_modes:
+        alt = {}
+        for other in [m for m in ("bf16x3", "fp32", "fp16x2") if m != args.precision][:2]:
+            saved = ops.DEFAULT_PRECISION
+            ops.DEFAULT_PRECISION = {"fp32": 0, "bf16x3": 2, "fp16x2": 3}[other]
+            try:
+                el, _ = timed(max(2, args.steps // 2), max(1, min(args.warmup, 2)), step)
+            finally:
+                ops.DEFAULT_PRECISION = saved
+            alt[other] = {"value": round(B * world * max(2, args.steps // 2) / el, 2), "unit": "frames/s",
+                          "ms_per_step": round(1e3 * el / max(2, args.steps // 2), 3), "dtype": DTYPES[other], "note": "python bench.py --precision " + other}
 
     dets = out.rec_count.float().mean().item()
     raw = out.det.count.float().mean().item()
@@ -336,8 +338,9 @@ def main():
     roofline = {
         "kernel": dname, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None, "pipe": dpipe,
-        "flops_counted": "EXECUTED on the matrix pipe: bf16x3 issues SIX bf16 MFMA products per fp32 multiply-add (peak = dense bf16 MFMA); "
-                         "Winograd F(2x2,3x3) performs 16 multiply-adds per 2x2 output tile and channel pair where the direct form performs 36",
+        "flops_counted": "EXECUTED on the matrix pipe: fp16x2 issues THREE fp16 MFMA products per fp32 multiply-add, bf16x3 SIX bf16 ones (peak = "
+                         "the dense 16-bit MFMA rate, the same for fp16 and bf16); Winograd F(2x2,3x3) performs 16 multiply-adds per 2x2 output "
+                         "tile and channel pair where the direct form performs 36",
         "fp32_equivalent_tflops": round(dexec / dsec / 1e12, 2),
         "algorithmic_tflops": round(dflops / dsec / 1e12, 2), "algorithmic_speedup": round(dflops / dexec, 4) if dexec else None,
         "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed_fp32_equivalent": round(dexec / dn / 1e9, 3),

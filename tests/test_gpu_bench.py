@@ -102,7 +102,7 @@ def test_bench_single_rank_rccl_gather(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] <= 1.0
-    assert d["roofline"]["kernel"].startswith(("wino_", "conv_")) and d["roofline"]["pipe"] in ("bf16x6", "f32")
+    assert d["roofline"]["kernel"].startswith(("wino_", "conv_")) and d["roofline"]["pipe"] in ("f16x3", "bf16x6", "f32")
 
 
 def test_bench_default_line_has_the_contract_fields():
@@ -114,7 +114,7 @@ def test_bench_default_line_has_the_contract_fields():
         assert k in d, k
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["pipe"] == "bf16x6" and rf["peak"] == 2500.0 and d["dtype"].startswith("f32")
+    assert rf["pipe"] == "f16x3" and rf["peak"] == 2500.0 and d["dtype"].startswith("f32")
     assert rf["algorithmic_speedup"] >= 1.0
     assert set(d["operating_points"]) == {"A_thresh0.7", "B_thresh0.0", "C_given4"}
     assert d["operating_points"]["B_thresh0.0"]["detections_per_frame"] == 100.0

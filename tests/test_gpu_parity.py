@@ -177,14 +177,69 @@ def test_split_k_head_fc_in_the_split_operand_arithmetic(ops):
     pk = ops.pack_linear(w, b, None, ops.ACT_RELU)
     sk = ops.choose_splitk(300, pk.cols, K)
     assert sk == 32
-    y = ops.linear(x, pk, splitk=sk)
-    assert ops.last_conv_variant() == "conv_x3w_kernel sk32", ops.last_conv_variant()
     ref = F.relu(x.double().cpu() @ w.double().t() + b.double())
-    assert rel(y[:, :N].double(), ref) < 5e-6
+    for prec, name in ((3, "conv_h2w_kernel sk32"), (2, "conv_x3w_kernel sk32")):
+        y = ops.linear(x, pk, splitk=sk, precision=prec)
+        assert ops.last_conv_variant() == name, ops.last_conv_variant()
+        assert rel(y[:, :N].double(), ref) < 5e-6
+        few = ops.linear(x[:7].contiguous(), pk, splitk=sk, precision=prec)
+        assert torch.equal(few, y[:7])
     y0 = ops.linear(x, pk, splitk=sk, precision=0)  # the fp32-input MFMA split-K kernel: same slices, same order
     assert rel(y0[:, :N].double(), ref) < 5e-6
-    few = ops.linear(x[:7].contiguous(), pk, splitk=sk)
-    assert torch.equal(few, y[:7])
+
+
+H2_CASES = [  # B, H, W, Cin, Cout, k, stride, kwargs, expected kernel
+    (6, 30, 40, 256, 1024, 1, 1, {}, "conv_h2_kernel"),
+    (5, 30, 40, 1024, 256, 1, 1, {}, "conv_h2_kernel"),
+    (4, 61, 79, 128, 128, 3, 2, {}, "conv_h2_kernel"),           # taps, stride, ragged tiles
+    (3, 61, 79, 64, 64, 3, 1, {}, "conv_h2_kernel"),             # a 3x3 s1 layer the 128-wide Winograd tiles do not fit: direct form
+    (700, 1, 1, 4096, 1024, 1, 1, dict(tune=9, precision=3), "conv_h2w_kernel"),
+    (300, 1, 1, 16384, 1024, 1, 1, dict(splitk=32), "conv_h2w_kernel sk32"),
+    (5, 30, 40, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
+    (3, 61, 79, 128, 384, 3, 1, {}, "wino_gemm_h2w_kernel"),     # ragged tile / channel blocks
+    (70, 14, 14, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
+]
+
+
+@pytest.mark.parametrize("case", H2_CASES, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}->{c[4]}k{c[5]}s{c[6]}")
+def test_fp16x2_kernels_are_fp32_grade_batch_invariant_and_record_their_maxima(ops, case):
+    """The default arithmetic (a3d_conv_desc.precision == 3): x * s = h + l in fp16 with a power-of-two scale per image, three MFMAs
+    per k step.  With images 10^6 apart in magnitude in ONE batch: (1) every image's error against float64 is no larger than bf16x3's
+    (x 1.25) and fp32-grade in absolute terms; (2) an image's result does not depend on the rest of the batch (bitwise); (3) the
+    per-image output maxima the epilogue records for the next layer are exact."""
+    B, H, W, Cin, Cout, k, st, kw, kernel = case
+    torch.manual_seed(2)
+    x = torch.relu(torch.randn(B, H, W, Cin, device="cuda")) * torch.exp(1.5 * torch.randn(Cin, device="cuda")) \
+        * torch.logspace(-3, 3, B, device="cuda")[:, None, None, None]
+    w = torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5)
+    pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+    kw3 = dict(kw)
+    kw3.setdefault("precision", 3)
+    y = ops.conv2d(x, pk, **kw3)
+    assert ops.last_conv_variant().startswith(kernel), ops.last_conv_variant()
+    y2 = ops.conv2d(x, pk, **dict(kw, precision=2))
+    nb = min(B, 8)
+    sel = torch.linspace(0, B - 1, nb).long().cuda()  # (float64 reference on a spread of the images)
+    ref = F.relu(F.conv2d(x[sel].permute(0, 3, 1, 2).double(), w.double().cuda(), pk.shift[:Cout].double(), stride=st, padding=k // 2)).permute(0, 2, 3, 1)
+    err = lambda t: ((t[sel][..., :Cout].double() - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1))
+    e3, e2 = err(y), err(y2)
+    assert float(e3.max()) < 2e-6 and bool((e3 <= 1.25 * e2 + 1e-8).all()), (e3.tolist(), e2.tolist())
+    assert torch.equal(y._a3d_amax, y.abs().flatten(1).amax(1))
+    alone = ops.conv2d(x[B // 2:B // 2 + 1].contiguous(), pk, **kw3)
+    assert torch.equal(alone[0], y[B // 2])
+
+
+def test_fp16x2_wide_and_narrow_direct_kernels_agree_bit_for_bit(ops):
+    """conv_h2w_kernel (256 x 256 tiles, pre-split scaled filter by LDS-DMA) and conv_h2_kernel keep one operation order per output, as
+    their bf16x3 counterparts do: the launcher may choose by problem size."""
+    torch.manual_seed(4)
+    x = torch.randn(600, 1, 1, 2048, device="cuda") * torch.logspace(-2, 2, 600, device="cuda")[:, None, None, None]
+    pk = ops.pack_conv(torch.randn(512, 2048, 1, 1) / 45, torch.randn(512) * 0.1, None, 1, 0, ops.ACT_RELU)
+    wide = ops.conv2d(x, pk, precision=3, tune=9)
+    assert ops.last_conv_variant() == "conv_h2w_kernel", ops.last_conv_variant()
+    narrow = ops.conv2d(x, pk, precision=3, tune=8)
+    assert ops.last_conv_variant().startswith("conv_h2_kernel"), ops.last_conv_variant()
+    assert torch.equal(wide, narrow)
 
 
 def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
