@@ -420,8 +420,12 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
     use_wino = wino_ok and (precision == 0 or (precision in (2, 3) and tune in (0, 8) and (Cin + Cin2) % 32 == 0))
-    if use_wino and precision == 3 and -(-p.cols // 64) % 2:
-        use_wino = False  # (an explicit precision=3 on a layer the wide Winograd kernels do not tile: direct form)
+    if use_wino and precision == 3 and (-(-p.cols // 64) % 2 or (Cin + Cin2 < 256 and wino is None)):
+        # fp16x2: the direct form where the wide Winograd kernels' 128-channel tiles do not fit (res2's 64 -> 64) and for layers under
+        # 256 input channels -- with three MFMAs per k step the 16-plane round trip costs more than the 2.25x multiply-adds it saves
+        # (whole-layer times at 64 frames, tools/h2_wino_vs_direct.py: 60x80x128 -> 128 0.435 Winograd | 0.352 direct; p2 256 -> 256
+        # 3.99 | 4.85).  A function of the layer only.
+        use_wino = False
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()

@@ -196,7 +196,9 @@ H2_CASES = [  # B, H, W, Cin, Cout, k, stride, kwargs, expected kernel
     (700, 1, 1, 4096, 1024, 1, 1, dict(tune=9, precision=3), "conv_h2w_kernel"),
     (300, 1, 1, 16384, 1024, 1, 1, dict(splitk=32), "conv_h2w_kernel sk32"),
     (5, 30, 40, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
-    (3, 61, 79, 128, 384, 3, 1, {}, "wino_gemm_h2w_kernel"),     # ragged tile / channel blocks
+    (3, 61, 79, 256, 384, 3, 1, {}, "wino_gemm_h2w_kernel"),     # ragged tile / channel blocks
+    (3, 60, 80, 128, 128, 3, 1, {}, "conv_h2_kernel"),           # under 256 input channels: the direct form (ops.conv2d's rule)
+    (3, 60, 80, 128, 128, 3, 1, dict(wino=True), "wino_gemm_h2w_kernel"),
     (70, 14, 14, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
 ]
 

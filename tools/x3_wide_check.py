@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops  # noqa: E402
 
+PREC = int(os.environ.get("X3_PREC", "3"))  # 3 = fp16x2 (default), 2 = bf16x3
+
 SHAPES = [(64000, 1, 1, 12544, 1024, 1, 1), (64000, 1, 1, 1024, 1024, 1, 1), (64, 30, 40, 256, 1024, 1, 1), (64, 30, 40, 1024, 256, 1, 1),
           (64, 60, 80, 128, 512, 1, 1), (64, 120, 160, 256, 256, 1, 1), (64, 15, 20, 512, 2048, 1, 1), (64, 15, 20, 2048, 512, 1, 1),
           (64, 30, 40, 1024, 2048, 1, 2), (64, 120, 160, 64, 256, 1, 1), (64, 60, 80, 512, 1024, 1, 2)]
@@ -19,7 +21,7 @@ if len(sys.argv) > 1:
 def ms(x, pk, tune, res, reps=7):
     ops.CONV_TIMING = []
     for _ in range(reps):
-        ops.conv2d(x, pk, precision=2, tune=tune, res=res)
+        ops.conv2d(x, pk, precision=PREC, tune=tune, res=res)
     torch.cuda.synchronize()
     t, ops.CONV_TIMING = ops.CONV_TIMING, None
     g = sorted(a.elapsed_time(b) for (_n, _f, a, b, *_r) in t)
@@ -33,11 +35,11 @@ for B, H, W, Cin, Cout, k, st in SHAPES:
     pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
     Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
     res = torch.randn(B, Ho, Wo, pk.cols, device="cuda") if (Cout >= 4 * Cin or Cout == Cin) else None
-    y9 = ops.conv2d(x, pk, precision=2, tune=9, res=res)
+    y9 = ops.conv2d(x, pk, precision=PREC, tune=9, res=res)
     v9 = ops.last_conv_variant()
-    y8 = ops.conv2d(x, pk, precision=2, tune=8, res=res)
+    y8 = ops.conv2d(x, pk, precision=PREC, tune=8, res=res)
     v8 = ops.last_conv_variant()
-    y0 = ops.conv2d(x, pk, precision=2, res=res)
+    y0 = ops.conv2d(x, pk, precision=PREC, res=res)
     v0 = ops.last_conv_variant()
     same = torch.equal(y9, y8) and torch.equal(y0, y8)
     m9, m8 = ms(x, pk, 9, res), ms(x, pk, 8, res)

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops  # noqa: E402
 
+PREC = int(os.environ.get("X3_PREC", "3"))  # 3 = fp16x2 (default), 2 = bf16x3
+
 SHAPES = [(64, 120, 160, 256, 256), (64, 60, 80, 256, 256), (64, 60, 80, 128, 128), (64, 30, 40, 256, 256), (64, 15, 20, 512, 512),
           (64, 120, 160, 64, 64), (1600, 14, 14, 256, 256), (64, 120, 160, 256, 128)]
 if len(sys.argv) > 1:
@@ -17,7 +19,7 @@ if len(sys.argv) > 1:
 def gemm_ms(x, pk, tune, reps=10):
     ops.CONV_TIMING = []
     for _ in range(reps):
-        ops.conv2d(x, pk, precision=2, tune=tune)
+        ops.conv2d(x, pk, precision=PREC, tune=tune)
     torch.cuda.synchronize()
     t, ops.CONV_TIMING = ops.CONV_TIMING, None
     g = [a.elapsed_time(b) for (name, _, a, b, *_r) in t if name.startswith("wino_gemm")]
@@ -29,9 +31,9 @@ for B, H, W, Cin, Cout in SHAPES:
     x = torch.randn(B, H, W, Cin, device="cuda")
     w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
     pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_RELU)
-    y0 = ops.conv2d(x, pk, precision=2)
+    y0 = ops.conv2d(x, pk, precision=PREC)
     v0 = ops.last_conv_variant()
-    y8 = ops.conv2d(x, pk, precision=2, tune=8)
+    y8 = ops.conv2d(x, pk, precision=PREC, tune=8)
     v8 = ops.last_conv_variant()
     same = torch.equal(y0, y8)
     m0, _ = gemm_ms(x, pk, 0)
