@@ -48,6 +48,24 @@ DTYPES = {
 }
 
 
+def rocprof_name(variant: str) -> str:
+    """The dispatcher's variant label (a3d_last_conv_variant) -> the kernel instantiation as a rocprofv3 trace spells it.  The fp16x2
+    kernels are the F16 = true instantiations of the split-operand templates ("conv_h2_kernel<2>" = conv_x3_kernel<2, false, true>)."""
+    import re
+
+    v = variant.split(" sk")[0]
+    m = re.match(r"conv_(x3|h2)_kernel<(\d)>( stem)?$", v)
+    if m:
+        return f"conv_x3_kernel<{m.group(2)}, {'true' if m.group(3) else 'false'}, {'true' if m.group(1) == 'h2' else 'false'}>"
+    m = re.match(r"conv_(x3|h2)w_kernel$", v)
+    if m:
+        return f"conv_x3w_kernel<{'true' if m.group(1) == 'h2' else 'false'}>"
+    m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>$", v)
+    if m:
+        return f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if m.group(1) == 'h2' else 'false'}>"
+    return v
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +360,7 @@ def main():
                          "the dense 16-bit MFMA rate, the same for fp16 and bf16); Winograd F(2x2,3x3) performs 16 multiply-adds per 2x2 output "
                          "tile and channel pair where the direct form performs 36",
         "fp32_equivalent_tflops": round(dexec / dsec / 1e12, 2),
+        "fp32_equivalent_vs_fp32_mfma_peak": round(dexec / dsec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),  # (what the fp32-input MFMA could do at best)
         "algorithmic_tflops": round(dflops / dsec / 1e12, 2), "algorithmic_speedup": round(dflops / dexec, 4) if dexec else None,
         "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed_fp32_equivalent": round(dexec / dn / 1e9, 3),
         "avg_launch_gflop_algorithmic": round(dflops / dn / 1e9, 3), "share_of_step_time": round(dsec / elapsed, 3),
@@ -349,11 +368,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
-        # the dispatcher's variant name vs the rocprofv3 kernel name: "conv_x3_kernel<2>" <-> "conv_x3_kernel<2, false>"
-        norm = lambda n: n.replace(", false>", ">").replace(", true>", "> stem").replace(" ", "")
-        stem = dname.split("<")[0].split(" ")[0]
-        k = next((v for n, v in tr.get("kernels", {}).items() if norm(n) == norm(dname)), None) or \
-            next((v for n, v in tr.get("kernels", {}).items() if n.split("<")[0] == stem), None)
+        rname = rocprof_name(dname)
+        roofline["rocprof_name"] = rname
+        k = next((v for n, v in tr.get("kernels", {}).items() if n.replace(" ", "") == rname.replace(" ", "")), None)
         if k:
             roofline["traffic"] = k["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "committed " + os.path.relpath(tpath, ROOT) + ": separate rocprofv3 --pmc passes of this command, NOT measured in this run"

@@ -8,8 +8,8 @@ OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points"
 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-for MODE in bf16x3 fp32; do
-  SUF=""; [ $MODE = fp32 ] && SUF="_fp32"
+for MODE in fp16x2 bf16x3 fp32; do
+  SUF=""; [ $MODE = fp32 ] && SUF="_fp32"; [ $MODE = bf16x3 ] && SUF="_bf16x3"
   rm -rf $OUT/${TAG}_prof$SUF
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof$SUF --output-format csv -- python3 bench.py $ARGS --precision $MODE > $OUT/${TAG}_bench_prof$SUF.json 2> $OUT/${TAG}_prof$SUF.err
   python3 tools/summarize_rocprof.py $OUT/${TAG}_prof$SUF $OUT/${TAG}_bench_prof$SUF.json 10 3 $OUT/${TAG}_kernel_summary$SUF.md > /dev/null
@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $OUT/
 python3 tools/summarize_pmc_mfma.py $OUT/${TAG}_pmc_MFMA $OUT/${TAG}_prof 10 $OUT/${TAG}_pmc_mfma_kernels.json > $OUT/${TAG}_mfma.txt 2>&1
 # the raw counter CSVs are tens of MB: keep the summaries only
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_MFMA
-find $OUT/${TAG}_prof $OUT/${TAG}_prof_fp32 -name "*agent_info.csv" -delete 2>/dev/null
+find $OUT/${TAG}_prof $OUT/${TAG}_prof_fp32 $OUT/${TAG}_prof_bf16x3 -name "*agent_info.csv" -delete 2>/dev/null
 tail -3 $OUT/${TAG}_bench.json | cut -c1-600
 cat $OUT/${TAG}_traffic.txt | head -30
 cat $OUT/${TAG}_mfma.txt | head -20
