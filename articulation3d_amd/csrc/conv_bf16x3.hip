@@ -52,8 +52,12 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16
 // STEM: the 7x7 s2 p3 stem on the NHWC4 input (a3d_conv_desc.stem; w packed [Cout][7][8][4], Kpad = 224): a 16-deep chunk is 4
 // consecutive filter columns x 4 channels of one filter row, i.e. loader lane j = tid % 4 fetches pixel (ih0 + kh, iw0 + 4 (c & 1) + j)
 // whole -- the float4 it would fetch anyway -- with kh = c >> 1; validity is a row bit and a column-half bit instead of a tap bit.
-template <int TN, bool STEM = false, bool F16 = false>
+// WDMA (fp16x2 only): the filter arrives pre-split and scaled (a3d_conv_desc.w_x3 = a3d_split_f16x2_chunk(w, .., 16, w_scale)) and goes
+// global -> LDS by LDS-DMA instead of through registers: no weight loads into VGPRs, no split, no VGPR -> LDS stores for that operand
+// (with three MFMAs per step those were 10-17 % of the compute-bound layers: res4 1x1 1024 -> 256 0.159 -> 0.135 ms without them).
+template <int TN, bool STEM = false, bool F16 = false, bool WDMA = false>
 __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    static_assert(!WDMA || F16, "pre-split weights by DMA belong to the fp16x2 form");
     constexpr int TM = 2, BKT = 16;
     constexpr int NP = F16 ? 2 : 3;  // operand planes
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
@@ -123,6 +127,28 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
         const int n = n0 + lr + RPP * i;
         woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
     }
+    // WDMA: w_x3 [Kpad/16][2][Cout][16] fp16; one (chunk, plane) tile of this workgroup's BN rows is a contiguous run = BN / 32 DMA
+    // wave-instructions of 32 rows.  Lane i lands at LDS byte 16 i of its 1 KiB = row i/2, half i%2, and fetches the k half the image
+    // keeps there: half ^ ((row >> 3) & 1).  Rows past Cout read the next plane's rows / zeros: their accumulators are never stored.
+    const __amdgpu_buffer_rsrc_t rw2 = x3_rsrc(WDMA ? d.w_x3 : d.w, WDMA ? (unsigned)((size_t)nk * d.Cout * 64) : 16u);
+    const int wvoff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    int dma_c = 0;
+    auto dma_w = [&](const int buf) {
+        constexpr int NPC = 2 * (BN / 32);  // pieces per chunk
+        __bf16 *Wt = lds + buf * BUF + NP * PX;
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        const int base = __builtin_amdgcn_readfirstlane(dma_c * d.Cout * 64 + n0 * 32);
+#pragma unroll
+        for (int i = 0; i < (NPC + 3) / 4; ++i) {
+            const int j = uw * ((NPC + 3) / 4) + i;
+            if (j < NPC) {
+                const int p = j / (BN / 32), g = j % (BN / 32);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void *)(Wt + p * PW + g * 32 * LKB), 16, wvoff,
+                                                         base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + g * 1024), 0, 0);
+            }
+        }
+        ++dma_c;
+    };
     int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next chunk to load inside the filter
     // Two register staging sets: the loads of chunk c are issued at iteration c-3, split into LDS at iteration c-1 and
     // multiplied at iteration c, so a buffer load has two full iterations (2 x 6*TN*2 MFMAs per wave) to land.
@@ -136,8 +162,10 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             for (int i = 0; i < XR; ++i)
                 xs[i] = x3_load4(rx, ((vmask[i] >> skh) & (vmask[i] >> (8 + half)) & livebit) ? rowoff[i] + tapoff : -1, 0);
             const int soff = kc * (BKT * 4);
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+                for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+            }
             ++kc;
             return;
         }
@@ -149,8 +177,10 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
 #pragma unroll
         for (int i = 0; i < XR; ++i) xs[i] = x3_load4(r, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
         const int soff = kc * (BKT * 4);
+        if constexpr (!WDMA) {
 #pragma unroll
-        for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+            for (int i = 0; i < WR; ++i) ws[i] = x3_load4(rw, livebit ? woff[i] : -1, soff);
+        }
         ++kc;
         c0 += BKT;
         if (c0 >= CinT) {
@@ -173,13 +203,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 *reinterpret_cast<h16x4 *>(p) = h;
                 *reinterpret_cast<h16x4 *>(p + PX) = l;
             }
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int i = 0; i < WR; ++i) {
-                h16x4 h, l;
-                split2h(ws[i], sw, h, l);
-                _Float16 *p = reinterpret_cast<_Float16 *>(Wt) + (lr + RPP * i) * LKB + lcs;
-                *reinterpret_cast<h16x4 *>(p) = h;
-                *reinterpret_cast<h16x4 *>(p + PW) = l;
+                for (int i = 0; i < WR; ++i) {
+                    h16x4 h, l;
+                    split2h(ws[i], sw, h, l);
+                    _Float16 *p = reinterpret_cast<_Float16 *>(Wt) + (lr + RPP * i) * LKB + lcs;
+                    *reinterpret_cast<h16x4 *>(p) = h;
+                    *reinterpret_cast<h16x4 *>(p + PW) = l;
+                }
             }
             return;
         }
@@ -212,10 +244,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     a3d_stage_scale_shift(ss, d, n0, BN, tid);
+    if constexpr (WDMA) {
+        dma_w(0);  // chunks 0 and 1 of the filter
+        dma_w(1);
+    }
     load_chunk(xsA, wsA);  // chunk 0
     store_chunk(0, xsA, wsA);
     load_chunk(xsB, wsB);  // chunk 1
     load_chunk(xsA, wsA);  // chunk 2
+    if constexpr (WDMA) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 31;
@@ -260,9 +297,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // <= 8 VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // <= 1 LDS write
             }
+            // (WDMA: the filter DMA of chunk it+1 -- issued an iteration ago, before that iteration's XR activation loads -- has landed)
+            if constexpr (WDMA) __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();
             X3_TERM(1, 0)
             read_frags(cur ^ 1, fan, fbn);
+            if constexpr (WDMA) {
+                dma_w(cur);  // chunk it+2 into the stage whose fragments were read an iteration ago
+                __builtin_amdgcn_sched_barrier(0);
+            }
             load_chunk(xs, ws);
 #pragma unroll
             for (int g = 0; g < TN * TM; ++g) {
@@ -350,7 +393,10 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
     if (d->precision == 3) {
         a3d_note_variant(STEM ? "conv_h2_kernel<%d> stem" : "conv_h2_kernel<%d>", TN);
-        hipLaunchKernelGGL((conv_x3_kernel<TN, STEM, true>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+        if (d->w_x3 && (size_t)d->Cout * d->Kpad * 4 < ((size_t)1 << 31))
+            hipLaunchKernelGGL((conv_x3_kernel<TN, STEM, true, true>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+        else
+            hipLaunchKernelGGL((conv_x3_kernel<TN, STEM, true, false>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
         return;
     }
     a3d_note_variant(STEM ? "conv_x3_kernel<%d> stem" : "conv_x3_kernel<%d>", TN);

@@ -215,7 +215,7 @@ def pack_stem(weight: torch.Tensor, bn, device="cuda") -> PackedConv:
     w[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
     scale, shift = fold_bn(*[t.detach().float() for t in bn[:4]], bn[4])
     return PackedConv(w.reshape(Cout, 224).contiguous().to(device), scale.contiguous().to(device),
-                      shift.contiguous().to(device), 7, 7, 2, 3, 4, Cout, 224, ACT_RELU, stem=True)
+                      shift.contiguous().to(device), 7, 7, 2, 3, 4, Cout, 224, ACT_RELU, stem=True, presplit=True)
 
 
 def pack_linear(weight: torch.Tensor, bias=None, chw: Optional[Tuple[int, int, int]] = None, act=ACT_NONE,
@@ -241,7 +241,7 @@ def pack_deconv2x2(weight: torch.Tensor, bias, act=ACT_RELU, device="cuda") -> P
     w = weight.detach().float().permute(2, 3, 1, 0).reshape(4 * Cout, Cin)  # [(dy,dx,co), ci]
     shift = bias.detach().float().repeat(4)
     return PackedConv(w.contiguous().to(device), None, shift.contiguous().to(device), 1, 1, 1, 0, Cin, 4 * Cout, Cin,
-                      act, pixshuf=True)
+                      act, pixshuf=True, presplit=True)
 
 
 def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], device="cuda") -> PackedConv:
@@ -250,7 +250,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
     K = w.shape[1]
     w = _pad_rows(w)
     b = _pad_rows(b)
-    return PackedConv(w.contiguous().to(device), None, b.contiguous().to(device), 1, 1, 1, 0, K, w.shape[0], K, ACT_NONE)
+    return PackedConv(w.contiguous().to(device), None, b.contiguous().to(device), 1, 1, 1, 0, K, w.shape[0], K, ACT_NONE, presplit=True)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -453,8 +453,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                 if not os.environ.get("A3D_NO_PUBLISH"):
                     torch.cuda.current_stream().synchronize()
             d.w_wino_x3 = p.w_wino_x3.data_ptr()
-    if (d.precision == 3 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
-            and not (p.stem or p.pixshuf)):
+    if d.precision == 3 and not use_wino and p.presplit and p.Kpad % 16 == 0:
+        # every direct fp16x2 launch of a module-cached layer streams its filter pre-split by LDS-DMA (narrow and wide kernels alike)
         if p.w_h2 is None or p.w_h2.device != p.w.device:  # the fp16x2 planes of the filter, scaled by w_scale (once per packed layer)
             p.w_h2 = torch.empty((p.Kpad // 16, 2, p.w.shape[0], 16), device=p.w.device, dtype=torch.float16)
             _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w.data_ptr(), p.w_h2.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, d.w_scale, _stream()),

@@ -219,7 +219,7 @@ def test_fp16x2_kernels_are_fp32_grade_batch_invariant_and_record_their_maxima(o
     kw3.setdefault("precision", 3)
     y = ops.conv2d(x, pk, **kw3)
     assert ops.last_conv_variant().startswith(kernel), ops.last_conv_variant()
-    y2 = ops.conv2d(x, pk, **dict(kw, precision=2))
+    y2 = ops.conv2d(x, pk, **dict(kw, precision=2, wino=kernel.startswith("wino")))  # bf16x3 in the same (Winograd / direct) form
     nb = min(B, 8)
     sel = torch.linspace(0, B - 1, nb).long().cuda()  # (float64 reference on a spread of the images)
     ref = F.relu(F.conv2d(x[sel].permute(0, 3, 1, 2).double(), w.double().cuda(), pk.shift[:Cout].double(), stride=st, padding=k // 2)).permute(0, 2, 3, 1)
