@@ -50,13 +50,14 @@ DTYPES = {
 
 def rocprof_name(variant: str) -> str:
     """The dispatcher's variant label (a3d_last_conv_variant) -> the kernel instantiation as a rocprofv3 trace spells it.  The fp16x2
-    kernels are the F16 = true instantiations of the split-operand templates ("conv_h2_kernel<2>" = conv_x3_kernel<2, false, true>)."""
+    kernels are the F16 = true instantiations of the split-operand templates ("conv_h2_kernel<2>" = conv_x3_kernel<2, false, true, true>)."""
     import re
 
     v = variant.split(" sk")[0]
     m = re.match(r"conv_(x3|h2)_kernel<(\d)>( stem)?$", v)
     if m:
-        return f"conv_x3_kernel<{m.group(2)}, {'true' if m.group(3) else 'false'}, {'true' if m.group(1) == 'h2' else 'false'}>"
+        h2 = "true" if m.group(1) == "h2" else "false"  # (F16, and WDMA: module-cached filters arrive pre-split by LDS-DMA)
+        return f"conv_x3_kernel<{m.group(2)}, {'true' if m.group(3) else 'false'}, {h2}, {h2}>"
     m = re.match(r"conv_(x3|h2)w_kernel$", v)
     if m:
         return f"conv_x3w_kernel<{'true' if m.group(1) == 'h2' else 'false'}>"
