@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
         const int bimg = mok ? m / hwo : 0;  // image / ROI of this lane's output pixel
         float vmax = 0.f;
         if (mok) {
-        const float unscale = F16 ? 1.f / (a3d_in_scale(d, bimg) * sw) : 1.f;
+        // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
+        const float unx = F16 ? 1.f / a3d_in_scale(d, bimg) : 1.f, unw = F16 ? 1.f / sw : 1.f;
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
-                if constexpr (F16) v = v * unscale;  // exact: a power of two
+                if constexpr (F16) v = (v * unx) * unw;  // exact: powers of two
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
                 vmax = fmaxf(vmax, a3d_absmax4(v));
                 store_out(d, v, m, n, b, oh, ow);

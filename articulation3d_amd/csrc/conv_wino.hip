@@ -875,7 +875,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const int bimg = tok ? t / (a.Ty * a.Tx) : 0;  // all four outputs of a tile belong to one image
     float vmax = 0.f;
     if (tok) {
-    const float unscale = F16 ? 1.f / (wino_v_scale(a, bimg) * a.w_scale) : 1.f;
+    // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
+    const float unx = F16 ? 1.f / wino_v_scale(a, bimg) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;
     const int tx = t % a.Tx;
     const int r = t / a.Tx;
     const int ty = r % a.Ty, b = r / a.Ty;
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 const int n = n0 + nl;
                 if (n >= a.Cout) continue;
                 f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
-                if constexpr (F16) v = v * unscale;  // exact: a power of two
+                if constexpr (F16) v = (v * unx) * unw;  // exact: powers of two
                 const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);

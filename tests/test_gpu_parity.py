@@ -231,6 +231,45 @@ def test_fp16x2_kernels_are_fp32_grade_batch_invariant_and_record_their_maxima(o
     assert torch.equal(alone[0], y[B // 2])
 
 
+def test_fp16x2_scaling_edge_cases(ops):
+    """The per-image power-of-two scale at its limits: an all-zero image (scale 1, output = the shift), images at 1e-30 and 1e+30
+    (fp16's range is 6e-8 .. 6.5e4: without the scale both would vanish / overflow), and one outlier 10^5 x the rest of its image
+    (the rest sits below 2^-16 of the maximum: still far inside the 2^-18 the two planes keep at full precision)."""
+    torch.manual_seed(6)
+    B, H, W, Cin, Cout = 5, 30, 40, 256, 256
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    x[0] = 0.0
+    x[1] *= 1e-30
+    x[2] *= 1e30
+    x[3, 7, 9, 11] = 3e5
+    w = torch.randn(Cout, Cin, 1, 1) / 16
+    pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, 1, 0, ops.ACT_NONE)
+    y = ops.conv2d(x, pk, precision=3)
+    assert ops.last_conv_variant().startswith("conv_h2_kernel")
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double().cuda(), pk.shift[:Cout].double()).permute(0, 2, 3, 1)
+    assert torch.equal(y[0], pk.shift[None, None, :].expand(H, W, -1))  # zero image: exactly the shift
+    for b in (1, 2, 4):
+        e = float((y[b].double() - ref[b]).norm() / ref[b].norm())
+        assert e < 1e-6, (b, e)
+    # the outlier image: every pixel but the outlier's keeps fp32-grade relative accuracy
+    m = torch.ones(H, W, dtype=torch.bool, device="cuda")
+    m[7, 9] = False
+    e = float((y[3][m].double() - ref[3][m]).norm() / ref[3][m].norm())
+    assert e < 1e-6, e
+    assert bool(torch.isfinite(y).all())
+    # a Winograd layer with the same extremes
+    w3 = torch.randn(Cout, Cin, 3, 3) / 48
+    pk3 = ops.pack_conv(w3, None, None, 1, 1, ops.ACT_NONE)
+    y3 = ops.conv2d(x, pk3, precision=3)
+    assert ops.last_conv_variant().startswith("wino_gemm_h2w_kernel")
+    ref3 = F.conv2d(x.permute(0, 3, 1, 2).double(), w3.double().cuda(), padding=1).permute(0, 2, 3, 1)
+    assert float(y3[0].abs().max()) == 0.0
+    for b in (1, 2, 4):
+        e = float((y3[b].double() - ref3[b]).norm() / ref3[b].norm())
+        assert e < 2e-6, (b, e)
+    assert bool(torch.isfinite(y3).all())
+
+
 def test_fp16x2_wide_and_narrow_direct_kernels_agree_bit_for_bit(ops):
     """conv_h2w_kernel (256 x 256 tiles, pre-split scaled filter by LDS-DMA) and conv_h2_kernel keep one operation order per output, as
     their bf16x3 counterparts do: the launcher may choose by problem size."""
