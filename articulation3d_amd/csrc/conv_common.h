@@ -99,7 +99,7 @@ __device__ __forceinline__ void store_out(const a3d_conv_desc &d, f32x4 v, int m
 // power of two s with amax * s in [2^14, 2^15)  (amax == 0 or not finite -> 1)
 __device__ __forceinline__ float a3d_pow2_scale(const float amax) {
     if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
-    return ldexpf(1.f, 14 - ilogbf(amax));
+    return ldexpf(1.f, min(14 - ilogbf(amax), 126));  // (amax below 2^-112: the largest finite power of two that keeps 1 / s normal)
 }
 // scale of the rows of input image b (both sources of a channel concat share it)
 __device__ __forceinline__ float a3d_in_scale(const a3d_conv_desc &d, const int b) {

@@ -106,7 +106,7 @@ typedef _Float16 wh16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float wino_v_scale(const WinoArgs &a, const int b) {
     float m = a.in_amax[b];
     if (a.in_amax2) m = fmaxf(m, a.in_amax2[b]);
-    return a3d_pow2_scale(4.f * m);
+    return 0.25f * a3d_pow2_scale(m);  // (4 m itself could overflow)
 }
 
 template <int TN, int BKT>
