@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     constexpr int XR = BM / RPP, WR = BN / RPP;
     constexpr int PX = BM * LKB, PW = BN * LKB;    // one operand plane
     constexpr int BUF = NP * (PX + PW);
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+    // WDMA: THREE filter stages (the third one behind the two operand stages): the DMA of chunk c+3 is issued while chunk c is being
+    // multiplied, two iterations before its fragments are read -- with one iteration of lead (~0.6 us here) the wait before the
+    // barrier sat on L2 latency every time (40 % of the wave-cycles parked, PMC)
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF + (WDMA ? NP * PW : 0)];
+    auto wstage = [&](const int st) -> __bf16 * { return st < 2 ? lds + st * BUF + NP * PX : lds + 2 * BUF; };
     __shared__ __attribute__((aligned(16))) float ss[2 * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,14 +137,17 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     const __amdgpu_buffer_rsrc_t rw2 = x3_rsrc(WDMA ? d.w_x3 : d.w, WDMA ? (unsigned)((size_t)nk * d.Cout * 64) : 16u);
     const int wvoff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
     int dma_c = 0;
-    auto dma_w = [&](const int buf) {
-        constexpr int NPC = 2 * (BN / 32);  // pieces per chunk
-        __bf16 *Wt = lds + buf * BUF + NP * PX;
+    constexpr int NPC = 2 * (BN / 32);      // DMA pieces per chunk
+    constexpr int DPWN = (NPC + 3) / 4;      // ... and per wave
+    int wst_dma = 0, wst_rd = 0;             // filter stage the next DMA goes to / the next fragment read comes from (chunk % 3)
+    auto dma_w = [&]() {
+        __bf16 *Wt = wstage(wst_dma);
+        wst_dma = wst_dma == 2 ? 0 : wst_dma + 1;
         const int uw = __builtin_amdgcn_readfirstlane(wave);
         const int base = __builtin_amdgcn_readfirstlane(dma_c * d.Cout * 64 + n0 * 32);
 #pragma unroll
-        for (int i = 0; i < (NPC + 3) / 4; ++i) {
-            const int j = uw * ((NPC + 3) / 4) + i;
+        for (int i = 0; i < DPWN; ++i) {
+            const int j = uw * DPWN + i;
             if (j < NPC) {
                 const int p = j / (BN / 32), g = j % (BN / 32);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void *)(Wt + p * PW + g * 32 * LKB), 16, wvoff,
@@ -245,8 +252,9 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
 
     a3d_stage_scale_shift(ss, d, n0, BN, tid);
     if constexpr (WDMA) {
-        dma_w(0);  // chunks 0 and 1 of the filter
-        dma_w(1);
+        dma_w();  // chunks 0, 1 and 2 of the filter
+        dma_w();
+        dma_w();
     }
     load_chunk(xsA, wsA);  // chunk 0
     store_chunk(0, xsA, wsA);
@@ -262,7 +270,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     bf16x8 fa0[NP][TN], fb0[NP][TM], fa1[NP][TN], fb1[NP][TM];
     auto read_frags = [&](int buf, bf16x8 (&fa)[NP][TN], bf16x8 (&fb)[NP][TM]) {
         const __bf16 *X = lds + buf * BUF + (wm * TM * 32) * LKB + frag_off;
-        const __bf16 *Wt = lds + buf * BUF + NP * PX + (wn * TN * 32) * LKB + frag_off;
+        const __bf16 *Wt = (WDMA ? wstage(wst_rd) : lds + buf * BUF + NP * PX) + (wn * TN * 32) * LKB + frag_off;
+        if constexpr (WDMA) wst_rd = wst_rd == 2 ? 0 : wst_rd + 1;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -297,13 +306,17 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // <= 8 VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // <= 1 LDS write
             }
-            // (WDMA: the filter DMA of chunk it+1 -- issued an iteration ago, before that iteration's XR activation loads -- has landed)
-            if constexpr (WDMA) __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // (WDMA: the filter DMA of chunk it+1 has landed -- issued two iterations ago; younger than it are that iteration's XR
+            // activation loads and the last iteration's DMA + loads)
+            if constexpr (WDMA) {
+                if constexpr (DPWN == 2) __asm__ volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else __asm__ volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            }
             __syncthreads();
             X3_TERM(1, 0)
             read_frags(cur ^ 1, fan, fbn);
             if constexpr (WDMA) {
-                dma_w(cur);  // chunk it+2 into the stage whose fragments were read an iteration ago
+                dma_w();  // chunk it+3 into the stage whose fragments were read an iteration ago
                 __builtin_amdgcn_sched_barrier(0);
             }
             load_chunk(xs, ws);

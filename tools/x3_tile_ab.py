@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops  # noqa: E402
 
+PREC = int(os.environ.get("X3_PREC", "3"))
+
 SHAPES = [(64, 120, 160, 64, 256, 1, 1, 1), (64, 120, 160, 64, 256, 1, 1, 0), (64, 60, 80, 128, 512, 1, 1, 1), (64, 120, 160, 256, 256, 1, 1, 0),
           (64, 30, 40, 256, 1024, 1, 1, 1), (64, 60, 80, 512, 128, 1, 1, 0), (64, 30, 40, 1024, 256, 1, 1, 0)]
 if len(sys.argv) > 1:
@@ -19,11 +21,11 @@ for B, H, W, Cin, Cout, k, st, has_res in SHAPES:
     res = torch.randn(B, Ho, Wo, pk.cols, device="cuda") if has_res else None
     out = []
     for tune in (10, 11):
-        y = ops.conv2d(x, pk, precision=2, tune=tune, res=res)
+        y = ops.conv2d(x, pk, precision=PREC, tune=tune, res=res)
         v = ops.last_conv_variant()
         ops.CONV_TIMING = []
         for _ in range(7):
-            ops.conv2d(x, pk, precision=2, tune=tune, res=res)
+            ops.conv2d(x, pk, precision=PREC, tune=tune, res=res)
         torch.cuda.synchronize()
         t, ops.CONV_TIMING = ops.CONV_TIMING, None
         g = sorted(a.elapsed_time(b) for (_n, _f, a, b, *_r) in t)
