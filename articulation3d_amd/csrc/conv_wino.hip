@@ -1037,8 +1037,11 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         if (wm_force3 < 0) wm_force3 = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
         const int nt = (d->Cout + X3W_BN - 1) / X3W_BN;
         const long blocks4 = (long)((T + 127) / 128) * nt;
-        // 128-tile blocks (one 512-thread workgroup per CU) once they fill the chip; below that 64-tile blocks, two per CU
-        const int wmx = wm_force3 ? wm_force3 : (blocks4 >= 192 ? 4 : 2);
+        // 64-tile blocks, two independent 256-thread workgroups per CU (with two operand planes the stage is 24 KiB: their barriers
+        // decouple), except where the 128-tile blocks finish in ONE round of the chip (small maps, a few hundred ROIs).  Measured
+        // (ms, 64-tile | 128-tile): p2 256 -> 256 2.67 | 2.66, 60x80x256 0.73 | 0.75, 30x40x256 0.26 | 0.29, 15x20x512 0.25 | 0.24,
+        // 276 ROIs 0.20 | 0.19.  Same kernel template, same operation order: bit-identical.
+        const int wmx = wm_force3 ? wm_force3 : (blocks4 <= 256 ? 4 : 2);
         static bool attr3 = false;
         if (!attr3) {
             if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||
