@@ -129,8 +129,8 @@ class PlaneRCNN(nn.Module):
         self.roi_heads.start_row_count(det)
         if self.depth_head_on and B <= self.small_batch_overlap and frames.is_cuda:
             # Small batches leave most of the 256 CUs idle (a 30x40 level is 10 tiles): the depth decoder runs on a second HIP
-            # stream beside the ROI branch: +14% frames/s at 1-4 frames, +8% at 8, +4% at 16.  At 64 frames it is +1.7% and is
-            # left off so that the per-kernel durations of the headline run are those of kernels running alone.
+            # stream beside the ROI branch: +14% frames/s at 1-4 frames, +8% at 8, +4% at 16, +2.9% at 64 (fp16x2: a few hundred ROIs
+            # are one partial round of the chip per head layer, and the decoder's tails fill it).
             main = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream()
@@ -216,7 +216,8 @@ class PlaneRCNN(nn.Module):
             self.load_state_dict(self._trainer.export_state_dict(), strict=False)
         return super().train(mode)
 
-    small_batch_overlap = int(os.environ.get("A3D_DEPTH_OVERLAP", "16"))  # batches up to this size run the depth decoder on a second HIP stream (0 disables)
+    # batches up to this size run the depth decoder on a second HIP stream beside the ROI branch (0 disables: every kernel then runs alone)
+    small_batch_overlap = int(os.environ.get("A3D_DEPTH_OVERLAP", "64"))
     fast_reference_path = True  # route uniform batches of the reference-signature call through inference_batched
 
     def _fast_path_ok(self, batched_inputs, do_postprocess) -> bool:

@@ -14,6 +14,10 @@ for MODE in fp16x2 bf16x3 fp32; do
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof$SUF --output-format csv -- python3 bench.py $ARGS --precision $MODE > $OUT/${TAG}_bench_prof$SUF.json 2> $OUT/${TAG}_prof$SUF.err
   python3 tools/summarize_rocprof.py $OUT/${TAG}_prof$SUF $OUT/${TAG}_bench_prof$SUF.json 10 3 $OUT/${TAG}_kernel_summary$SUF.md > /dev/null
 done
+# the default arithmetic once more with the depth decoder NOT on its own stream: every kernel has the chip alone
+rm -rf $OUT/${TAG}_prof_alone
+A3D_DEPTH_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_alone --output-format csv -- python3 bench.py $ARGS > $OUT/${TAG}_bench_prof_alone.json 2> $OUT/${TAG}_prof_alone.err
+python3 tools/summarize_rocprof.py $OUT/${TAG}_prof_alone $OUT/${TAG}_bench_prof_alone.json 10 3 $OUT/${TAG}_kernel_summary_alone.md > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_$C
   rocprofv3 --pmc $C -d $OUT/${TAG}_pmc_$C --output-format csv -- python3 bench.py $ARGS > $OUT/${TAG}_bench_pmc_$C.json 2> $OUT/${TAG}_pmc_$C.err
@@ -24,7 +28,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $OUT/
 python3 tools/summarize_pmc_mfma.py $OUT/${TAG}_pmc_MFMA $OUT/${TAG}_prof 10 $OUT/${TAG}_pmc_mfma_kernels.json > $OUT/${TAG}_mfma.txt 2>&1
 # the raw counter CSVs are tens of MB: keep the summaries only
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_MFMA
-find $OUT/${TAG}_prof $OUT/${TAG}_prof_fp32 $OUT/${TAG}_prof_bf16x3 -name "*agent_info.csv" -delete 2>/dev/null
+find $OUT/${TAG}_prof $OUT/${TAG}_prof_fp32 $OUT/${TAG}_prof_bf16x3 $OUT/${TAG}_prof_alone -name "*agent_info.csv" -delete 2>/dev/null
 tail -3 $OUT/${TAG}_bench.json | cut -c1-600
 cat $OUT/${TAG}_traffic.txt | head -30
 cat $OUT/${TAG}_mfma.txt | head -20
