@@ -10,6 +10,7 @@ so their pooled tensors are identical: they are pooled once and shared (the refe
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -25,6 +26,9 @@ from ..mask_head import build_mask_head
 from ..poolers import ROIPooler
 from .axis_head import build_axis_head
 from .plane_head import build_plane_head
+
+# heads run as concurrent branches when the batch holds at most this many ROI rows in total (schedule only: same bits)
+HEADS_CONCURRENT_ROWS = int(os.environ.get("A3D_HEADS_CONCURRENT_ROWS", "1024"))
 
 
 class BatchedDetections:
@@ -117,7 +121,8 @@ class PlaneRCNNROIHeads(nn.Module):
         same_pool = self.plane_on and self.axis_on and self._same_pooler(self.plane_pooler, self.axis_pooler)
         pool = lambda p: p.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
         shared = pool(self.plane_pooler) if self.plane_on else None
-        # the three heads are independent: concurrent branches for 1-2 frame batches (streams.py)
+        # the three heads are independent: concurrent branches for 1-2 frame batches (streams.py), and for any batch whose
+        # heads are single-round launches (few ROIs: each conv fills a fraction of the chip; measured +0.6% on the 64-frame clip)
         names, fns = [], []
         if self.mask_on:
             names.append("mask")
@@ -128,7 +133,7 @@ class PlaneRCNNROIHeads(nn.Module):
         if self.axis_on:
             names.append("axis")
             fns.append(lambda: self.axis_head.forward_rows(shared if same_pool else pool(self.axis_pooler)))
-        concurrent = det.boxes.is_cuda and det.boxes.shape[0] <= SMALL_BATCH
+        concurrent = det.boxes.is_cuda and (det.boxes.shape[0] <= SMALL_BATCH or rows <= HEADS_CONCURRENT_ROWS)
         # plane and axis heads read the same pooled tensor: their first 3x3 layers share one Winograd input transform
         with ops.share_wino_input([shared] if same_pool and not concurrent and shared.is_cuda else []):
             outs = dict(zip(names, run_branches(fns, concurrent=concurrent)))
