@@ -12,6 +12,13 @@
 // (one workgroup per ROI x slice, then bins from LDS) ran the 7x7 box pooler in 3.07 ms per 32 frames
 // against 1.93 ms for this direct form: proposal windows are only ~100 cells, so the extra workgroups,
 // barrier and 12-wave occupancy cost more than the duplicate corner reads that L2 already absorbs.
+//
+// Round-2 counters of the 7x7 box pooler at 64 x 1000 boxes (tools/pmc_roi.sh, gpurun_out -> DESIGN.md 5a): 27.8 M wave loads =
+// 31.6 GB of L1 accesses, 12.2 GB requested from L2 (L1 hit rate 0.57), 4.1 GB missing L2 (hit rate 0.73), mean L2 read latency
+// 345 cycles, TA busy 0.53, the L1 in "pending miss" stall 0.65 of the time; 21 waves per CU.  No unit is saturated: the
+// one-load-at-a-time walk and the batched walk now run in the same time (2.59 ms before the spatial order, 2.39 with it), and
+// giving each wave its own contiguous run of bins instead of every fourth bin was slower (2.52 ms: the four waves of a
+// workgroup no longer share their neighbouring cells in L1).
 #include "a3d_common.h"
 #ifndef A3D_ROI_NC
 #define A3D_ROI_NC 9

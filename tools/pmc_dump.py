@@ -1,4 +1,4 @@
-"""Sums rocprofv3 --pmc counter CSVs per kernel (last dispatch of each kernel name).  python3 tools/pmc_dump.py <dir> [substr]"""
+"""Sums rocprofv3 --pmc counter CSVs per kernel (last dispatch of each kernel name).  python3 tools/pmc_dump.py <dir> [substr] [dispatch index]"""
 import collections
 import csv
 import glob
@@ -6,6 +6,7 @@ import sys
 
 d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
+idx = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 acc = collections.defaultdict(dict)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -15,4 +16,4 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
 for k, v in acc.items():
     print(k)
     for c, vals in sorted(v.items()):
-        print(f"   {c:32s} last={vals[-1]:.4g}  n={len(vals)}")
+        print(f"   {c:32s} last={vals[idx]:.4g}  n={len(vals)}")
