@@ -18,6 +18,7 @@
 // 48-byte row pitch: a fragment is ONE ds_read_b128 and 16 rows tile the 64 banks exactly once), double-buffered,
 // one barrier per chunk; 6 x TN x 2 MFMAs per wave per chunk against (TN + 2) x 3 fragment reads.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -361,6 +362,74 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
 
     const bool has_res = d.res != nullptr;
     const int hwo = d.Ho * d.Wo;
+    // Row-major epilogue.  The MFMA leaves a lane with ONE pixel and register quads of 4 channels: stored as they are, a wave
+    // instruction touches 32 rows x 32 bytes (64 separate 16-byte requests, and the same again for the residual).  Each 32 x 32 tile
+    // therefore goes through 4 KiB of LDS (quad index XOR-swizzled with the row: conflict-free both ways) and comes back with 8 lanes
+    // per row: a wave instruction then covers 8 rows x 128 contiguous bytes (res2 1x1 64 -> 256 + residual: 0.79 -> 0.61 ms).  Same
+    // values, same operations per element: the stored bits do not change.  No barrier: behind the last chunk's barrier every
+    // fragment a wave still multiplies is in registers, and the only later LDS traffic (fragment reads of a chunk that does not
+    // exist, filter DMAs past the last chunk) reads garbage nobody uses or lands in the FILTER areas -- the tiles go through the two
+    // ACTIVATION areas (a barrier + vmcnt(0) here cost the compute-bound layers 15 %).  Scattering stores (phase / pixel shuffle /
+    // gate) keep the direct form; tune 12 forces it (A/B, bit-equality test).
+    if (!(d.phase || d.pixshuf || d.gate) && d.tune != 12) {
+        static_assert(NP * PX * 2 >= 8192, "two 4 KiB tiles per activation area");
+        float *T = reinterpret_cast<float *>(lds + (wave >> 1) * BUF) + (wave & 1) * 1024;
+        const int pr = lane & 31, ph = lane >> 5;
+        const int qr = lane >> 3, qc = lane & 7;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int mb = m0 + (wm * TM + mi) * 32;
+            const int mp = mb + pr;
+            const float unx = (F16 && mp < M) ? 1.f / a3d_in_scale(d, mp / hwo) : 1.f, unw = F16 ? 1.f / sw : 1.f;
+            float vmax[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                    if constexpr (F16) v = (v * unx) * unw;  // exact: powers of two
+                    *reinterpret_cast<f32x4 *>(T + pr * 32 + (((rg * 2 + ph) ^ (pr & 7)) << 2)) = v;
+                }
+                const int nl = (wn * TN + ni) * 32 + qc * 4;
+                const int n = n0 + nl;
+                const bool nok = n < d.Cout;
+                f32x4 rv[4], tv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = qr + 8 * j;
+                    tv[j] = *reinterpret_cast<const f32x4 *>(T + q * 32 + ((qc ^ (q & 7)) << 2));
+                    const int m = mb + q;
+                    if (has_res && nok && m < M) {
+                        size_t res_row;
+                        int b, oh, ow;
+                        out_rows(d, m, res_row, b, oh, ow);
+                        rv[j] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + n);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = mb + qr + 8 * j;
+                    if (!nok || m >= M) continue;
+                    const f32x4 v = a3d_epilogue_math(d, tv[j], *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[j]);
+                    vmax[j] = fmaxf(vmax[j], a3d_absmax4(v));
+                    *reinterpret_cast<f32x4 *>(d.y + (size_t)m * d.Cout + n) = v;
+                }
+            }
+            if (d.y_amax) {
+                const int mlast = min(mb + 31, M - 1);
+                if (mb < M && mb / hwo == mlast / hwo) {  // the tile's rows belong to one image (uniform per wave): one reduction
+                    a3d_note_amax(d.y_amax, mb / hwo, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mb + qr + 8 * j;
+                        a3d_note_amax(d.y_amax, m < M ? m / hwo : 0, vmax[j], m < M);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
@@ -418,7 +487,15 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
 }
 }  // namespace
 
-int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s) {
+int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
+    static const bool direct_epilogue = [] { const char *e = getenv("A3D_X3_DIRECT_EPILOGUE"); return e && e[0] == '1'; }();  // A/B runs
+    a3d_conv_desc dd;
+    const a3d_conv_desc *d = d0;
+    if (direct_epilogue && d0->tune == 0) {
+        dd = *d0;
+        dd.tune = 12;
+        d = &dd;
+    }
     if (d->precision == 3 && (!d->in_amax || !(d->w_scale > 0.f))) return A3D_ERR_ARG;
     const int rw = a3d_conv_launch_bf16x3_wide(d, s);  // wide and large layers with pre-split weights (bit-identical results)
     if (rw != A3D_ERR_UNSUPPORTED) return rw;

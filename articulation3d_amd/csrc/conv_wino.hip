@@ -870,32 +870,53 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 #undef X3W_MFMA
 #undef X3W_FENCE
 
-    const int t = t0 + wm * 32 + (lane & 31);
-    const bool tok = t < a.T;
-    const int bimg = tok ? t / (a.Ty * a.Tx) : 0;  // all four outputs of a tile belong to one image
-    float vmax = 0.f;
-    if (tok) {
+    // Row-major epilogue (as conv_x3_kernel's): a lane holds one TILE and register quads of 4 channels, i.e. a store instruction would
+    // touch 32 pixels x 32 bytes.  Every 32-tile x 32-channel block of an output position goes through 4 KiB of LDS and comes back
+    // with 8 lanes per tile: 8 pixels x 128 contiguous bytes per instruction.  Same values and operations per element.  No barrier:
+    // behind the last barrier every fragment still to be multiplied is in registers; the late weight DMAs land in the FILTER areas
+    // and the tiles use the two stages' V areas (WM waves x 4 KiB each).
+    static_assert(NP * PLX * 2 >= WM * 4096, "WM 4 KiB tiles per V area");
+    float *Tt = reinterpret_cast<float *>(lds + (wave / WM) * BUF) + (wave % WM) * 1024;
+    const int tb = t0 + wm * 32;
+    const int pr = lane & 31, ph = lane >> 5, qr = lane >> 3, qc = lane & 7;
+    const int tyx = a.Ty * a.Tx;
     // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
-    const float unx = F16 ? 1.f / wino_v_scale(a, bimg) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;
-    const int tx = t % a.Tx;
-    const int r = t / a.Tx;
-    const int ty = r % a.Ty, b = r / a.Ty;
+    const float unx = (F16 && tb + pr < a.T) ? 1.f / wino_v_scale(a, (tb + pr) / tyx) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;
+    int jb[4], jy[4], jx[4];  // image / first output row / first output column of the tile this lane stores in pass j (-1: none)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = tb + qr + 8 * j;
+        const int r = t / a.Tx;
+        jx[j] = 2 * (t - r * a.Tx);
+        jy[j] = 2 * (r % a.Ty);
+        jb[j] = t < a.T ? r / a.Ty : -1;
+    }
+    float vmax[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ij = 0; ij < 4; ++ij) {
-        const int oy = 2 * ty + (ij >> 1), ox = 2 * tx + (ij & 1);
-        if (oy >= a.Hl || ox >= a.Wl) continue;
-        const size_t ooff = (((size_t)b * a.Hl + oy) * a.Wl + ox) * a.Cout;
-        float *orow = a.y + ooff;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int nl = wn * 64 + ni * 32 + rg * 8 + (lane >> 5) * 4;
-                const int n = n0 + nl;
-                if (n >= a.Cout) continue;
                 f32x4 v = {yy[ij][ni][rg * 4 + 0], yy[ij][ni][rg * 4 + 1], yy[ij][ni][rg * 4 + 2], yy[ij][ni][rg * 4 + 3]};
                 if constexpr (F16) v = (v * unx) * unw;  // exact: powers of two
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
+                *reinterpret_cast<f32x4 *>(Tt + pr * 32 + (((rg * 2 + ph) ^ (pr & 7)) << 2)) = v;
+            }
+            const int nl = wn * 64 + ni * 32 + qc * 4;
+            const int n = n0 + nl;
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + nl), sh = *reinterpret_cast<const f32x4 *>(ss + BN + nl);
+            f32x4 tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = qr + 8 * j;
+                tv[j] = *reinterpret_cast<const f32x4 *>(Tt + q * 32 + ((qc ^ (q & 7)) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = jy[j] + (ij >> 1), ox = jx[j] + (ij & 1);
+                if (jb[j] < 0 || oy >= a.Hl || ox >= a.Wl || n >= a.Cout) continue;
+                const size_t ooff = (((size_t)jb[j] * a.Hl + oy) * a.Wl + ox) * a.Cout + n;
+                f32x4 v = tv[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
                 if (a.act == A3D_ACT_RELU) {
@@ -904,16 +925,23 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
                 }
                 if (a.gate) {
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff + n);
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff);
                     for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
                 }
-                vmax = fmaxf(vmax, a3d_absmax4(v));
-                *reinterpret_cast<f32x4 *>(orow + n) = v;
+                vmax[j] = fmaxf(vmax[j], a3d_absmax4(v));
+                *reinterpret_cast<f32x4 *>(a.y + ooff) = v;
             }
         }
     }
+    if (a.y_amax) {
+        const int tl = min(tb + 31, a.T - 1);
+        if (tb < a.T && tb / tyx == tl / tyx) {  // the wave's 32 tiles belong to one image: one reduction
+            a3d_note_amax(a.y_amax, tb / tyx, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a3d_note_amax(a.y_amax, max(jb[j], 0), vmax[j], jb[j] >= 0);
+        }
     }
-    if (a.y_amax) a3d_note_amax(a.y_amax, bimg, vmax, tok);  // (every lane of the wave gets here)
 }
 // src [outer][rows][cols] fp32 -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly: the chunk-major
 // plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops  # noqa: E402
 
 PREC = int(os.environ.get("X3_PREC", "3"))
+TUNES = tuple(int(v) for v in os.environ.get("X3_TUNES", "10,11").split(","))  # (12 = direct epilogue, 0 = the dispatcher's choice)
 
 SHAPES = [(64, 120, 160, 64, 256, 1, 1, 1), (64, 120, 160, 64, 256, 1, 1, 0), (64, 60, 80, 128, 512, 1, 1, 1), (64, 120, 160, 256, 256, 1, 1, 0),
           (64, 30, 40, 256, 1024, 1, 1, 1), (64, 60, 80, 512, 128, 1, 1, 0), (64, 30, 40, 1024, 256, 1, 1, 0)]
@@ -20,7 +21,7 @@ for B, H, W, Cin, Cout, k, st, has_res in SHAPES:
     Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
     res = torch.randn(B, Ho, Wo, pk.cols, device="cuda") if has_res else None
     out = []
-    for tune in (10, 11):
+    for tune in TUNES:
         y = ops.conv2d(x, pk, precision=PREC, tune=tune, res=res)
         v = ops.last_conv_variant()
         ops.CONV_TIMING = []
