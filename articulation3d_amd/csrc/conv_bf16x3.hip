@@ -369,9 +369,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // values, same operations per element: the stored bits do not change.  No barrier: behind the last chunk's barrier every
     // fragment a wave still multiplies is in registers, and the only later LDS traffic (fragment reads of a chunk that does not
     // exist, filter DMAs past the last chunk) reads garbage nobody uses or lands in the FILTER areas -- the tiles go through the two
-    // ACTIVATION areas (a barrier + vmcnt(0) here cost the compute-bound layers 15 %).  Scattering stores (phase / pixel shuffle /
-    // gate) keep the direct form; tune 12 forces it (A/B, bit-equality test).
-    if (!(d.phase || d.pixshuf || d.gate) && d.tune != 12) {
+    // ACTIVATION areas.  Pixel-shuffle and gated stores keep the direct form; tune 12 forces it (A/B, bit-equality test).
+    if (!(d.pixshuf || d.gate) && d.tune != 12) {
         static_assert(NP * PX * 2 >= 8192, "two 4 KiB tiles per activation area");
         float *T = reinterpret_cast<float *>(lds + (wave >> 1) * BUF) + (wave & 1) * 1024;
         const int pr = lane & 31, ph = lane >> 5;
@@ -412,7 +411,13 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                     if (!nok || m >= M) continue;
                     const f32x4 v = a3d_epilogue_math(d, tv[j], *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[j]);
                     vmax[j] = fmaxf(vmax[j], a3d_absmax4(v));
-                    *reinterpret_cast<f32x4 *>(d.y + (size_t)m * d.Cout + n) = v;
+                    size_t orow = (size_t)m;
+                    if (d.phase) {  // output phase (dy, dx) of an upsampled 3x3 conv: pixel (2 oh + dy, 2 ow + dx) of the 2x map
+                        const int b = m / hwo, r = m - b * hwo;
+                        const int oh = r / d.Wo, ow = r - oh * d.Wo;
+                        orow = ((size_t)b * (2 * d.Ho) + (2 * oh + ((d.phase - 1) >> 1))) * (size_t)(2 * d.Wo) + (2 * ow + ((d.phase - 1) & 1));
+                    }
+                    *reinterpret_cast<f32x4 *>(d.y + orow * d.Cout + n) = v;
                 }
             }
             if (d.y_amax) {

@@ -283,6 +283,34 @@ def test_fp16x2_wide_and_narrow_direct_kernels_agree_bit_for_bit(ops):
     assert torch.equal(wide, narrow)
 
 
+@pytest.mark.parametrize("precision", [3, 2])
+def test_row_major_and_direct_epilogues_store_the_same_bits(ops, precision):
+    """The split-operand kernels pass their output tiles through LDS so that a store covers 8 rows x 128 B; tune 12 keeps the direct
+    per-lane stores.  Same value per element either way -- residual, upsampled residual, ragged row / channel counts, several images
+    per tile (per-image maxima), two filter taps widths."""
+    torch.manual_seed(9)
+    cases = [  # B, H, W, Cin, Cout, k, stride, residual kind
+        (3, 23, 31, 64, 256, 1, 1, "same"), (2, 30, 40, 512, 256, 1, 1, "ups"), (37, 3, 3, 128, 96, 3, 1, None),
+        (2, 24, 40, 64, 64, 3, 1, None), (2, 31, 17, 256, 512, 1, 2, None), (5, 9, 7, 32, 132, 1, 1, "same")]
+    for B, H, W, Cin, Cout, k, st, rk in cases:
+        x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+        pk = ops.pack_conv(torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5), torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+        Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+        kw = {}
+        if rk == "same":
+            kw["res"] = torch.randn(B, Ho, Wo, pk.cols, device="cuda")
+        elif rk == "ups":
+            kw["res"], kw["res_ups"] = torch.randn(B, Ho // 2, Wo // 2, pk.cols, device="cuda"), True
+        b = ops.conv2d(x, pk, precision=precision, tune=12, **kw)
+        assert ops.last_conv_variant().startswith(("conv_h2_kernel", "conv_x3_kernel")), ops.last_conv_variant()
+        for tune in (10, 11):  # 128 x 64 and 128 x 128 tiles
+            a = ops.conv2d(x, pk, precision=precision, tune=tune, **kw)
+            assert ops.last_conv_variant().startswith(("conv_h2_kernel", "conv_x3_kernel")), ops.last_conv_variant()
+            assert torch.equal(a, b), (B, H, W, Cin, Cout, k, st, rk, tune)
+            if precision == 3:
+                assert torch.equal(ops.amax_of(a), ops.amax_of(b))
+
+
 def test_detector_results_do_not_depend_on_winograd_input_sharing(ops, hip_model, oracle):
     model = hip_model
     model.roi_heads.box_predictor.test_score_thresh = 0.3

@@ -16,4 +16,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
 for k, v in acc.items():
     print(k)
     for c, vals in sorted(v.items()):
-        print(f"   {c:32s} last={vals[idx]:.4g}  n={len(vals)}")
+        if idx == -2:
+            print(f"   {c:32s} " + " ".join(f"{v:.4g}" for v in vals))
+        else:
+            print(f"   {c:32s} last={vals[idx]:.4g}  n={len(vals)}")
