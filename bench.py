@@ -376,9 +376,10 @@ def main():
             roofline["traffic"] = k["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "committed " + os.path.relpath(tpath, ROOT) + ": separate rocprofv3 --pmc passes of this command, NOT measured in this run"
     if getattr(model, "small_batch_overlap", 0) >= B:
-        roofline["overlap_note"] = ("the depth decoder runs on a second HIP stream beside the ROI branch (A3D_DEPTH_OVERLAP): launch durations of those "
-                                    "two branches are those of kernels SHARING the chip, so per-kernel rates here are lower bounds; kernels alone: "
-                                    "A3D_DEPTH_OVERLAP=0, profiles/r02_kernel_summary_alone.md")
+        roofline["overlap_note"] = ("the depth decoder runs on a second HIP stream beside the ROI branch (A3D_DEPTH_OVERLAP) and the ROI heads run as "
+                                    "concurrent branches while the batch holds <= 1024 ROI rows (A3D_HEADS_CONCURRENT_ROWS): launch durations of those "
+                                    "branches are those of kernels SHARING the chip, so per-kernel rates here are lower bounds; kernels alone: "
+                                    "A3D_DEPTH_OVERLAP=0 A3D_HEADS_CONCURRENT_ROWS=0, profiles/r02_kernel_summary_alone.md")
     roofline["all_conv_kernels"] = {k: {"pipe": v[4], "fp32_equivalent_tflops": round(v[3] / v[1] / 1e12, 2) if v[3] else 0.0,
                                         "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None,
                                         "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),

@@ -14,9 +14,9 @@ for MODE in fp16x2 bf16x3 fp32; do
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof$SUF --output-format csv -- python3 bench.py $ARGS --precision $MODE > $OUT/${TAG}_bench_prof$SUF.json 2> $OUT/${TAG}_prof$SUF.err
   python3 tools/summarize_rocprof.py $OUT/${TAG}_prof$SUF $OUT/${TAG}_bench_prof$SUF.json 10 3 $OUT/${TAG}_kernel_summary$SUF.md > /dev/null
 done
-# the default arithmetic once more with the depth decoder NOT on its own stream: every kernel has the chip alone
+# the default arithmetic once more with the depth decoder and the ROI heads NOT on their own streams: every kernel has the chip alone
 rm -rf $OUT/${TAG}_prof_alone
-A3D_DEPTH_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_alone --output-format csv -- python3 bench.py $ARGS > $OUT/${TAG}_bench_prof_alone.json 2> $OUT/${TAG}_prof_alone.err
+A3D_DEPTH_OVERLAP=0 A3D_HEADS_CONCURRENT_ROWS=0 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_alone --output-format csv -- python3 bench.py $ARGS > $OUT/${TAG}_bench_prof_alone.json 2> $OUT/${TAG}_prof_alone.err
 python3 tools/summarize_rocprof.py $OUT/${TAG}_prof_alone $OUT/${TAG}_bench_prof_alone.json 10 3 $OUT/${TAG}_kernel_summary_alone.md > /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_$C
