@@ -263,12 +263,16 @@ __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandArgs 
 template <int CAP>
 __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                          const int *__restrict__ g_n, int *__restrict__ g_keep,
-                                                         float thr, u64 *__restrict__ gmask, const int have_mask) {
+                                                         float thr, u64 *__restrict__ gmask, const int have_mask, const int inner) {
     constexpr int W = CAP / 64;  // suppression words per row
     __shared__ u64 smask[CAP == 1024 ? 1024 * 16 : 1];
     __shared__ f32x4 sb[CAP];
     __shared__ unsigned char sv[CAP];
-    const int g = blockIdx.x;
+    // One workgroup per CU (144 KiB of LDS), so 64 frames x 5 levels = 320 groups take two rounds of the chip.  Groups are g = image *
+    // inner + level; walking them level-major puts the 1000-box levels in the first round and leaves the coarsest level's short
+    // groups (240 anchors) for the second one instead of a random fifth of everything.
+    const int nimg = gridDim.x / inner;
+    const int g = (blockIdx.x % nimg) * inner + blockIdx.x / nimg;
     u64 *mask = (CAP == 1024) ? smask : gmask + (size_t)g * CAP * W;
     const int n = min(g_n[g], CAP);
     for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
@@ -515,13 +519,13 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     a3d_begin();
     if (cap == GROUP_CAP) {
         hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(d->L, d->B), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0);
+        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0, d->L);
         hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     } else {
         hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(d->L, d->B), dim3(1024), 0, s, a);
         hipLaunchKernelGGL(nms_mask_kernel, dim3(G, 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
-        hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask, 1);
+        hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask, 1, d->L);
         hipLaunchKernelGGL((merge_topk_kernel<2048, 16384>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     }
@@ -559,7 +563,7 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
     a.g_n = gb.n;
     a3d_begin();
     hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0);
+    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0, d->C);
     hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
                        d->topk, d->out_boxes, d->out_scores, d->out_classes, d->out_pos, d->out_count);
     return a3d_check_launch();
@@ -571,6 +575,6 @@ extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int
     if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
     a3d_begin();
     hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
-                       g_keep, thresh, nullptr, 0);
+                       g_keep, thresh, nullptr, 0, 1);
     return a3d_check_launch();
 }
