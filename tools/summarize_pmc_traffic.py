@@ -69,7 +69,8 @@ def main():
         "group_nms_kernel": {"note": "latency-bound LDS kernel: <= 1024 boxes x 16 B per group, 128 KiB of suppression words stay in LDS",
                              "read_bytes": int(B * 5 * 1024 * 24)},
     }
-    want = {k for k, v in timed.items() if sum(x[1] for x in v) >= 0.01 * grand} | {k for k in timed if k in algo}
+    algo_of = lambda k: next((v for a, v in algo.items() if k == a or k.startswith(a + "<")), None)  # (template arguments stay in the base name)
+    want = {k for k, v in timed.items() if sum(x[1] for x in v) >= 0.01 * grand} | {k for k in timed if algo_of(k)}
     res = {}
     for k in sorted(want, key=lambda k: -sum(x[1] for x in timed[k])):
         n = len(timed[k])
@@ -81,8 +82,8 @@ def main():
         e = {"launches_per_step": n / steps, "avg_launch_us": round(dur * 1e6, 2), "share_of_step": round(sum(x[1] for x in timed[k]) / grand, 4),
              "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "hbm_bytes_per_launch": round(fb + wb),
              "achieved_GBps": round((fb + wb) / dur / 1e9, 1), "counter_launches_averaged": min(len(f), len(w))}
-        if k in algo:
-            e["algorithmic"] = algo[k]
+        if algo_of(k):
+            e["algorithmic"] = algo_of(k)
         res[k] = e
     ra = res.get("roi_align_fpn_kernel")
     if ra:
