@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("in_amax2", fptr),
         ("y_amax", fptr),
         ("w_scale", C.c_float),
+        ("wino_m", fptr),
     ]
 
 
@@ -187,6 +188,7 @@ SIGNATURES = {
     "a3d_preprocess_resize_u8": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "a3d_wino_m_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),

@@ -523,6 +523,10 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
     if (d->tune == 10) launch_x3<1>(d, s);  // (tune 10 / 11: explicit tile width, A/B runs)
     else if (d->tune == 11) launch_x3<2>(d, s);
     else if (d->Cout <= 64 || (d->precision == 2 && n128 <= 500)) launch_x3<1>(d, s);  // (fp16x2: the 128-wide tile also on small grids,
-    else launch_x3<2>(d, s);                                                             //  measured 10-30 % faster there; same bits)
+    // measured 10-30 % faster there; same bits) -- except tiny grids with deep reductions (single frames: the launch is one
+    // partial round whose length is the k loop's, and the 64-wide tile's iteration is shorter: 1x30x40 1024 -> 256 43 -> 34 us,
+    // 1x15x20 2048 -> 512 84 -> 69 us, 4x30x40 1024 -> 256 48 -> 43 us; shallow layers stay: 1x60x80 128 -> 512 23 | 26 us)
+    else if (d->precision == 3 && n128 <= 96 && d->Kpad >= 512) launch_x3<1>(d, s);
+    else launch_x3<2>(d, s);
     return a3d_check_launch();
 }

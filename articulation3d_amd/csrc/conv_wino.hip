@@ -98,6 +98,7 @@ struct WinoArgs {
     float *y_amax;       // optional [B]: raised to max |y[b]| (a3d_conv_desc.y_amax)
     const float *in_amax, *in_amax2;  // precision 3: per-image maxima of the conv input(s)
     float w_scale;                    // precision 3: scale of the pre-split filter planes in U3
+    float *M;                         // plane-split form: [16][T][Cout] per-plane products (a3d_conv_desc.wino_m)
 };
 
 typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
@@ -559,7 +560,10 @@ constexpr int x3w_lds_bytes(int WM, int NP) { return 2 * x3w_buf(WM, NP) * 2 + 2
 // workgroup per CU (every 64-tile block streams all of U3 -- 6 B per weight -- from L2: 30 GB per p2 layer; 128-tile blocks halve it)
 // F16: the fp16x2 arithmetic (a3d_conv_desc.precision == 3): two operand planes, three product terms per step; V rows are scaled by the
 // power of two of 4 x their image's input maximum (|B^T d B| <= 4 max |d|), U3 holds the filter pre-split by a3d_split_f16x2_chunk.
-template <int WM, bool F16 = false>
+// PS (plane-split, small problems): blockIdx.y = Winograd plane; the workgroup runs that plane's k loop only and stores the raw product
+// tile to a.M [16][T][Cout]; wino_fold_kernel then folds the 16 planes in the same order and applies the same epilogue.  A problem of
+// a few tile blocks otherwise occupies a few CUs for 16 x C/32 latency-bound iterations (a single 30x40 frame: 6 workgroups, 116 us).
+template <int WM, bool F16 = false, bool PS = false>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
     constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
@@ -581,6 +585,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const unsigned vbytes = (unsigned)(vplane * 4);
     const int KC = a.C / BKT;
     const int NIT = 16 * KC;
+    const int pf = PS ? (int)blockIdx.y : 0;   // plane of a plane-split workgroup
+    const int nit = PS ? KC : NIT;             // chunks this workgroup multiplies
 
     int xoff[XR];
     float sxr[XR];  // fp16x2: scale of each loader row (tile) = that of its image
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const __amdgpu_buffer_rsrc_t ru = wuni_rsrc(a.U3, (unsigned)((size_t)16 * a.Cout * a.C * 2 * NP));
     const int wvoff = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
     const int u3tile = a.Cout * 64;  // bytes of one (f, chunk, plane) tile
-    int dma_c = 0;                   // flat (f, kc) index of the next weight chunk to fetch
+    int dma_c = pf * KC;             // flat (f, kc) index of the next weight chunk to fetch
     auto dma_w = [&](const int buf) {
         // 24 instructions per chunk: instruction j = plane j/8, row group j%8
         __bf16 *Wt = lds + buf * BUF + NP * PLX;
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         ++dma_c;
     };
     f32x4 xsA[XR], xsB[XR];
-    int ld_f = 0, ld_kc = 0;
+    int ld_f = pf, ld_kc = 0;
     auto load_chunk = [&](f32x4 (&xs)[XR]) {
         const int f = min(ld_f, 15);
         const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(a.V + (size_t)f * vplane, vbytes);
@@ -845,23 +851,27 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     X3W_FENCE
 
     int cf = 0, ckc = 0;
-    for (int it = 0; it < NIT; it += 2) {
+    for (int it = 0; it < nit; it += 2) {
         step0(0, F0, F1, xsB);
         __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");  // all but the two youngest (V loads): the weight DMA of chunk it+1 has landed
         __syncthreads();
         step1(0, F1, F0, xsB);
-        if (++ckc == KC) {
-            ckc = 0;
-            fold(mf, cf++);
+        if constexpr (!PS) {
+            if (++ckc == KC) {
+                ckc = 0;
+                fold(mf, cf++);
+            }
         }
         X3W_FENCE
         step0(1, F0, F1, xsA);
         __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __syncthreads();
         step1(1, F1, F0, xsA);
-        if (++ckc == KC) {
-            ckc = 0;
-            fold(mf, cf++);
+        if constexpr (!PS) {
+            if (++ckc == KC) {
+                ckc = 0;
+                fold(mf, cf++);
+            }
         }
         X3W_FENCE
     }
@@ -879,6 +889,25 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     float *Tt = reinterpret_cast<float *>(lds + (wave / WM) * BUF) + (wave % WM) * 1024;
     const int tb = t0 + wm * 32;
     const int pr = lane & 31, ph = lane >> 5, qr = lane >> 3, qc = lane & 7;
+    if constexpr (PS) {  // the raw plane product, row-major: M[pf][tile][channel]
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 v = {mf[ni][rg * 4 + 0], mf[ni][rg * 4 + 1], mf[ni][rg * 4 + 2], mf[ni][rg * 4 + 3]};
+                *reinterpret_cast<f32x4 *>(Tt + pr * 32 + (((rg * 2 + ph) ^ (pr & 7)) << 2)) = v;
+            }
+            const int n = n0 + wn * 64 + ni * 32 + qc * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = qr + 8 * j;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(Tt + q * 32 + ((qc ^ (q & 7)) << 2));
+                const int t = tb + q;
+                if (t < a.T && n < a.Cout) *reinterpret_cast<f32x4 *>(a.M + ((size_t)pf * a.T + t) * a.Cout + n) = v;
+            }
+        }
+        return;
+    }
     const int tyx = a.Ty * a.Tx;
     // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
     const float unx = (F16 && tb + pr < a.T) ? 1.f / wino_v_scale(a, (tb + pr) / tyx) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;
@@ -942,6 +971,64 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             for (int j = 0; j < 4; ++j) a3d_note_amax(a.y_amax, max(jb[j], 0), vmax[j], jb[j] >= 0);
         }
     }
+}
+// Second launch of the plane-split form: one thread = (tile, channel quad).  The 16 plane products are folded with the SAME
+// fused multiply-adds, in the same order, as wino_gemm_x3w_kernel's fold(), then the same epilogue: bit-identical output.
+__global__ __launch_bounds__(256) void wino_fold_kernel(const WinoArgs a) {
+    const int C4 = a.Cout >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = idx < (size_t)a.T * C4;
+    const int t = ok ? (int)(idx / C4) : 0;
+    const int n = ok ? (int)(idx - (size_t)t * C4) * 4 : 0;
+    const int tyx = a.Ty * a.Tx;
+    const int bimg = t / tyx;
+    float vmax = 0.f;
+    if (ok) {
+        f32x4 yy[4];
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) yy[ij] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(a.M + ((size_t)f * a.T + t) * a.Cout + n);
+            const int u = f >> 2, v = f & 3;
+            const float au0 = (u < 3) ? 1.f : 0.f, au1 = (u == 0) ? 0.f : ((u == 1) ? 1.f : -1.f);
+            const float av0 = (v < 3) ? 1.f : 0.f, av1 = (v == 0) ? 0.f : ((v == 1) ? 1.f : -1.f);
+            const float c00 = au0 * av0, c01 = au0 * av1, c10 = au1 * av0, c11 = au1 * av1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                yy[0][k] = __builtin_fmaf(c00, x[k], yy[0][k]);
+                yy[1][k] = __builtin_fmaf(c01, x[k], yy[1][k]);
+                yy[2][k] = __builtin_fmaf(c10, x[k], yy[2][k]);
+                yy[3][k] = __builtin_fmaf(c11, x[k], yy[3][k]);
+            }
+        }
+        const float unx = 1.f / wino_v_scale(a, bimg), unw = 1.f / a.w_scale;
+        const int r = t / a.Tx;
+        const int ox0 = 2 * (t - r * a.Tx), oy0 = 2 * (r % a.Ty);
+        const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4 *>(a.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const int oy = oy0 + (ij >> 1), ox = ox0 + (ij & 1);
+            if (oy >= a.Hl || ox >= a.Wl) continue;
+            const size_t ooff = (((size_t)bimg * a.Hl + oy) * a.Wl + ox) * a.Cout + n;
+            f32x4 v = (yy[ij] * unx) * unw;  // exact: powers of two
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+            if (a.act == A3D_ACT_RELU) {
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            } else if (a.act == A3D_ACT_LEAKY) {
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
+            }
+            if (a.gate) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff);
+                for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
+            }
+            vmax = fmaxf(vmax, a3d_absmax4(v));
+            *reinterpret_cast<f32x4 *>(a.y + ooff) = v;
+        }
+    }
+    if (a.y_amax) a3d_note_amax(a.y_amax, bimg, vmax, ok);  // (every lane of the wave gets here)
 }
 // src [outer][rows][cols] fp32 -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly: the chunk-major
 // plane layout the split-operand GEMM streams (the `rows` of one plane of one 32-deep chunk are one contiguous run; with a
@@ -1017,6 +1104,23 @@ size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
     return 16 * T * ((size_t)d->Cin + d->Cin2) * sizeof(float);
 }
 
+// Plane-split form (precision 3): worth it while the one-launch form would start at most 48 128-tile workgroups -- they leave most
+// of the 256 CUs idle for 16 x C/32 iterations, and 32 x as many 64-tile single-plane workgroups still fit in a few rounds.  Measured
+// (frames/s, bound 0 | 16 | 32 | 48 | 96): 1 frame 113 | 145 | 143 | 145 | 143, 4 frames 386 | 426 | 447 | 451 | 453, 64 frames
+// 1288 | . | 1278 (= its 0) | . | 1285 (-0.3 %).  A3D_WINO_PS_BLOCKS overrides the bound (0 = never; A/B runs).
+extern "C" size_t a3d_wino_m_bytes(const a3d_conv_desc *d) {
+    static int ps_max = -1;
+    if (ps_max < 0) ps_max = getenv("A3D_WINO_PS_BLOCKS") ? atoi(getenv("A3D_WINO_PS_BLOCKS")) : 48;
+    if (!d || d->precision != 3 || !a3d_wino_eligible(d)) return 0;
+    const int C = d->Cin + d->Cin2;
+    if ((C & 63) || ((d->Cout + 63) / 64) % 2 != 0) return 0;  // (an even number of 32-deep chunks per plane; the wide tiles' channel blocks)
+    const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
+    const size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
+    const long blocks4 = (long)((T + 127) / 128) * ((d->Cout + X3W_BN - 1) / X3W_BN);
+    if (blocks4 > ps_max) return 0;
+    return 16 * T * (size_t)d->Cout * sizeof(float);
+}
+
 static int wino_launch_input(const a3d_conv_desc *d, hipStream_t s) {
     const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
     const int Ty = (Hl + 1) / 2, Tx = (Wl + 1) / 2;
@@ -1056,6 +1160,7 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.in_amax = d->in_amax;
     a.in_amax2 = d->in_amax2;
     a.w_scale = d->w_scale;
+    a.M = nullptr;
     if (d->precision == 3) {  // fp16x2: the wide kernels only (w_wino_x3 = the filter pre-split by a3d_split_f16x2_chunk(.., 32, w_scale))
         if (!d->w_wino_x3 || (a.C & 31) || !d->in_amax || !(d->w_scale > 0.f) || ((d->Cout + 63) / 64) % 2 != 0 ||
             (size_t)16 * d->Cout * a.C * 4 >= ((size_t)1 << 32))
@@ -1073,9 +1178,18 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         static bool attr3 = false;
         if (!attr3) {
             if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||
-                hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess)
+                hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess)
                 return A3D_ERR_LAUNCH;
             attr3 = true;
+        }
+        if (d->wino_m && a3d_wino_m_bytes(d)) {  // small problem: one plane per workgroup, then the fold (same bits)
+            a.M = d->wino_m;
+            a3d_note_variant("wino_gemm_h2w_kernel<2> planes + wino_fold_kernel");
+            hipLaunchKernelGGL((wino_gemm_x3w_kernel<2, true, true>), dim3(mtiles * nt, 16), dim3(256), x3w_lds_bytes(2, 2), s, a, nt, mtiles * nt);
+            const size_t threads = T * (size_t)(d->Cout / 4);
+            hipLaunchKernelGGL(wino_fold_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+            return A3D_OK;
         }
         a3d_note_variant("wino_gemm_h2w_kernel<%d>", wmx);
         if (wmx == 4) {

@@ -260,6 +260,7 @@ def pack_fused_rows(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tens
 # A tensor [B, ...] produced by a split-operand launch carries `_a3d_amax`, a device tensor [B] with max |t[b]| (recorded by the
 # launch's epilogue into a zero-initialised slot).  Views made on the hot path hand it on with keep_amax(); any other tensor gets its
 # maxima from a3d_absmax_rows on first use.  Slots come from zeroed arena chunks (one fill per ~256k floats, freed with their tensors).
+WINO_PLANE_SPLIT = os.environ.get("A3D_WINO_PLANE_SPLIT", "1") != "0"  # (False: small Winograd problems keep the one-launch form; same bits)
 _AMAX_CHUNK = 1 << 18
 AMAX_MISSES: Optional[list] = None  # debugging: install a list to record the tensors whose maxima had to be computed by a3d_absmax_rows
 _amax_arena: dict = {}
@@ -489,6 +490,11 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         elif nbytes:
             ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
             d.workspace = ws.data_ptr()
+        if use_wino and d.precision == 3 and WINO_PLANE_SPLIT:  # small problems: scratch for the plane-split form (a3d_conv_desc.wino_m; 0 bytes otherwise)
+            mbytes = _lib.lib().a3d_wino_m_bytes(C.byref(d))
+            if mbytes:
+                wino_m = torch.empty(mbytes // 4, device=x.device, dtype=torch.float32)
+                d.wino_m = wino_m.data_ptr()
     if shared is not None:
         have_v, shared[1] = shared[1] is not None, ws
         if CONV_TIMING is None:

@@ -134,9 +134,17 @@ typedef struct a3d_conv_desc {
     float *y_amax;         /* optional DEVICE [B], zero-initialised by the caller: the launch raises y_amax[b] to max |y[b]| (atomic
                               max; any precision of the split-operand kernels) so that the next layer has its in_amax for free      */
     float w_scale;         /* precision 3: power of two that puts max |w| (Winograd layers: max |w_wino|) in [2^14, 2^15)           */
+    float *wino_m;         /* optional, precision 3 Winograd layers: a3d_wino_m_bytes() of scratch.  With it SMALL problems (a few
+                              workgroups in the one-launch form: single frames, the coarsest pyramid levels) run plane-split: 16 x as
+                              many workgroups each compute ONE Winograd plane's product into wino_m [16][tiles][Cout], and a second
+                              launch folds the planes in the same order and applies the epilogue -- the same bits, a 16th of the
+                              per-workgroup latency                                                                                 */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
+/* bytes of a3d_conv_desc.wino_m if this launch would use it (0: the problem is large enough for the one-launch form, or not a
+ * precision-3 Winograd layer) */
+size_t a3d_wino_m_bytes(const a3d_conv_desc *d);
 int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
 /* src [outer][rows][cols] fp32 (cols % 32 == 0) -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly
  * (round-to-nearest-even at each level). */

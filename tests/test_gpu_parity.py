@@ -283,6 +283,30 @@ def test_fp16x2_wide_and_narrow_direct_kernels_agree_bit_for_bit(ops):
     assert torch.equal(wide, narrow)
 
 
+def test_plane_split_winograd_equals_the_one_launch_form_bit_for_bit(ops):
+    """Small fp16x2 Winograd problems run one plane per workgroup into a3d_conv_desc.wino_m and fold afterwards (wino_fold_kernel): the
+    same multiply-adds in the same order as the one-launch kernel -- outputs and recorded maxima are identical."""
+    torch.manual_seed(11)
+    cases = [(1, 30, 40, 256, 256), (2, 15, 20, 512, 512), (3, 9, 11, 256, 128), (1, 60, 80, 256, 256), (5, 14, 14, 256, 256), (1, 8, 10, 256, 256), (3, 37, 41, 256, 256)]
+    for B, H, W, Cin, Cout in cases:
+        x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+        pk = ops.pack_conv(torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_RELU)
+        a = ops.conv2d(x, pk, precision=3)
+        assert ops.last_conv_variant().endswith("wino_fold_kernel"), ops.last_conv_variant()
+        ops.WINO_PLANE_SPLIT = False
+        try:
+            b = ops.conv2d(x, pk, precision=3)
+            assert ops.last_conv_variant().startswith("wino_gemm_h2w_kernel<") and "fold" not in ops.last_conv_variant()
+        finally:
+            ops.WINO_PLANE_SPLIT = True
+        assert torch.equal(a, b), (B, H, W, Cin, Cout)
+        assert torch.equal(ops.amax_of(a), ops.amax_of(b))
+    big = torch.randn(64, 30, 40, 256, device="cuda")  # 150 blocks: the one-launch form stays
+    pk = ops.pack_conv(torch.randn(256, 256, 3, 3) / 48, None, None, 1, 1, ops.ACT_NONE)
+    ops.conv2d(big, pk, precision=3)
+    assert "fold" not in ops.last_conv_variant()
+
+
 @pytest.mark.parametrize("precision", [3, 2])
 def test_row_major_and_direct_epilogues_store_the_same_bits(ops, precision):
     """The split-operand kernels pass their output tiles through LDS so that a store covers 8 rows x 128 B; tune 12 keeps the direct
