@@ -425,10 +425,16 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                 if (mb < M && mb / hwo == mlast / hwo) {  // the tile's rows belong to one image (uniform per wave): one reduction
                     a3d_note_amax(d.y_amax, mb / hwo, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
                 } else {
+                    // (rows of several images, e.g. the FC layers where every ROI is one: the 8 lanes of a row reduce first, so a row
+                    // costs one pre-checked atomic per wave instead of eight -- fc2 at 64000 rows 1.03 -> see DESIGN 5a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int m = mb + qr + 8 * j;
-                        a3d_note_amax(d.y_amax, m < M ? m / hwo : 0, vmax[j], m < M);
+                        float v = vmax[j];
+                        v = fmaxf(v, __shfl_xor(v, 1, 64));
+                        v = fmaxf(v, __shfl_xor(v, 2, 64));
+                        v = fmaxf(v, __shfl_xor(v, 4, 64));
+                        a3d_note_amax(d.y_amax, m < M ? m / hwo : 0, v, m < M && qc == 0);
                     }
                 }
             }

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
             }
         }
         }
-        if (d.y_amax && d.splitk == 1) a3d_note_amax(d.y_amax, bimg, vmax, mok);  // (every lane of the wave gets here; split-K: the reducer)
+        // (every lane of the wave gets here; split-K: the reducer.  Lanes l and l+32 hold the same row: one of them reports it -- with
+        // one image per row, as in the FC layers, every report is a pre-checked atomic)
+        if (d.y_amax && d.splitk == 1) a3d_note_amax(d.y_amax, bimg, fmaxf(vmax, __shfl_xor(vmax, 32, 64)), mok && lane < 32);
     }
 }
 }  // namespace

@@ -968,7 +968,13 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             a3d_note_amax(a.y_amax, tb / tyx, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a3d_note_amax(a.y_amax, max(jb[j], 0), vmax[j], jb[j] >= 0);
+            for (int j = 0; j < 4; ++j) {  // (the 8 lanes of a tile reduce first: one pre-checked atomic per tile, not eight)
+                float v = vmax[j];
+                v = fmaxf(v, __shfl_xor(v, 1, 64));
+                v = fmaxf(v, __shfl_xor(v, 2, 64));
+                v = fmaxf(v, __shfl_xor(v, 4, 64));
+                a3d_note_amax(a.y_amax, max(jb[j], 0), v, jb[j] >= 0 && qc == 0);
+            }
         }
     }
 }
