@@ -411,7 +411,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         if getattr(p, "_w_scale", None) is None:
             p._w_scale = _pow2_scale_host(float(p.w.abs().max()))
         d.w_scale = p._w_scale
-    if d.precision in (2, 3) and (DEFAULT_PRECISION == 3 or d.precision == 3) and not p.pixshuf:
+    if d.precision in (2, 3) and (DEFAULT_PRECISION == 3 or d.precision == 3) and not p.pixshuf and not os.environ.get("A3D_NO_YAMAX"):
         ya = getattr(out, "_a3d_amax", None)  # (the four phase launches of an upsampled conv share their output and its slot)
         if ya is None or ya.numel() != out.shape[0]:
             ya = out._a3d_amax = amax_slot(out.shape[0], out.device)
