@@ -200,6 +200,11 @@ def main():
     dev = f"cuda:{local_dev}"
     dist = None
     use_dist = world > 1 or force_dist
+    if world > 1:
+        # N ranks share one host: torch's default of one intra-op worker per host core would put N x cores spinning OpenMP threads
+        # next to the N HIP runtimes (utils/arti_vis.py measured what that does to a launch-bound loop); the step needs none of them
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(8, avail // world)))
     if use_dist:
         import torch.distributed as dist
 
