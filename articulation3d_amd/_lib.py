@@ -83,6 +83,7 @@ class RoiAlignDesc(C.Structure):
         ("B", C.c_int), ("R", C.c_int),
         ("P", C.c_int), ("sampling_ratio", C.c_int), ("aligned", C.c_int),
         ("out", fptr), ("out_level", fptr), ("order_ws", fptr),
+        ("out_amax", fptr), ("level_amax", fptr * 4), ("window_count", fptr),
     ]
 
 

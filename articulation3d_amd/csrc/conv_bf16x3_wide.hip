@@ -411,12 +411,12 @@ int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
         if (d->Cout < 192 || ntiles * XW_BN > d->Cout + d->Cout / 4) return A3D_ERR_UNSUPPORTED;
         if (d->splitk == 1 && (long)mtiles * ntiles < 2 * 256) return A3D_ERR_UNSUPPORTED;  // (split-K launches stream the weights: any M)
     }
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+    static a3d_attr_once attr_set;
+    if (attr_set.needed()) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device)
         if (hipFuncSetAttribute((const void *)conv_x3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(3)) != hipSuccess ||
             hipFuncSetAttribute((const void *)conv_x3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(2)) != hipSuccess)
             return A3D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     if (d->precision == 3) {
         if (!d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;

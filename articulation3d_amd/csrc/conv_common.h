@@ -8,7 +8,7 @@
 
 template <int ACT>
 __device__ __forceinline__ float a3d_act(float v) {
-    if (ACT == A3D_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == A3D_ACT_RELU) return v <= 0.f ? 0.f : v;  // (NaN stays NaN, like torch.relu)
     if (ACT == A3D_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
     return v;
 }
@@ -23,7 +23,7 @@ __device__ __forceinline__ f32x4 apply_epilogue(const a3d_conv_desc &d, f32x4 v,
         v += r;
     }
     if (d.act == A3D_ACT_RELU) {
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = v[i] <= 0.f ? 0.f : v[i];
     } else if (d.act == A3D_ACT_LEAKY) {
         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.01f * v[i];
     }
@@ -52,7 +52,7 @@ __device__ __forceinline__ f32x4 a3d_epilogue_math(const a3d_conv_desc &d, f32x4
     if (has_res) v += r;
     if (d.act == A3D_ACT_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) v[i] = v[i] <= 0.f ? 0.f : v[i];
     } else if (d.act == A3D_ACT_LEAKY) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.01f * v[i];
@@ -123,8 +123,6 @@ __device__ __forceinline__ void a3d_note_amax(float *y_amax, const int b, float 
         atomicMax(reinterpret_cast<int *>(y_amax + b), __float_as_int(v));
     }
 }
-__device__ __forceinline__ float a3d_absmax4(const f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
-
 // Every conv launcher records the kernel instantiation it dispatched (name + template arguments as they appear in a
 // rocprofv3 kernel trace) in a per-thread slot; `a3d_last_conv_variant()` (include/a3d.h) reads it back, so measurement
 // code labels launches with what the dispatcher DID, not with a host-side copy of its rules.

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 1) void wino_gemm_kernel(const W
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
                 if (a.act == A3D_ACT_RELU) {
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] <= 0.f ? 0.f : v[k];
                 } else if (a.act == A3D_ACT_LEAKY) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
                 }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_x3_kernel(const WinoArgs a, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
             if (a.act == A3D_ACT_RELU) {
-                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                for (int k = 0; k < 4; ++k) v[k] = v[k] <= 0.f ? 0.f : v[k];
             } else if (a.act == A3D_ACT_LEAKY) {
                 for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
             }
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
                 if (a.act == A3D_ACT_RELU) {
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] <= 0.f ? 0.f : v[k];
                 } else if (a.act == A3D_ACT_LEAKY) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
                 }
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void wino_fold_kernel(const WinoArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
             if (a.act == A3D_ACT_RELU) {
-                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                for (int k = 0; k < 4; ++k) v[k] = v[k] <= 0.f ? 0.f : v[k];
             } else if (a.act == A3D_ACT_LEAKY) {
                 for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
             }
@@ -1181,13 +1181,13 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         // (ms, 64-tile | 128-tile): p2 256 -> 256 2.67 | 2.66, 60x80x256 0.73 | 0.75, 30x40x256 0.26 | 0.29, 15x20x512 0.25 | 0.24,
         // 276 ROIs 0.20 | 0.19.  Same kernel template, same operation order: bit-identical.
         const int wmx = wm_force3 ? wm_force3 : (blocks4 <= 256 ? 4 : 2);
-        static bool attr3 = false;
-        if (!attr3) {
+        static a3d_attr_once attr3;
+        if (attr3.needed()) {
             if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess)
                 return A3D_ERR_LAUNCH;
-            attr3 = true;
+            attr3.mark();
         }
         if (d->wino_m && a3d_wino_m_bytes(d)) {  // small problem: one plane per workgroup, then the fold (same bits)
             a.M = d->wino_m;
@@ -1226,12 +1226,12 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         if (wide) {
             const int nt = ntw;
             const int wmx = wm_force ? wm_force : 4;
-            static bool attr_set = false;
-            if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+            static a3d_attr_once attr_set;
+            if (attr_set.needed()) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device)
                 if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 3)) != hipSuccess ||
                     hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 3)) != hipSuccess)
                     return A3D_ERR_LAUNCH;
-                attr_set = true;
+                attr_set.mark();
             }
             a3d_note_variant("wino_gemm_x3w_kernel<%d>", wmx);
             if (wmx == 4) {
@@ -1267,21 +1267,25 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
 
 int a3d_conv_launch_wino(const a3d_conv_desc *d, hipStream_t s) {
     if (!a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_UNSUPPORTED;
-    wino_launch_input(d, s);
-    wino_launch_gemm(d, s);
+    int r = wino_launch_input(d, s);
+    if (r != A3D_OK) return r;
+    r = wino_launch_gemm(d, s);  // (argument / attribute failures launch nothing: report them instead of a clean launch status)
+    if (r != A3D_OK) return r;
     return a3d_check_launch();
 }
 
 extern "C" int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream) {
     if (!d || !d->x || !a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_ARG;
     a3d_begin();
-    wino_launch_input(d, (hipStream_t)stream);
+    const int r = wino_launch_input(d, (hipStream_t)stream);
+    if (r != A3D_OK) return r;
     return a3d_check_launch();
 }
 
 extern "C" int a3d_wino_gemm(const a3d_conv_desc *d, void *stream) {
     if (!d || !d->y || !a3d_wino_eligible(d) || !d->workspace) return A3D_ERR_ARG;
     a3d_begin();
-    wino_launch_gemm(d, (hipStream_t)stream);
+    const int r = wino_launch_gemm(d, (hipStream_t)stream);
+    if (r != A3D_OK) return r;
     return a3d_check_launch();
 }

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void wino_fused_kernel(const WinoFusedArgs 
             for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(o[k], sc[k], sh[k]);
             if (a.act == A3D_ACT_RELU) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+                for (int k = 0; k < 4; ++k) o[k] = o[k] <= 0.f ? 0.f : o[k];
             } else if (a.act == A3D_ACT_LEAKY) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.01f * o[k];
@@ -366,11 +366,11 @@ int a3d_conv_launch_wino_fused(const a3d_conv_desc *d, hipStream_t s) {
     a.act = d->act;
     a.lbw = pick_block((d->H + 1) / 2, (d->W + 1) / 2, &a.NBY, &a.NBX);
     const int mtiles = d->B * a.NBY * a.NBX, ntiles = (d->Cout + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+    static a3d_attr_once attr_set;
+    if (attr_set.needed()) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device)
         if (hipFuncSetAttribute((const void *)wino_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4) != hipSuccess)
             return A3D_ERR_LAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     a3d_note_variant("wino_fused_kernel %dx%d tiles x 64 ch, bk8 (F(2x2,3x3), input transform in the loader)", 64 >> a.lbw, 1 << a.lbw);
     hipLaunchKernelGGL(wino_fused_kernel, dim3(mtiles * ntiles), dim3(256), LDS_FLOATS * 4, s, a, ntiles, mtiles * ntiles);

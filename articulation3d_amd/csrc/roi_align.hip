@@ -40,7 +40,11 @@ struct RoiArgs {
     int serial;  // A/B + test hook (A3D_ROI_SERIAL=1): the one-load-at-a-time bin walk the batched form replaced
     const int *order;  // optional [B*R]: slot walked by workgroup (b, rank); see a3d_roialign_desc.order_ws
     int nblk;
+    float *out_amax;            // optional [rows]: max |pooled[row]| over the finite pooled values (a3d_roialign_desc.out_amax)
+    const float *level_amax[4]; // optional per level [B]: maxima of the pyramid level, for the window monitor below
+    int *window_count;          // optional: number of live ROIs fainter than 2^-A3D_ROI_WINDOW_LOG2 of their level's maximum
 };
+#define A3D_ROI_WINDOW_LOG2 16
 
 // ---- spatial order of an image's boxes ---------------------------------------------------------------------------------------
 // Proposals arrive score-sorted, i.e. in random spatial order, and all ~1000 boxes of an image are in flight at once across the
@@ -128,6 +132,8 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = a.C >> 2;
     float *orow = a.out + (size_t)row * a.P * a.P * a.C;
+    float lmax = 0.f;  // max |pooled| over this lane's stores (finite values only), reduced per ROI at the end
+    __shared__ float wave_max[4];
 
     // Separable form.  The samples of a bin form a gh x gw lattice and a bilinear weight factorises into a y part and
     // an x part, so  sum_samples sum_corners w*f  ==  sum_rows sum_cols WY[row] * WX[col] * f[row][col]  with
@@ -212,7 +218,9 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                     for (int kx = 0; kx < nx; ++kx) acc += (wy * WX[pw][kx]) * *reinterpret_cast<const f32x4 *>(frow + (size_t)kx * a.C);
                 }
             }
-            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + lane * 4) = acc / count;
+            const f32x4 o = acc / count;
+            lmax = fmaxf(lmax, a3d_absmax4(o));
+            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + lane * 4) = o;
         };
         if (C4 == 64 && !a.serial) {
             // A bin's (ny x nx) cells are independent 1 KiB loads.  Walking them with run-time loop bounds made hipcc issue one load,
@@ -221,8 +229,7 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
             // a second register set that prefetches the next bin (144 VGPRs, 3 workgroups per CU instead of 4-5: 3.1 ms vs 2.6 ms).
             f32x4 v[NC];
             for (int bin = wave; bin < nbins; bin += 4) finish(v, bin, issue(v, bin));
-            return;
-        }
+        } else
         for (int bin = wave; bin < nbins; bin += 4) {
             const int ph = bin / a.P, pw = bin - ph * a.P;
             const int ry0 = Y0[ph], ny = NY[ph], rx0 = X0[pw], nx = NX[pw];
@@ -236,11 +243,12 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                         acc += (wy * WX[pw][kx]) * v;
                     }
                 }
-                *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = acc / count;
+                const f32x4 o = acc / count;
+                lmax = fmaxf(lmax, a3d_absmax4(o));
+                *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = o;
             }
         }
-        return;
-    }
+    } else
     // general path (very large sampling grids): per-sample evaluation, as torchvision writes it
     for (int bin = wave; bin < a.P * a.P; bin += 4) {
         const int ph = bin / a.P, pw = bin - ph * a.P;
@@ -276,7 +284,28 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                     acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
                 }
             }
-            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = acc / count;
+            const f32x4 o = acc / count;
+            lmax = fmaxf(lmax, a3d_absmax4(o));
+            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = o;
+        }
+    }
+    // The ROI's own maximum (fp16x2: the power-of-two scale of every layer that consumes this row).  One workgroup owns the ROI, so
+    // the reduction needs no atomics and its result does not depend on anything but the ROI.  A level-wide bound instead (round 2)
+    // scaled a faint ROI by the hottest cell of its image.  Window monitor: the ROI's features inherit an ABSOLUTE error of
+    // ~2^-40 of their LEVEL's maximum from the backbone's per-image block exponents; relative to the ROI that is 2^-40 x
+    // (level max / ROI max), i.e. fp32-grade while the ratio stays below ~2^16.  ROIs past that are counted, never silently passed.
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+        if (lane == 0) wave_max[wave] = lmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+            a.out_amax[row] = m;
+            if (a.window_count && a.level_amax[lv]) {
+                const float lm = a.level_amax[lv][b];
+                if (m > 0.f && lm < 1.7e38f && m * (float)(1 << A3D_ROI_WINDOW_LOG2) < lm) atomicAdd(a.window_count, 1);
+            }
         }
     }
 }
@@ -307,6 +336,9 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     a.serial = ser && ser[0] == '1';
     a.order = nullptr;
     a.nblk = d->B * d->R;
+    a.out_amax = d->out_amax;
+    a.window_count = d->window_count;
+    for (int l = 0; l < 4; ++l) a.level_amax[l] = l < d->L ? d->level_amax[l] : nullptr;
     a3d_begin();
     if (d->order_ws && d->R <= 1024) {
         hipLaunchKernelGGL(roi_order_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, d->boxes, d->count, d->order_ws, d->R, d->L);

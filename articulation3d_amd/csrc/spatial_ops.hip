@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
                 const int iw = ow * 2 - 1 + dx;
                 if ((unsigned)iw >= (unsigned)W) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((size_t)b * H + ih) * W + iw) * (C4 * 4) + c * 4);
-                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+                for (int k = 0; k < 4; ++k) m[k] = (v[k] > m[k] || v[k] != v[k]) ? v[k] : m[k];  // (a NaN in the window wins, like torch's max_pool2d)
             }
         }
         *reinterpret_cast<f32x4 *>(y + i * 4) = m;
@@ -307,28 +307,34 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
 
 
 // ---- per-image maxima of a tensor no kernel of this library produced (a3d_conv_desc.in_amax) --------------------------------
-__global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
-    const int b = blockIdx.y;
-    const float *row = x + (size_t)b * n;
-    float m = 0.f;
-    const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + i * 4);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-    if (blockIdx.x == 0)
-        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(row[i]));
+// Any row count (the grid strides over rows), any row length and alignment (scalar head / tail around the 16-byte body).
+// Non-finite values do not count (conv_common.h a3d_finite_mag): the scale of an image comes from its finite values.
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float *__restrict__ x, float *__restrict__ out, int B, size_t n) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float *row = x + (size_t)b * n;
+        const size_t head = min(n, (size_t)((4 - ((reinterpret_cast<size_t>(row) >> 2) & 3)) & 3));  // floats before the first 16-byte boundary
+        const size_t n4 = (n - head) >> 2;
+        float m = 0.f;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row + head + i * 4);
+            m = fmaxf(m, a3d_absmax4(v));
+        }
+        if (blockIdx.x == 0) {
+            for (size_t i = threadIdx.x; i < head; i += blockDim.x) m = fmaxf(m, a3d_finite_mag(row[i]));
+            for (size_t i = head + (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, a3d_finite_mag(row[i]));
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > out[b]) atomicMax(reinterpret_cast<int *>(out + b), __float_as_int(m));
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0 && m > out[b]) atomicMax(reinterpret_cast<int *>(out + b), __float_as_int(m));
+    }
 }
 
 extern "C" int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream) {
-    if (!x || !out || B <= 0 || B > 65535 || n == 0 || (((size_t)x | (n * 4)) & 15)) return A3D_ERR_ARG;
+    if (!x || !out || B <= 0 || n == 0 || ((size_t)x & 3)) return A3D_ERR_ARG;
     a3d_begin();
     size_t bx = (n / 4 + 255) / 256;
     if (bx > 64) bx = 64;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)bx, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, (hipStream_t)stream, x, out, B, n);
     return a3d_check_launch();
 }

@@ -342,11 +342,71 @@ class share_wino_input:
         return False
 
 
+_ADDR_LIMIT = (1 << 32) - 1  # the kernels address every operand with 32-bit buffer offsets: one launch sees < 4 GiB per tensor
+
+
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
            wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
-    """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4])."""
+    """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4]).
+
+    A launch addresses each operand through a 32-bit buffer descriptor.  Batches whose largest tensor (input, output, residual,
+    Winograd tiles, split-K partial sums) reaches 4 GiB -- ~86 frames x 1000 proposals at the box head's fc1, ~218 frames at a
+    256-channel 120x160 layer -- run as consecutive launches over blocks of images.  Every image's result is a function of that
+    image alone (per-image scales, fixed layer algorithm), so the blocks reproduce the single launch bit for bit."""
+    _req(x)
+    B = x.shape[0]
+    if B > 1:
+        Hl_, Wl_ = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
+        Ho_ = x.shape[1] if p.phase else (Hl_ + 2 * p.pad - p.KH) // p.stride + 1
+        Wo_ = x.shape[2] if p.phase else (Wl_ + 2 * p.pad - p.KW) // p.stride + 1
+        per_in = x.shape[1] * x.shape[2] * max(x.shape[3], 0 if x2 is None else x2.shape[3]) * 4
+        per_out = Ho_ * Wo_ * p.cols * 4 * (4 if p.phase else 1) * max(1, int(splitk))
+        per_v = ((Hl_ + 1) // 2) * ((Wl_ + 1) // 2) * (x.shape[3] + (0 if x2 is None else x2.shape[3])) * 4 if p.w_wino is not None else 0
+        per = max(per_in, per_out, per_v, 1)
+        if B * per > _ADDR_LIMIT:
+            return _conv2d_blocks(x, p, max(1, _ADDR_LIMIT // per), (Ho_, Wo_), x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk,
+                                  m_dev=m_dev, out=out, tune=tune, wino=wino, gate=gate, precision=precision)
+    return _conv2d_launch(x, p, x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk, m_dev=m_dev, out=out, tune=tune,
+                          wino=wino, gate=gate, precision=precision)
+
+
+def _conv2d_blocks(x, p, nb, hw_out, *, x2, res, out, gate, m_dev, **kw):
+    B = x.shape[0]
+    Ho, Wo = hw_out
+    if out is None:
+        shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    cut = lambda t, s, e: None if t is None else keep_amax(t[s:e], _amax_rows(t, s, e))
+    recorded = []
+    for s in range(0, B, nb):
+        e = min(s + nb, B)
+        md = None if m_dev is None else (m_dev.reshape(1) - s).clamp(0, e - s).to(torch.int32)  # live rows of this block (device side)
+        o = out[s:e]
+        ya = getattr(out, "_a3d_amax", None)
+        if ya is not None and ya.numel() == B:  # (the phase launches of an upsampled conv share their output's slots)
+            o._a3d_amax = ya[s:e]
+        _conv2d_launch(cut(x, s, e), p, x2=cut(x2, s, e), res=cut(res, s, e), out=o, gate=cut(gate, s, e), m_dev=md, **kw)
+        recorded.append(getattr(o, "_a3d_amax", None))
+    if getattr(out, "_a3d_amax", None) is None and all(r is not None for r in recorded):
+        out._a3d_amax = torch.cat(recorded)
+    return out
+
+
+class _amax_rows:
+    """Stand-in `old` argument of keep_amax for a block of images: rows [s, e) of a tensor's recorded maxima."""
+
+    def __init__(self, t, s, e):
+        a = getattr(t, "_a3d_amax", None)
+        self._a3d_amax = None if a is None or a.numel() != t.shape[0] else a[s:e]
+        self.shape = (e - s,)
+
+
+def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                   res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
+                   m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
+                   wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
     _req(x)
     B, H, W, Cin = x.shape
     Cin2 = 0
@@ -777,13 +837,38 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     # (measured, tools/roi_bench.py: -7 % on the 1000-proposal box pooler; the 100-detection poolers lose 3-5 % to the sort launch)
     order = torch.empty((B * R,), device=dev, dtype=torch.int32) if (512 <= R <= 1024 and ROI_SPATIAL_ORDER) else None
     d.order_ws = _p(order)
-    _lib.check(_lib.lib().a3d_roi_align_fpn(C.byref(d), _stream()), "a3d_roi_align_fpn")
-    if DEFAULT_PRECISION == 3:  # fp16x2: per-ROI bound of the pooled magnitudes from the levels' per-image maxima (a3d_roi_amax)
-        la = (fptr_t * 4)(*([amax_of(f).data_ptr() for f in feats] + [None] * (4 - len(feats))))
+    ra = None
+    if DEFAULT_PRECISION == 3:  # fp16x2: every pooled row records ITS OWN maximum (the scale of the layers that consume it) ...
         ra = amax_slot(nrows, dev)
-        _lib.check(_lib.lib().a3d_roi_amax(la, len(feats), _p(count), _p(row_offset), B, R, ra.data_ptr(), _stream()), "a3d_roi_amax")
+        d.out_amax = ra.data_ptr()
+        for l, f in enumerate(feats):  # ... and ROIs fainter than 2^-16 of their level are counted (roi_window_count)
+            d.level_amax[l] = amax_of(f).data_ptr()
+        d.window_count = window_counter(dev).data_ptr()
+    _lib.check(_lib.lib().a3d_roi_align_fpn(C.byref(d), _stream()), "a3d_roi_align_fpn")
+    if ra is not None:
         out._a3d_amax = ra
     return (out, lvl) if want_level else out
+
+
+_WINDOW_COUNTERS: dict = {}
+
+
+def window_counter(device) -> torch.Tensor:
+    """Device-side int32 counter of the default arithmetic's window monitor (a3d_roialign_desc.window_count): ROIs whose own maximum
+    lies below 2^-16 of their pyramid level's, i.e. whose pooled features the per-image block exponents of the backbone no longer
+    resolve to fp32's own rounding.  Accumulates over the process; `roi_window_count()` reads it (one synchronisation)."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = _WINDOW_COUNTERS.get(device)
+    if t is None:
+        t = _WINDOW_COUNTERS[device] = torch.zeros(1, device=device, dtype=torch.int32)
+        torch.cuda.current_stream(device).synchronize()  # (visible to every stream that will count into it)
+    return t
+
+
+def roi_window_count(device="cuda") -> int:
+    return int(window_counter(device).item())
 
 
 def count_offsets(count: torch.Tensor, cap: int) -> torch.Tensor:

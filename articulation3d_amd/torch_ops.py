@@ -70,9 +70,27 @@ def _box_detections(pred: Tensor, prop_boxes: Tensor, prop_count: Tensor, img_h:
 
 def _conv2d_fused(x: Tensor, w: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], res: Optional[Tensor], w_wino: Optional[Tensor],
                   KH: int, KW: int, stride: int, pad: int, act: int) -> Tensor:
-    cols, Kpad = w.shape
-    p = ops.PackedConv(w, scale, shift, KH, KW, stride, pad, Kpad // (KH * KW), cols, Kpad, act, w_wino=w_wino)
-    return ops.conv2d(x, p, res=res)
+    return ops.conv2d(x, _packed_for(w, scale, shift, w_wino, KH, KW, stride, pad, act), res=res)
+
+
+_PACKED: "dict" = {}  # (storage identity and version of the filter tensors, geometry) -> PackedConv with its cached splits / scales
+
+
+def _packed_for(w, scale, shift, w_wino, KH, KW, stride, pad, act):
+    """The op takes raw tensors, the kernels want the filter's derived forms (its power-of-two scale, the fp16 planes of the default
+    arithmetic, published to every stream): building them per call cost 2-3 host synchronisations and redundant split kernels per
+    op call.  They are cached per filter identity -- data_ptr + `_version` (bumped by every in-place update) of each tensor -- in a
+    small LRU, like the modules' own packed weights (modeling/layers.py)."""
+    ident = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.device)
+    key = (ident(w), ident(scale), ident(shift), ident(w_wino), KH, KW, stride, pad, act)
+    p = _PACKED.pop(key, None)
+    if p is None:
+        cols, Kpad = w.shape
+        p = ops.PackedConv(w, scale, shift, KH, KW, stride, pad, Kpad // (KH * KW), cols, Kpad, act, w_wino=w_wino, presplit=True)
+        while len(_PACKED) >= 256:
+            _PACKED.pop(next(iter(_PACKED)))
+    _PACKED[key] = p  # (re-inserted last: most recently used)
+    return p
 
 
 def _paste_lsq(boxes: Tensor, scores: Tensor, count: Tensor, row_offset: Tensor, mask_prob: Tensor, normals: Optional[Tensor],

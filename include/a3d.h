@@ -261,12 +261,22 @@ typedef struct a3d_roialign_desc {
                        into it and walks them in that order, with each XCD taking whole images, so that workgroups running
                        side by side touch neighbouring feature cells (L2 hits instead of re-fetches).  The OUTPUT rows do not
                        move and the values are bit-identical to the unsorted walk: only the schedule changes. */
+    float *out_amax; /* optional [rows]: max |pooled[row]| over the row's finite values, written by the workgroup that pools the
+                        row (no atomics; rows of dead slots are not touched).  It is a3d_conv_desc.in_amax of the layers that consume
+                        the pooled rows: every ROI is scaled by ITS OWN maximum (round 2 used a3d_roi_amax's level-wide bound, which
+                        scaled a faint ROI by the hottest cell of its image). */
+    const float *level_amax[4]; /* optional, with window_count: per level [B] = max |feat[l][b]| */
+    int *window_count; /* optional: += number of live ROIs whose own maximum is below 2^-16 of their level's.  The backbone's per-image
+                          block exponents leave every feature with an absolute error of ~2^-40 of its level's maximum; relative to
+                          such a ROI that exceeds fp32's own rounding.  The default arithmetic counts these ROIs instead of passing
+                          them silently (0 on every frame of the test and bench clips; A3D_PRECISION=2 is the remedy). */
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);
 
 /* out[row of (b, r)] = max over the L levels of level_amax[l][b], for the live boxes r < count[b]: an upper bound of max |pooled[row]|
- * (a3d_conv_desc.in_amax of the layers that consume the pooled features; rows as in a3d_roi_align_fpn). */
+ * (rows as in a3d_roi_align_fpn).  Superseded on the detection path by a3d_roialign_desc.out_amax (the ROI's own maximum); kept for
+ * callers that pool with their own kernel. */
 int a3d_roi_amax(const float *const level_amax[4], int L, const int *count, const int *row_offset, int B, int R, float *out, void *stream);
 
 /* offsets[b] = sum_{i<b} min(count[i], cap); offsets[B] = total.  (compacts ragged per-image ROI lists) */
