@@ -48,6 +48,7 @@ class PlaneRCNNConvFCHead(nn.Module):
         for layer in self.fcs_R + self.fcs_T:
             c2_xavier_fill(layer.weight, layer.bias)
         self._loss_weight = h.LOSS_WEIGHT
+        self.keep_raw, self.raw = False, None
 
     @property
     def output_size(self):
@@ -69,6 +70,8 @@ class PlaneRCNNConvFCHead(nn.Module):
         rot = ops.linear_small(xr, w, b, norm_n=2)  # normalise (sin, cos); offset passes through
         xt = self._tower(x, self.conv_norm_relus_T, self.fcs_T)
         tran = ops.linear_small(xt, self.translation.weight, self.translation.bias, norm_n=2)
+        if self.keep_raw:  # checker hook: the rotation | offset and translation FC outputs before F.normalize (axis_head.py:106,120)
+            self.raw = (ops.linear_small(xr, w, b, norm_n=0), ops.linear_small(xt, self.translation.weight, self.translation.bias, norm_n=0))
         return rot, tran
 
     def forward(self, x, instances):

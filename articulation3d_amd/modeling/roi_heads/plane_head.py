@@ -49,6 +49,7 @@ class PlaneRCNNConvFCHead(nn.Module):
         for layer in self.fcs:
             c2_xavier_fill(layer.weight, layer.bias)
         self._loss_weight = h.LOSS_WEIGHT
+        self.keep_raw, self.raw = False, None
 
     @property
     def output_size(self):
@@ -62,6 +63,8 @@ class PlaneRCNNConvFCHead(nn.Module):
         for fc in self.fcs:
             x = head_fc(x, fc)
         n = self.param_pred.out_features
+        if self.keep_raw:  # checker hook (tests, bench): the param_pred output before F.normalize (plane_head.py:80), same kernel
+            self.raw = ops.linear_small(x, self.param_pred.weight, self.param_pred.bias, norm_n=0)
         return ops.linear_small(x, self.param_pred.weight, self.param_pred.bias,
                                 norm_n=n if self._plane_normal_only else 0)
 

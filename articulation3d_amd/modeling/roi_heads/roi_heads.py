@@ -143,6 +143,10 @@ class PlaneRCNNROIHeads(nn.Module):
             det.pred_plane = outs["plane"]
         if "axis" in outs:
             det.pred_rot_axis, det.pred_tran_axis = outs["axis"]
+        if self.plane_on and self.plane_head.keep_raw:  # checker hook: pre-normalisation head vectors (tests/test_gpu_e2e.py)
+            det.raw_plane = self.plane_head.raw
+        if self.axis_on and self.axis_head.keep_raw:
+            det.raw_rot, det.raw_tran = self.axis_head.raw
         return det
 
     @staticmethod

@@ -124,10 +124,11 @@ def detect_exact(images_chw: List[torch.Tensor], P64, cfg: O.OracleCfg, outs32: 
         res.append(dict(pred_boxes=bx, scores=pr[rows, cl], pred_classes=cl, depth=depth[n]))
     nd = [len(b) for b in boxes_all]
     m = O.mask_head(_pool(feats, boxes_all, *cfg.mask_pool), P64)
-    pl = O.plane_head(_pool(feats, boxes_all, *cfg.plane_pool), P64)
-    ra, ta = O.axis_head(_pool(feats, boxes_all, *cfg.axis_pool), P64)
-    for r, mm, pp, a, t in zip(res, m.split(nd), pl.split(nd), ra.split(nd), ta.split(nd)):
+    pl, plr = O.plane_head(_pool(feats, boxes_all, *cfg.plane_pool), P64, return_raw=True)
+    ra, ta, rar, tar = O.axis_head(_pool(feats, boxes_all, *cfg.axis_pool), P64, return_raw=True)
+    for r, mm, pp, a, t, pr, ar, tr in zip(res, m.split(nd), pl.split(nd), ra.split(nd), ta.split(nd), plr.split(nd), rar.split(nd), tar.split(nd)):
         r["pred_plane"], r["pred_rot_axis"], r["pred_tran_axis"] = pp, a, t
+        r["raw_plane"], r["raw_rot"], r["raw_tran"] = pr, ar, tr
         r["pred_masks"] = _paste(mm[:, 0], r["pred_boxes"], H, W, cfg.mask_threshold)
         r["plane_offset"] = _override_depth(r["depth"], r["pred_masks"], pp)
     return res

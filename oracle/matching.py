@@ -45,6 +45,9 @@ def gpu_frame_results(out) -> List[Dict[str, torch.Tensor]]:
                      pred_tran_axis=out.det.pred_tran_axis.cpu()[rows], plane_offset=out.planes[b].cpu()[idx])
             if out.masks is not None:
                 r["pred_masks"] = out.masks[b].cpu()[idx].bool()
+            for k in ("raw_plane", "raw_rot", "raw_tran"):  # present when the heads ran with keep_raw (checker hook)
+                if getattr(out.det, k, None) is not None:
+                    r[k] = getattr(out.det, k).cpu()[rows]
         else:
             r.update(pred_plane=torch.zeros(0, 3), pred_rot_axis=torch.zeros(0, 3), pred_tran_axis=torch.zeros(0, 2),
                      plane_offset=torch.zeros(0, 3), pred_masks=torch.zeros(0, *out.image_size, dtype=torch.bool))
@@ -110,6 +113,21 @@ def compare_frame(g: Dict, o: Dict) -> Dict:
     for key, name in (("pred_plane", "plane"), ("pred_rot_axis", "rot_axis"), ("pred_tran_axis", "tran_axis")):
         d = (g[key].float() - o[key].float()).abs().flatten(1).amax(1) / (o[key].float().abs().max() + 1e-12) if n else torch.zeros(0)
         m[name + "_err_all"] = [float(v) for v in d]
+    # RAW head vectors (before F.normalize) and the normalised outputs weighted by their conditioning.  n = r / |r| has
+    # dn ~ dr / |r|: the whole heavy tail of the normalised errors is the factor 1 / |r| of short raw vectors, so
+    #   raw_*_err_all   = |r_g - r_o|_inf per detection (no amplification: comparable at its MAXIMUM), and
+    #   *_cond_all      = |n_g - n_o|_inf * |r_o|       (the normalised error with the amplification divided out)
+    # are held to the float64 yardstick at their maxima (tests/test_gpu_e2e.py); both in units of the frame's largest |r_o|.
+    for raw, key, name, nn_ in (("raw_plane", "pred_plane", "plane", 3), ("raw_rot", "pred_rot_axis", "rot_axis", 2), ("raw_tran", "pred_tran_axis", "tran_axis", 2)):
+        if raw in g and raw in o and n:
+            ro, rg = o[raw].double(), g[raw].double()
+            scale = float(ro.abs().max()) + 1e-300
+            m[raw + "_rel"] = float((rg - ro).abs().max() / scale)
+            m[raw + "_err_all"] = [float(v) for v in (rg - ro).abs().amax(1) / scale]
+            nrm = ro[:, :nn_].norm(dim=1)
+            dn = (g[key].double()[:, :nn_] - o[key].double()[:, :nn_]).abs().amax(1)
+            m[name + "_cond_all"] = [float(v) for v in dn * nrm / scale]
+            m[name + "_rawnorm_all"] = [float(v) for v in nrm / scale]
     same_mask = torch.ones(n, dtype=torch.bool)
     if "pred_masks" in g and "pred_masks" in o and n:
         diff = (g["pred_masks"] != o["pred_masks"]).flatten(1).sum(1)
@@ -146,6 +164,10 @@ def summarize(ms: List[Dict]) -> Dict:
         if v:
             s["max_" + k] = float(max(v))
     s["mask_hamming_px"] = int(sum(m.get("mask_hamming_px", 0) for m in ms))
+    for k in ("raw_plane_err_all", "raw_rot_err_all", "raw_tran_err_all", "plane_cond_all", "rot_axis_cond_all", "tran_axis_cond_all"):
+        v = [x for m in ms for x in m.get(k, [])]
+        if v:
+            s["max_" + k[:-4]] = float(max(v))
     return s
 
 

@@ -87,6 +87,10 @@ class OracleCfg:
     axis_on: bool = True
     depth_on: bool = True
     scale_clamp: float = field(default=math.log(1000.0 / 16))
+    # torchvision's batched_nms strategy (see batched_nms below): "plain" = one NMS per category on the boxes as they are (the
+    # parity definition); "offset" = torchvision >= 0.9's coordinate trick for every call;
+    # "tv-gpu" / "tv-cpu" = torchvision's own size rule on that device (trick up to 5000 / 1000 boxes, per-category loop above).
+    nms_strategy: str = "plain"
 
 
 FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
@@ -452,10 +456,29 @@ def nms_sorted_py(boxes, cats, thr):
     return torch.tensor(keep, dtype=torch.bool)
 
 
-def batched_nms(boxes, scores, cats, thr):
-    """Returns kept indices in score-descending order (stable)."""
+def batched_nms(boxes, scores, cats, thr, strategy: str = "plain"):
+    """Returns kept indices in score-descending order (stable).
+
+    [d2-spec / tv-spec] detectron2's `batched_nms` (layers/nms.py, v0.4-v0.6) forwards to `torchvision.ops.boxes.batched_nms`, which
+    since torchvision 0.9 picks between two formulations by the number of boxes (`boxes.numel() > 4000` on the CPU, `> 20000` on a
+    GPU -> `_batched_nms_vanilla`: one `nms` per category on the boxes as they are; otherwise `_batched_nms_coordinate_trick`):
+        max_coordinate = boxes.max(); offsets = idxs.to(boxes) * (max_coordinate + 1); keep = nms(boxes + offsets[:, None], scores, thr)
+    Categories then never overlap, and the IoU of two boxes of one category is evaluated on coordinates shifted by up to
+    (C - 1) * (max + 1) -- in fp32 the shift costs the coordinates up to 2-3 low bits, so an IoU within ~1e-6 of the threshold can
+    fall on the other side.  `strategy` "plain" is the parity definition (what the HIP kernels implement); "offset" restates the
+    trick, "tv-gpu" / "tv-cpu" torchvision's size rule.  tests/test_oracle_golden.py reports whether any committed frame's keep
+    set differs between the formulations (the reference's proposal stage holds 5 x 1000 candidates: trick on a GPU, loop on the
+    CPU; its box stage <= 2000: trick on a GPU)."""
     order = torch.sort(scores, descending=True, stable=True)[1]
-    keep = nms_sorted(boxes[order], cats[order], thr)
+    n = boxes.shape[0]
+    trick = strategy == "offset" or (strategy == "tv-gpu" and 4 * n <= 20000) or (strategy == "tv-cpu" and 4 * n <= 4000)
+    if trick and n:
+        max_coordinate = boxes.max()
+        offsets = cats.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+        shifted = boxes + offsets[:, None]
+        keep = nms_sorted(shifted[order], torch.zeros(n, dtype=torch.int64), thr)
+    else:
+        keep = nms_sorted(boxes[order], cats[order], thr)
     return order[keep]
 
 
@@ -499,7 +522,7 @@ def rpn_select(logits, deltas, feat_hw, image_sizes, cfg: OracleCfg, return_grou
             ls.append(torch.full((int(valid.sum()),), li, dtype=torch.int64))
             ai.append(idx[valid])
         b, s_, l = torch.cat(bs), torch.cat(ss), torch.cat(ls)
-        keep = batched_nms(b, s_, l, cfg.rpn_nms_thresh)[: cfg.rpn_post_topk]
+        keep = batched_nms(b, s_, l, cfg.rpn_nms_thresh, cfg.nms_strategy)[: cfg.rpn_post_topk]
         out.append((b[keep], s_[keep]))
         if sources is not None:
             sources.append((l[keep], torch.cat(ai)[keep]))
@@ -645,7 +668,7 @@ def fast_rcnn_inference_single(boxes, scores, image_size, cfg: OracleCfg):
     finds = fmask.nonzero()
     b = boxes[fmask]
     s = scores[fmask]
-    keep = batched_nms(b, s, finds[:, 1], cfg.nms_thresh)
+    keep = batched_nms(b, s, finds[:, 1], cfg.nms_thresh, cfg.nms_strategy)
     if cfg.dets_per_image >= 0:
         keep = keep[: cfg.dets_per_image]
     return b[keep], s[keep], finds[keep, 1], rows[finds[keep, 0]]
@@ -677,19 +700,20 @@ def mask_head(x, P):
     return x.sigmoid()  # (D,1,28,28), class agnostic
 
 
-def plane_head(x, P):
-    """plane_head.py:71-82"""
+def plane_head(x, P, return_raw=False):
+    """plane_head.py:71-82.  return_raw: also the param_pred output before F.normalize (:80) -- the quantity whose rounding error
+    the normalisation amplifies by 1 / |raw| (tests/test_gpu_e2e.py compares it directly)."""
     rh = "roi_heads.plane_head."
     for k in range(1, 5):
         x = F.relu(F.conv2d(x, P[rh + f"plane_conv{k}.weight"], P[rh + f"plane_conv{k}.bias"], padding=1))
     x = torch.flatten(x, 1)
     x = F.relu(F.linear(x, P[rh + "plane_fc1.weight"], P[rh + "plane_fc1.bias"]))
     x = F.linear(x, P[rh + "param_pred.weight"], P[rh + "param_pred.bias"])
-    return F.normalize(x, p=2, dim=1)
+    return (F.normalize(x, p=2, dim=1), x) if return_raw else F.normalize(x, p=2, dim=1)
 
 
-def axis_head(x, P):
-    """axis_head.py:95-120"""
+def axis_head(x, P, return_raw=False):
+    """axis_head.py:95-120.  return_raw: also (rotation | offset, translation) before F.normalize (:106,:120)."""
     rh = "roi_heads.axis_head."
 
     def tower(t, x):
@@ -699,10 +723,14 @@ def axis_head(x, P):
         return F.relu(F.linear(x, P[rh + f"axis_{t}_fc1.weight"], P[rh + f"axis_{t}_fc1.bias"]))
 
     xr = tower("R", x)
-    rot = F.normalize(F.linear(xr, P[rh + "rotation.weight"], P[rh + "rotation.bias"]), p=2, dim=1)
+    rot_raw = F.linear(xr, P[rh + "rotation.weight"], P[rh + "rotation.bias"])
+    rot = F.normalize(rot_raw, p=2, dim=1)
     off = F.linear(xr, P[rh + "offset.weight"], P[rh + "offset.bias"])
     xt = tower("T", x)
-    tran = F.normalize(F.linear(xt, P[rh + "translation.weight"], P[rh + "translation.bias"]), p=2, dim=1)
+    tran_raw = F.linear(xt, P[rh + "translation.weight"], P[rh + "translation.bias"])
+    tran = F.normalize(tran_raw, p=2, dim=1)
+    if return_raw:
+        return torch.cat((rot, off), 1), tran, torch.cat((rot_raw, off), 1), tran_raw
     return torch.cat((rot, off), 1), tran
 
 
@@ -845,14 +873,16 @@ def detect(images_chw: List[torch.Tensor], P, cfg: Optional[OracleCfg] = None, g
         for r, mm in zip(results, m.split(nper)):
             r["pred_masks"] = mm
     if cfg.plane_on:
-        pl = plane_head(roi_pool_fpn(feats, boxes, *cfg.plane_pool), P)
-        for r, pp in zip(results, pl.split(nper)):
+        pl, plr = plane_head(roi_pool_fpn(feats, boxes, *cfg.plane_pool), P, return_raw=True)
+        for r, pp, pr in zip(results, pl.split(nper), plr.split(nper)):
             r["pred_plane"] = pp
+            r["raw_plane"] = pr  # (checker bookkeeping, not a reference field: the vector before F.normalize)
     if cfg.axis_on:
-        ra, ta = axis_head(roi_pool_fpn(feats, boxes, *cfg.axis_pool), P)
-        for r, a, t in zip(results, ra.split(nper), ta.split(nper)):
+        ra, ta, rar, tar = axis_head(roi_pool_fpn(feats, boxes, *cfg.axis_pool), P, return_raw=True)
+        for r, a, t, ar, tr in zip(results, ra.split(nper), ta.split(nper), rar.split(nper), tar.split(nper)):
             r["pred_rot_axis"] = a
             r["pred_tran_axis"] = t
+            r["raw_rot"], r["raw_tran"] = ar, tr
     rays = k_inv_dot_xy1()
     outs = []
     for i, (r, sz) in enumerate(zip(results, sizes)):

@@ -11,6 +11,11 @@ Per frame, at SCORE_THRESH_TEST 0.5 (a handful of detections) and 0.0 (the 100-d
   CONTINUOUS (asserted against a yardstick): boxes <= 5e-3 px and scores <= 1e-4 of the oracle's; plane normals, rotation /
     translation axis parameters, plane normal*offset, depth:  | HIP - float64 |  <=  max(1e-4, 3 x | oracle fp32 - float64 |),
     where float64 is the exact evaluation of the same graph with the oracle's discrete choices imposed (oracle/exact.py).
+    The per-ROI head outputs are L2-NORMALISED 2- / 3-vectors n = r / |r|, whose error is the raw vector's divided by |r|.  Round 3
+    compares what the arithmetic actually produces, at its MAXIMUM over all detections, no quantiles and no gross-error escape:
+      - the RAW vectors r (param_pred, rotation | offset, translation FC outputs before F.normalize; the heads' keep_raw hook), and
+      - every normalised output weighted by its own conditioning, | n_hip - n_64 | * | r_64 |,
+    each <= max(floor, 3 x the same statistic of the oracle's fp32 evaluation).
     Why a yardstick and not a flat 1e-4: end to end, two fp32 evaluations of this graph differ by 3e-5 .. 9e-5 at the FPN outputs
     (CPU summation orders among themselves -- oracle/seed_search.py -- and HIP vs CPU alike), and the 6-layer heads that end in an
     L2-normalised 2- or 3-vector amplify that to 1e-4 .. 4e-3 on random-init weights.  The flat 1e-4 (BASELINE.json north_star)
@@ -33,6 +38,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONT = ("box_err_px", "score_err", "plane_rel", "rot_axis_rel", "tran_axis_rel", "plane_offset_rel", "depth_rel")
 K_YARD = 3.0
+RAW_FLOOR = 2e-5  # of the largest raw component: below this the comparison is fp32 rounding of the final 1024-deep FC itself
 
 
 def _frames(golden_dir, oracle, n=8):
@@ -43,59 +49,89 @@ def _frames(golden_dir, oracle, n=8):
     return sel, frames
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_runs(thresh, golden_dir, O, P):
+    """fp32 oracle + float64 exact evaluation of the committed frames at one threshold: computed once, shared by the three
+    arithmetic modes the HIP path is run in."""
+    if thresh not in _ORACLE_RUNS:
+        from oracle import exact as E
+        from oracle import matching as M
+
+        sel, frames = _frames(golden_dir, O)
+        ocfg = O.OracleCfg(score_thresh=thresh)
+        imgs = O.frames_to_chw(frames)
+        P64 = E.to_double(P)
+        o32s, o64s = [], []
+        for i in range(len(imgs)):  # one frame at a time: bounds the float64 run's memory
+            o32, aux = O.detect(imgs[i:i + 1], P, ocfg, return_aux=True)
+            o64 = E.detect_exact(imgs[i:i + 1], P64, ocfg, o32, aux)
+            o32s.append(o32[0])
+            o64s.append(o64[0])
+        cpu64 = [M.compare_frame(a, b) for a, b in zip(o32s, o64s)]
+        _ORACLE_RUNS[thresh] = (sel, frames, o32s, o64s, cpu64)
+    return _ORACLE_RUNS[thresh]
+
+
+MODES = {3: "fp16x2", 2: "bf16x3", 0: "fp32"}
+
+
+@pytest.mark.parametrize("precision", [3, 2, 0], ids=lambda p: MODES[p])
 @pytest.mark.parametrize("thresh", [0.5, 0.0])
-def test_matched_detections_end_to_end(hip_model, oracle, oracle_params, golden_dir, thresh):
-    from oracle import exact as E
+def test_matched_detections_end_to_end(hip_model, oracle, oracle_params, golden_dir, thresh, precision):
+    """The acceptance criterion in every arithmetic the library offers as fp32-grade: the default fp16x2 (precision 3), bf16x3 (2)
+    and the fp32-input MFMA (0) -- the `alt_modes` of the bench line are backed by the same assertions as the headline."""
+    from articulation3d_amd import ops
     from oracle import matching as M
 
     O, P, model = oracle, oracle_params, hip_model
-    sel, frames = _frames(golden_dir, O)
+    sel, frames, o32s, o64s, cpu64 = _oracle_runs(thresh, golden_dir, O, P)
     model.roi_heads.box_predictor.test_score_thresh = thresh
+    saved = ops.DEFAULT_PRECISION
+    ops.DEFAULT_PRECISION = precision
+    model.roi_heads.plane_head.keep_raw = model.roi_heads.axis_head.keep_raw = True
+    window0 = ops.roi_window_count() if precision == 3 else 0
     try:
         out = model.inference_batched(torch.from_numpy(frames).cuda(), want_masks=True)
         torch.cuda.synchronize()
         got = M.gpu_frame_results(out)
     finally:
         model.roi_heads.box_predictor.test_score_thresh = 0.0
-    ocfg = O.OracleCfg(score_thresh=thresh)
-    imgs = O.frames_to_chw(frames)
-    P64 = E.to_double(P)
-    vs32, hip64, cpu64 = [], [], []
-    for i in range(len(imgs)):  # one frame at a time: bounds the float64 run's memory
-        o32, aux = O.detect(imgs[i:i + 1], P, ocfg, return_aux=True)
-        o64 = E.detect_exact(imgs[i:i + 1], P64, ocfg, o32, aux)
-        vs32.append(M.compare_frame(got[i], o32[0]))
-        hip64.append(M.compare_frame(got[i], o64[0]))
-        cpu64.append(M.compare_frame(o32[0], o64[0]))
+        model.roi_heads.plane_head.keep_raw = model.roi_heads.axis_head.keep_raw = False
+        ops.DEFAULT_PRECISION = saved
+    if precision == 3:  # the window monitor of the default arithmetic: no ROI of these frames is fainter than 2^-16 of its level
+        assert ops.roi_window_count() == window0
+    vs32 = [M.compare_frame(g, o) for g, o in zip(got, o32s)]
+    hip64 = [M.compare_frame(g, o) for g, o in zip(got, o64s)]
     s32, sh, sc = M.summarize(vs32), M.summarize(hip64), M.summarize(cpu64)
     margins = [f["margins"][str(thresh)] for f in sel]
-    report = dict(score_thresh_test=thresh, seeds=[f["seed"] for f in sel], hip_vs_oracle_fp32=s32, hip_vs_float64=sh,
+    report = dict(score_thresh_test=thresh, arithmetic=MODES[precision], seeds=[f["seed"] for f in sel], hip_vs_oracle_fp32=s32, hip_vs_float64=sh,
                   oracle_fp32_vs_float64=sc,
                   min_margins={k: min(m[k] for m in margins) for k in margins[0] if k != "detections"})
-    print("\nmatched detections @ thresh", thresh, json.dumps(report, indent=1))
+    print("\nmatched detections @ thresh", thresh, MODES[precision], json.dumps(report, indent=1))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"e2e_matched_t{thresh}.json"), "w") as f:
+    tag = "" if precision == 3 else "_" + MODES[precision]
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_matched_t{thresh}{tag}.json"), "w") as f:
         json.dump(dict(report=report, frames_vs_fp32=vs32, frames_hip_vs_f64=hip64, frames_cpu_vs_f64=cpu64), f, indent=1)
     for s, m in zip(report["seeds"], vs32):  # discrete identity + boxes / scores, frame by frame
         assert m["same_count"], (s, m)
         assert m["classes_equal"], (s, m)
         assert m["box_err_px"] <= M.TOL["box_px"] and m["score_err"] <= M.TOL["score"] and m["matched"], (s, m)
     # The yardstick: as close to the exact (float64) evaluation as the reference's own fp32 arithmetic is.  Dense quantities by their
-    # maximum.  The per-ROI head outputs are NORMALISED vectors: a detection whose raw vector is short amplifies any rounding, so
-    # their maximum over up to 800 detections is a heavy-tailed statistic in EVERY fp32-grade arithmetic (tools/mode_compare.py:
-    # fp16x2 and bf16x3 against the fp32-input MFMA -- same medians, same 99th percentiles, maxima anywhere in 1.5e-3 .. 8e-3).
-    # They are therefore held to the yardstick at the median and the 99th percentile of all detections, and their single worst
-    # detection to a gross-error bound of 10 x the CPU's worst.
+    # maximum.
     for k in ("plane_offset_rel", "depth_rel"):
         hip, cpu = sh["max_" + k], sc["max_" + k]
         assert hip <= max(1e-4, K_YARD * cpu), (k, hip, cpu)
-    for k in ("plane", "rot_axis", "tran_axis"):
-        h = np.array([v for m in hip64 for v in m.get(k + "_err_all", [])])
-        c = np.array([v for m in cpu64 for v in m.get(k + "_err_all", [])])
-        if len(h) and len(c):
-            for q, floor in ((50, 2e-5), (99, 1e-4)):
-                assert np.percentile(h, q) <= max(floor, K_YARD * np.percentile(c, q)), (k, q, np.percentile(h, q), np.percentile(c, q))
-            assert h.max() <= max(1e-4, 10 * c.max()), (k, h.max(), c.max())
+    # Per-ROI head outputs, at their MAXIMUM over all detections (57 at threshold 0.5, 800 at 0.0):
+    #  (1) the raw vectors before F.normalize -- no amplification, so a plain maximum is a fair statistic;
+    #  (2) every normalised output with its conditioning divided out: |n_hip - n_64| * |r_64|  (n = r / |r|  =>  dn ~ dr / |r|).
+    # The quantile rule and the 10x gross-error clause of round 2 are gone: the heavy tail they existed for is exactly the factor
+    # 1 / |r|, and (2) removes it detection by detection.
+    for k in ("raw_plane", "raw_rot", "raw_tran", "plane_cond", "rot_axis_cond", "tran_axis_cond"):
+        hip, cpu = sh["max_" + k], sc["max_" + k]
+        assert hip <= max(RAW_FLOOR, K_YARD * cpu), (k, hip, cpu)
+    # (equivalently: every normalised output is within  bound / |r_64|  of the exact one -- its own conditioning, nothing more)
     assert sh["mask_hamming_px"] <= K_YARD * sc["mask_hamming_px"] + 32, (sh["mask_hamming_px"], sc["mask_hamming_px"])
     if thresh == 0.0:
         assert all(d == 100 for d in s32["detections"])

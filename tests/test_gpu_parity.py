@@ -770,24 +770,49 @@ def _merge_expected(g, g0, ng, K):
     return boxes, [it[2] for it in items]
 
 
-@pytest.fixture(scope="module")
-def staged(ops, hip_model, oracle, oracle_params):
-    """Runs the HIP path on two synthetic frames, keeping every intermediate."""
+MODES = {3: "fp16x2", 2: "bf16x3", 0: "fp32"}
+_ORACLE_STAGE = {}
+
+
+class arithmetic:
+    """`with arithmetic(ops, p):` -- the library's module-default arithmetic (ops.DEFAULT_PRECISION) for the duration of the block.
+    The stage tests run once per fp32-grade mode: 3 = fp16x2 (the default), 2 = bf16x3, 0 = fp32-input MFMA."""
+
+    def __init__(self, ops, p):
+        self.ops, self.p = ops, p
+
+    def __enter__(self):
+        self.saved, self.ops.DEFAULT_PRECISION = self.ops.DEFAULT_PRECISION, self.p
+
+    def __exit__(self, *exc):
+        self.ops.DEFAULT_PRECISION = self.saved
+        return False
+
+
+@pytest.fixture(scope="module", params=[3, 2, 0], ids=lambda p: MODES[p])
+def staged(request, ops, hip_model, oracle, oracle_params):
+    """Runs the HIP path on two synthetic frames in one arithmetic mode, keeping every intermediate.  (The mode is set only while
+    the HIP launches of a fixture / test run -- `arithmetic` -- never for the lifetime of the fixture: tests that do not use the
+    fixture may be scheduled between its users.)"""
     O, P, model = oracle, oracle_params, hip_model
     nf = 2
     frames = O.synthetic_frames(nf)
     fr = torch.from_numpy(frames).cuda()
     ocfg = O.OracleCfg(score_thresh=0.0)
     model.roi_heads.box_predictor.test_score_thresh = 0.0
-    x, _ = O.preprocess(O.frames_to_chw(frames), ocfg)
-    s = dict(nf=nf, frames=frames, fr=fr, ocfg=ocfg, ofeats=O.backbone(x, P), x=x)
-    s["x4"] = ops.preprocess_u8hwc(fr, model.pixel_mean, model.pixel_std)
-    s["feats"] = model.backbone.forward_nhwc(s["x4"])
-    rpn = model.proposal_generator
-    s["heads"] = rpn.rpn_head.forward_nhwc([s["feats"][f] for f in rpn.in_features])
-    s["depth"] = model.depth_head.forward_nhwc(s["feats"])
-    s["gfeats"] = {k: s["feats"][k].permute(0, 3, 1, 2).contiguous().cpu() for k in NAMES}
-    s["props"] = rpn.forward_batched(s["feats"], HW, heads=s["heads"], return_groups=True)
+    if "x" not in _ORACLE_STAGE:  # the oracle's side does not depend on the HIP arithmetic: once for the three modes
+        x, _ = O.preprocess(O.frames_to_chw(frames), ocfg)
+        _ORACLE_STAGE.update(x=x, ofeats=O.backbone(x, P))
+    s = dict(nf=nf, frames=frames, fr=fr, ocfg=ocfg, ofeats=_ORACLE_STAGE["ofeats"], x=_ORACLE_STAGE["x"], precision=request.param)
+    with arithmetic(ops, request.param):
+        s["x4"] = ops.preprocess_u8hwc(fr, model.pixel_mean, model.pixel_std)
+        s["feats"] = model.backbone.forward_nhwc(s["x4"])
+        rpn = model.proposal_generator
+        s["heads"] = rpn.rpn_head.forward_nhwc([s["feats"][f] for f in rpn.in_features])
+        s["depth"] = model.depth_head.forward_nhwc(s["feats"])
+        s["gfeats"] = {k: s["feats"][k].permute(0, 3, 1, 2).contiguous().cpu() for k in NAMES}
+        s["props"] = rpn.forward_batched(s["feats"], HW, heads=s["heads"], return_groups=True)
+        torch.cuda.synchronize()
     return s
 
 
@@ -842,10 +867,13 @@ def staged_box(staged, hip_model, oracle, oracle_params):
     rh = model.roi_heads
     pb, _pl, _lv, _pos, pc, _g = s["props"]
     lv = [s["feats"][f] for f in rh.box_in_features]
-    pooled = rh.box_pooler.forward_batched(lv, pb, pc)
-    pred = rh.box_predictor(rh.box_head(pooled))
-    rh.box_predictor.test_score_thresh = 0.0
-    det = rh.box_predictor.inference_batched(pred, pb, pc, HW, return_groups=True)
+    from articulation3d_amd import ops as _ops
+    with arithmetic(_ops, s["precision"]):
+        pooled = rh.box_pooler.forward_batched(lv, pb, pc)
+        pred = rh.box_predictor(rh.box_head(pooled))
+        rh.box_predictor.test_score_thresh = 0.0
+        det = rh.box_predictor.inference_batched(pred, pb, pc, HW, return_groups=True)
+        torch.cuda.synchronize()
     return dict(pooled=pooled, pred=pred, det=det, props_cpu=[pb[b, : int(pc[b])].cpu() for b in range(s["nf"])])
 
 
@@ -918,7 +946,10 @@ def test_stage_roi_heads_paste_lsq_and_records(staged, staged_box, hip_model, or
     s, sb, O, P, model = staged, staged_box, oracle, oracle_params, hip_model
     nf, ocfg = s["nf"], s["ocfg"]
     db, dsc, dcl, _dpos, dcnt, _g2 = sb["det"]
-    det = model.roi_heads.given_boxes_batched(s["feats"], BatchedDetections(db, dsc, dcl, dcnt, HW))
+    from articulation3d_amd import ops as _ops
+    with arithmetic(_ops, s["precision"]):
+        det = model.roi_heads.given_boxes_batched(s["feats"], BatchedDetections(db, dsc, dcl, dcnt, HW))
+        torch.cuda.synchronize()
     dets_cpu = [db[b, : int(dcnt[b])].cpu() for b in range(nf)]
     assert det.total == sum(len(d) for d in dets_cpu) == 200
     om = O.mask_head(O.roi_pool_fpn(s["gfeats"], dets_cpu, *ocfg.mask_pool), P)
@@ -1063,7 +1094,10 @@ def test_forward_with_given_boxes_ragged(hip_model, oracle, oracle_params, stage
         i.pred_boxes = Boxes(b.cuda())
         i.pred_classes = torch.zeros(len(b), dtype=torch.int64).cuda()
         insts.append(i)
-    out = model.roi_heads.forward_with_given_boxes(feats, insts)
+    from articulation3d_amd import ops as _ops
+    with arithmetic(_ops, staged["precision"]):
+        out = model.roi_heads.forward_with_given_boxes(feats, insts)
+        torch.cuda.synchronize()
     assert out[0].pred_masks.shape == (3, 1, 28, 28) and out[1].pred_masks.shape == (0, 1, 28, 28)
     ocfg = O.OracleCfg()
     ref = O.plane_head(O.roi_pool_fpn(staged["gfeats"], boxes, *ocfg.plane_pool), P)
