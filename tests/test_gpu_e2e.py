@@ -128,7 +128,7 @@ def test_matched_detections_end_to_end(hip_model, oracle, oracle_params, golden_
     #  (2) every normalised output with its conditioning divided out: |n_hip - n_64| * |r_64|  (n = r / |r|  =>  dn ~ dr / |r|).
     # The quantile rule and the 10x gross-error clause of round 2 are gone: the heavy tail they existed for is exactly the factor
     # 1 / |r|, and (2) removes it detection by detection.
-    for k in ("raw_plane", "raw_rot", "raw_tran", "plane_cond", "rot_axis_cond", "tran_axis_cond"):
+    for k in ("raw_plane_err", "raw_rot_err", "raw_tran_err", "plane_cond", "rot_axis_cond", "tran_axis_cond"):
         hip, cpu = sh["max_" + k], sc["max_" + k]
         assert hip <= max(RAW_FLOOR, K_YARD * cpu), (k, hip, cpu)
     # (equivalently: every normalised output is within  bound / |r_64|  of the exact one -- its own conditioning, nothing more)
