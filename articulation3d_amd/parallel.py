@@ -30,64 +30,159 @@ def gather_records(records: torch.Tensor, rec_count: torch.Tensor, rows: Optiona
 
 
 class GatherHandle:
-    """Result of gather_records_async.  `wait()` makes the current stream wait for the collective and returns
-    (all_records, all_counts); until then the exchange runs on RCCL's own stream, under the next batch's kernels."""
+    """Result of gather_records_async.  Two ways to collect it, both ordered on the CURRENT stream (no host wait beyond the counts):
+      wait_compact() -> (rows [N, F], counts [G*rows] int32): the live records of the whole job, frame-major in rank order -- what
+                        travelled; frame s of rank r is slot r*rows + s, its records start at counts[:slot].sum();
+      wait()         -> (all_records [G*rows, R, F], all_counts [G*rows]): the dense slot layout (dead slots zero)."""
 
-    def __init__(self, all_rec, all_cnt, works, keep):
-        self._out, self._works, self._keep = (all_rec, all_cnt), works, keep
+    def __init__(self, finish, dense_shape):
+        self._finish, self._dense_shape, self._res = finish, dense_shape, None
+
+    def wait_compact(self):
+        if self._res is None:
+            self._res, self._finish = self._finish(), None
+        return self._res
 
     def wait(self):
-        for w in self._works:
-            w.wait()
-        self._works, self._keep = [], None
-        return self._out
+        rows, counts = self.wait_compact()
+        n, R, F = self._dense_shape
+        return scatter_compact(rows, counts, R), counts
 
 
-_blocks_verified = False
+def compact_index(counts, R: int, device) -> torch.Tensor:
+    """Flat slot-row indices (slot * R + r, r < count[slot]) of the live records, frame-major.  counts: host list of ints."""
+    idx = [s * R + r for s, c in enumerate(counts) for r in range(min(int(c), R))]
+    return torch.tensor(idx, device=device, dtype=torch.int64)
+
+
+def scatter_compact(rows: torch.Tensor, counts: torch.Tensor, R: int) -> torch.Tensor:
+    """Live rows [N, F] + per-slot counts -> dense [slots, R, F] (zeros in dead slots)."""
+    n = counts.numel()
+    dense = rows.new_zeros((n * R, rows.shape[1]))
+    if rows.shape[0]:
+        dense[compact_index(counts.tolist(), R, rows.device)] = rows
+    return dense.view(n, R, rows.shape[1])
+
+
+class _LocalHandle(GatherHandle):
+    """Single process: nothing travels.  wait() hands the block back as it is; wait_compact() compacts it (one host read of the counts)."""
+
+    def __init__(self, records, rec_count):
+        self._rec, self._cnt = records, rec_count
+
+    def wait(self):
+        return self._rec, self._cnt
+
+    def wait_compact(self):
+        B, R, F = self._rec.shape
+        idx = compact_index(self._cnt.tolist(), R, self._rec.device)
+        return self._rec.reshape(B * R, F)[idx], self._cnt
+
+
+_verified_blocks = set()
 
 
 def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: Optional[int] = None) -> GatherHandle:
-    """Starts the all-gather of one batch's detection records without blocking the launch stream: the detector's next
-    batch is enqueued while the records travel over xGMI (one collective per batch, overlapped with compute).
+    """All-gather of one batch's detection records in two phases -- counts first, then only the LIVE records.
 
-    `all_gather_into_tensor` needs the SAME block size on every rank, while `shard_range` hands out uneven blocks
-    whenever F % world != 0 (10 frames on 4 ranks: 3,3,3,1).  Pass `rows` = ceil(F / world): the block is zero-padded to
-    that many frames (count 0) before it travels.  Without `rows` the caller guarantees equal blocks; the first call of a
-    process verifies that with one small synchronous all-gather of the block sizes and raises on a mismatch (instead of
-    hanging in RCCL); later calls trust the same batching."""
-    global _blocks_verified
+    The slot layout is [frames, R = 100 slots, F = 798 floats] per rank, but a frame holds D ~ 4 detections: shipping the slots is
+    20 MB per rank and step to every rank (2.6 GB of dense records for a 1024-frame clip on the receiving side), the live records
+    under 1 MB (counts, then payload).
+      phase 1 (here, asynchronous on RCCL's stream, under the next batch's kernels): `rows + 1` int32 per rank = the block's frame
+              count and its per-frame detection counts, zero-padded to `rows` frames;
+      phase 2 (at wait time): every rank compacts its live records, pads them to the largest per-rank total -- known to all from
+              phase 1 -- and one `all_gather_into_tensor` moves them; the receiver drops the padding.
+    `rows` = frames per rank block, the same on every rank (ceil(F / world) for a sharded clip: `shard_range` hands out uneven
+    blocks whenever F % world != 0 -- 10 frames on 4 ranks: 3,3,3,1 -- and shorter blocks are padded with empty frames).  A block
+    LARGER than `rows` cannot travel: every rank learns that from phase 1 and all of them raise together (a local raise before the
+    collective would leave the others hanging in RCCL).  Without `rows` the caller promises equal blocks; the first call per block
+    shape verifies that with one small fixed-size collective and raises on every rank when they differ."""
     if not (dist.is_available() and dist.is_initialized()):
-        return GatherHandle(records, rec_count, [], None)
+        return _LocalHandle(records, rec_count)
     G = dist.get_world_size()
-    rec, cnt = records.contiguous(), rec_count.contiguous()
-    back = None
-    if rec.is_cuda and dist.get_backend() == "gloo":  # test rigs (several ranks on one GPU): gloo moves host memory
-        back = rec.device
-        rec, cnt = rec.cpu(), cnt.cpu()
-    if rows is not None:
-        if rec.shape[0] > rows:
-            raise ValueError(f"block of {rec.shape[0]} frames does not fit rows={rows}")
-        if rec.shape[0] < rows:
-            pad = rows - rec.shape[0]
-            rec = torch.cat([rec, rec.new_zeros((pad,) + tuple(rec.shape[1:]))])
-            cnt = torch.cat([cnt, cnt.new_zeros((pad,))])
-    if not _blocks_verified:
-        mine = torch.tensor([rec.shape[0]], device=rec.device, dtype=torch.int64)
-        sizes = torch.empty((G,), device=rec.device, dtype=torch.int64)
-        dist.all_gather_into_tensor(sizes, mine)
-        sizes = sizes.tolist()
-        if len(set(sizes)) != 1:
-            raise ValueError(f"gather_records: ranks hold blocks of {sizes} frames; pass rows=ceil(F/world) to pad them")
-        _blocks_verified = True
-    all_rec = torch.empty((G * rec.shape[0],) + tuple(rec.shape[1:]), device=rec.device, dtype=rec.dtype)
-    all_cnt = torch.empty((G * cnt.shape[0],), device=cnt.device, dtype=cnt.dtype)
+    rec, cnt = records.contiguous(), rec_count.contiguous().to(torch.int32)
+    B, R, F = rec.shape
+    gloo = dist.get_backend() == "gloo"
+    back = rec.device if (rec.is_cuda and gloo) else None  # test rigs (several ranks on one GPU): gloo moves host memory
     if back is not None:
-        dist.all_gather_into_tensor(all_cnt, cnt)
-        dist.all_gather_into_tensor(all_rec, rec)
-        return GatherHandle(all_rec.to(back), all_cnt.to(back), [], None)
-    w1 = dist.all_gather_into_tensor(all_cnt, cnt, async_op=True)
-    w2 = dist.all_gather_into_tensor(all_rec, rec, async_op=True)
-    return GatherHandle(all_rec, all_cnt, [w1, w2], (rec, cnt))  # inputs stay referenced until the collective is waited for
+        rec, cnt = rec.cpu(), cnt.cpu()
+    dev = rec.device
+    if rows is None:
+        key = (B, R, F)
+        if key not in _verified_blocks:  # fixed-size exchange: well-formed whatever the blocks are
+            sizes = torch.empty((G,), device=dev, dtype=torch.int64)
+            dist.all_gather_into_tensor(sizes, torch.tensor([B], device=dev, dtype=torch.int64))
+            sizes = sizes.tolist()
+            if len(set(sizes)) != 1:
+                raise ValueError(f"gather_records: ranks hold blocks of {sizes} frames; pass rows=ceil(F/world) to pad them")
+            _verified_blocks.add(key)
+        rows = B
+    # ---- phase 1: [frames in the block, count[0..rows)] per rank
+    hdr = torch.zeros((rows + 1,), device=dev, dtype=torch.int32)
+    hdr[0] = B
+    nb = min(B, rows)
+    hdr[1:1 + nb] = cnt[:nb]
+    all_hdr = torch.empty((G * (rows + 1),), device=dev, dtype=torch.int32)
+    hdr_host, ev = None, None
+    if rec.is_cuda:
+        w1 = dist.all_gather_into_tensor(all_hdr, hdr, async_op=True)
+        # the counts reach the host through a side stream that waits for the collective only -- not for whatever the caller
+        # has enqueued on its stream in the meantime (the next batch)
+        side = _side_stream(dev)
+        hdr_host = torch.empty((G * (rows + 1),), dtype=torch.int32, pin_memory=True)
+        with torch.cuda.stream(side):
+            w1.wait()
+            hdr_host.copy_(all_hdr, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+    else:
+        dist.all_gather_into_tensor(all_hdr, hdr)
+
+    keep_alive = [hdr, all_hdr, rec, cnt]  # referenced until the exchange has been collected
+
+    def finish():
+        keep_alive.clear()
+        if ev is not None:
+            ev.synchronize()
+            h = hdr_host.view(G, rows + 1)
+        else:
+            h = all_hdr.view(G, rows + 1)
+        sizes = h[:, 0].tolist()
+        if max(sizes) > rows:  # seen by every rank: all of them raise
+            raise ValueError(f"gather_records: ranks hold blocks of {sizes} frames but rows={rows}; pass rows=ceil(F/world)")
+        counts = h[:, 1:].contiguous()                      # [G, rows]
+        live = [int(v) for v in counts.clamp(max=R).sum(1).tolist()]
+        mx = max(live)
+        all_cnt = counts.reshape(-1).to(dev)
+        if mx == 0:
+            out = (rec.new_zeros((0, F)), all_cnt)
+        else:
+            mine = compact_index(counts[dist.get_rank()].tolist()[:B], R, dev)
+            send = rec.new_zeros((mx, F))
+            if mine.numel():
+                send[: mine.numel()] = rec.view(B * R, F)[mine]
+            got = rec.new_empty((G * mx, F))
+            if rec.is_cuda:
+                dist.all_gather_into_tensor(got, send, async_op=True).wait()  # (the current stream waits; the host does not)
+            else:
+                dist.all_gather_into_tensor(got, send)
+            keep = torch.tensor([g * mx + i for g in range(G) for i in range(live[g])], device=dev, dtype=torch.int64)
+            out = (got[keep], all_cnt)
+        if back is not None:
+            out = (out[0].to(back), out[1].to(back))
+        return out
+
+    return GatherHandle(finish, (G * rows, R, F))
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, group=None) -> float:

@@ -41,8 +41,11 @@ PIPE_FLOPS_PER_FMA = {"f32": 1.0, "bf16": 1.0, "bf16x6": 6.0, "f16x3": 3.0, "non
 DTYPES = {
     "bf16x3": "f32 (fp32 tensors and accumulation; every product formed from exact 3-way bf16 operand splits, six bf16 MFMAs per k step: "
               "error vs float64 <= the fp32-input MFMA's, the whole parity suite runs in this arithmetic)",
-    "fp16x2": "f32 (fp32 tensors and accumulation; every product formed from a two-way fp16 split of each operand, scaled by a power of two "
-              "per image: three fp16 MFMAs per k step, error vs float64 <= the fp32-input MFMA's)",
+    "fp16x2": "f32 storage and accumulation; operands enter the matrix pipe with a 22-bit significand under ONE power-of-two block exponent "
+              "per image (per ROI behind the poolers, per layer for filters): x*s = h + l in fp16, three fp16 MFMAs per k step (h.h + h.l + l.h). "
+              "Elementwise law |y - y64| <= c (2^-22 sum|x||w| + 2^-39 (max|x| sum|w| + max|w| sum|x|)): fp32-grade while an output's "
+              "receptive field lies within 2^18 of its image's maximum (tests/test_gpu_precision.py); ROIs fainter than 2^-16 of their pyramid "
+              "level are counted (roi_out_of_window)",
     "fp32": "f32 (fp32-input MFMA)",
     "bf16": "bf16 arithmetic (fp32 accumulate, fp32 tensors) -- opt-in autocast mode, not comparable with the f32 figures",
 }
@@ -166,7 +169,9 @@ def cpu_baseline(model, frames_u8, score_thresh: float, nframes: int, gpu_result
     matched = dict(matched=bool(all(m["matched"] for m in ms)),
                    definition="per frame: equal detection count; every oracle detection pairs with a HIP detection of the same class, "
                               "box within 5e-3 px, score within 1e-4, rank exchanged only between scores tied to 2e-4 "
-                              "(oracle/matching.py); continuous head outputs are reported, their bound is tests/test_gpu_e2e.py's float64 yardstick",
+                              "(oracle/matching.py); continuous head outputs are reported -- incl. the RAW head vectors before F.normalize "
+                              "(max_raw_*_err, no 1/|r| amplification) and the normalised ones weighted by their conditioning (max_*_cond), "
+                              "here against the oracle's fp32 run; their bound is tests/test_gpu_e2e.py's float64 yardstick",
                    frames=len(ms), frames_matched=sum(1 for m in ms if m["matched"]),
                    **{k: v for k, v in summ.items() if k.startswith("max_") or k in ("detections", "detections_gpu", "mask_hamming_px")})
     base = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
@@ -234,14 +239,14 @@ def main():
     def step(given=None, src=frames):
         out = model.inference_batched(src, given_boxes=given)
         if use_dist:
-            pending.append(gather_records_async(out.records, out.rec_count))
+            pending.append(gather_records_async(out.records, out.rec_count, rows=out.records.shape[0]))
             if len(pending) > 1:
-                pending.pop(0).wait()
+                pending.pop(0).wait_compact()  # (counts first, then the live records only: parallel.gather_records_async)
         return out
 
     def drain():
         while pending:
-            pending.pop(0).wait()
+            pending.pop(0).wait_compact()
 
     def barrier():
         if use_dist:
@@ -371,8 +376,8 @@ def main():
         "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed_fp32_equivalent": round(dexec / dn / 1e9, 3),
         "avg_launch_gflop_algorithmic": round(dflops / dn / 1e9, 3), "share_of_step_time": round(dsec / elapsed, 3),
     }
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (3, 2)) if os.path.exists(q)), "")
+    if tpath:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
         rname = rocprof_name(dname)
         roofline["rocprof_name"] = rname
@@ -408,18 +413,29 @@ def main():
         **extra,
         **({"alt_modes": alt} if alt else {}),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import matching as M
+    result["roi_out_of_window"] = ops.roi_window_count(dev) if args.precision == "fp16x2" else None  # (the window monitor: 0 expected)
+    if not args.no_cpu_baseline:
+        # The CPU leg runs on rank 0 AFTER the timed region, at every N (the other ranks wait at the barrier below, their GPUs idle):
+        # the oracle on the host cores, and the HIP detections of the same frames compared with its detections.
+        if rank == 0:
+            from oracle import matching as M
 
-        n_cmp = 3 + args.cpu_frames  # rank 0's clip starts with exactly the frames the CPU leg runs (same seed, same generator)
-        cmp_np = synthetic_frames(n_cmp, 2020)
-        cmp_out = model.inference_batched(torch.from_numpy(cmp_np).to(dev), want_masks=True)
-        torch.cuda.synchronize()
-        base, matched = cpu_baseline(model, cmp_np, args.score_thresh, args.cpu_frames, M.gpu_frame_results(cmp_out))
-        result["cpu_baseline"] = base
-        result["matched_detections"] = matched
-        result["gpu_over_cpu"] = round(fps / base["value"], 1)
-        result["gpu_over_cpu_batch8"] = round(fps / base["batch8_frames_per_s"], 1)
+            n_cmp = 3 + args.cpu_frames  # rank 0's clip starts with exactly the frames the CPU leg runs (same seed, same generator)
+            cmp_np = synthetic_frames(n_cmp, 2020)
+            heads = model.roi_heads
+            heads.plane_head.keep_raw = heads.axis_head.keep_raw = True  # checker hook: the head vectors before F.normalize
+            try:
+                cmp_out = model.inference_batched(torch.from_numpy(cmp_np).to(dev), want_masks=True)
+                torch.cuda.synchronize()
+            finally:
+                heads.plane_head.keep_raw = heads.axis_head.keep_raw = False
+            base, matched = cpu_baseline(model, cmp_np, args.score_thresh, args.cpu_frames, M.gpu_frame_results(cmp_out))
+            result["cpu_baseline"] = base
+            result["matched_detections"] = matched
+            result["gpu_over_cpu"] = round(fps / base["value"], 1)
+            result["gpu_over_cpu_batch8"] = round(fps / base["batch8_frames_per_s"], 1)
+        if use_dist:
+            barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

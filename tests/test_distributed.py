@@ -43,6 +43,10 @@ def _worker(rank, world, port, q):
     h1, h2 = gather_records_async(rec, cnt), gather_records_async(rec * 2, cnt)
     (r1, c1), (r2, c2) = h1.wait(), h2.wait()
     ok = ok and torch.equal(r1, all_rec) and torch.equal(r2, all_rec * 2) and torch.equal(c1, all_cnt) and torch.equal(c2, all_cnt)
+    # what travels is the LIVE records only: [sum of counts, F], frame-major, in rank order
+    rows, cc = gather_records_async(rec, cnt).wait_compact()
+    want = [f + 0.1 * r for f in range(F_) for r in range(f % 3)]
+    ok = ok and rows.shape == (len(want), REC) and torch.equal(cc, all_cnt) and all(abs(float(a) - b) < 1e-6 for a, b in zip(rows[:, 4], want))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -92,6 +96,11 @@ def _uneven_worker(rank, world, port, q):
         ok = False
     except ValueError as e:
         ok = "rows=" in str(e)
+    try:  # a block that does not fit `rows`: every rank learns it from the counts exchange and ALL raise (nobody hangs) --
+        gather_records(rec, cnt, rows=per - 1)  # rank 3's own block (1 frame) fits, it must raise too
+        ok = False
+    except ValueError as e:
+        ok = ok and "rows=" in str(e)
     all_rec, all_cnt = gather_records(rec, cnt, rows=per)
     ok = ok and all_rec.shape == (world * per, R, REC) and all_cnt.shape == (world * per,)
     slots = [r * per + i for r in range(world) for i in range(shard_range(F_, r, world)[1] - shard_range(F_, r, world)[0])]
@@ -119,9 +128,17 @@ def test_gather_records_uneven_shards_gloo_world4():
 def test_gather_records_single_process_is_identity():
     from articulation3d_amd.parallel import gather_records
 
+    from articulation3d_amd.parallel import gather_records_async, scatter_compact
+
     a, b = torch.zeros(2, 3, 798), torch.zeros(2, dtype=torch.int32)
     x, y = gather_records(a, b)
     assert x is a and y is b
+    a = torch.arange(2 * 3 * 798, dtype=torch.float32).view(2, 3, 798)
+    b = torch.tensor([2, 1], dtype=torch.int32)
+    rows, cnt = gather_records_async(a, b).wait_compact()
+    assert rows.shape == (3, 798) and torch.equal(rows[0], a[0, 0]) and torch.equal(rows[1], a[0, 1]) and torch.equal(rows[2], a[1, 0])
+    dense = scatter_compact(rows, cnt, 3)
+    assert torch.equal(dense[0, :2], a[0, :2]) and torch.equal(dense[1, :1], a[1, :1]) and float(dense[0, 2].abs().sum() + dense[1, 1:].abs().sum()) == 0
 
 
 def _grad_worker(rank, world, port, q):

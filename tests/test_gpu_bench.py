@@ -86,13 +86,48 @@ def test_inference_script_sharded_over_two_ranks(tmp_path):
 def test_bench_spawns_its_ranks(tmp_path):
     """`python bench.py --gpus 2` outside torchrun must launch two ranks and report n_gpus = 2 (the flag was dead)."""
     r = _run(["bench.py", "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "4",
-              "--no-cpu-baseline", "--no-alt-modes", "--no-operating-points"])
+              "--cpu-frames", "2", "--no-alt-modes", "--no-operating-points"], timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    # an N > 1 line carries the CPU leg and the matched-detections check too (rank 0 runs them after the timed region)
+    assert d["cpu_baseline"]["cores"] >= 1 and d["matched_detections"]["frames"] == 5 and d["matched_detections"]["matched"] is True
     # a launcher / flag disagreement is refused instead of mislabelled
     r = _run(["bench.py", "--gpus", "1", "--steps", "1"], env=dict(ENV, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def _two_gpus():
+    import torch
+
+    return torch.cuda.device_count() >= 2  # (does not initialise HIP)
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs: RCCL gives every rank its own device")
+def test_two_real_rccl_ranks_bench_and_inference(tmp_path):
+    """On a box with >= 2 GPUs: `bench.py --gpus 2` over RCCL (two ranks, one GPU each, the two-phase gather of the records, the CPU
+    leg and the matched-detections check on rank 0 while rank 1 waits) and `torchrun -n 2 tools/inference.py` over nccl against the
+    single-process run.  Skips itself on the 1-GPU boxes of the development pool."""
+    import socket
+
+    r = _run(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--cpu-frames", "2", "--no-alt-modes", "--no-operating-points"],
+             timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 16 and "cpu_baseline" in d and d["matched_detections"]["matched"] is True
+    common = ["--config", "configs/planercnn_inference.yaml", "--input", "synthetic:7", "--random-init", "--calibrate-bn",
+              "--conf-threshold", "0.3", "--batch", "2"]
+    opts = ["MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.3"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    assert _run(["tools/inference.py", *common, "--output", str(one), *opts]).returncode == 0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+              "tools/inference.py", *common, "--output", str(two), "--dist-backend", "nccl", *opts])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.load(open(one / "predictions.json")) == json.load(open(two / "predictions.json"))
 
 
 def test_bench_single_rank_rccl_gather(tmp_path):
@@ -122,6 +157,8 @@ def test_bench_default_line_has_the_contract_fields():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["batch8_frames_per_s"] > 0 and cb["os_cpu_count"] >= cb["cores"]
     md = d["matched_detections"]
     assert md["frames"] == 5 and md["matched"] is True, md
+    assert all(k in md for k in ("max_raw_plane_err", "max_raw_rot_err", "max_raw_tran_err", "max_plane_cond", "max_tran_axis_cond")), md
+    assert d["roi_out_of_window"] == 0 and "22-bit significand" in d["dtype"] and "block exponent" in d["dtype"]
 
 
 def test_first_small_batch_of_a_process_equals_the_steady_state():

@@ -33,25 +33,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def read_frames(path: str) -> np.ndarray:
-    """-> uint8 [F,Hs,Ws,3] RGB at the SOURCE size (no host-side resize)."""
+def count_frames(path: str) -> int:
+    """Number of frames of a clip without decoding it (npy header / directory listing)."""
+    if path.startswith("synthetic:"):
+        return int(path.split(":")[1].split("x")[0])
+    if path.endswith(".npy"):
+        return int(np.load(path, mmap_mode="r").shape[0])
+    if path.endswith(".npz"):
+        z = np.load(path)
+        return int(z[list(z.keys())[0]].shape[0])
+    if os.path.isdir(path):
+        return len([n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg"))])
+    return 1
+
+
+def read_frames(path: str, lo: int = 0, hi: int = None) -> np.ndarray:
+    """-> uint8 [hi-lo,Hs,Ws,3] RGB at the SOURCE size (no host-side resize): frames lo .. hi-1 of the clip (default: all).  Under
+    torchrun every rank reads only its own block (memory-mapped .npy, per-file image decode)."""
     from PIL import Image
+
+    sl = slice(lo, hi)
 
     if path.startswith("synthetic:"):
         from articulation3d_amd.utils.synthetic import synthetic_frames
 
         spec = path.split(":")[1].split("x")
         n, h, w = int(spec[0]), (int(spec[1]) if len(spec) == 3 else 480), (int(spec[2]) if len(spec) == 3 else 640)
-        return synthetic_frames(n, h=h, w=w)[..., ::-1].copy()  # generated BGR -> RGB, flipped back on the device
+        return synthetic_frames(n, h=h, w=w)[sl][..., ::-1].copy()  # generated BGR -> RGB, flipped back on the device
     if path.endswith((".mp4", ".avi", ".mov")):
         raise SystemExit("no video decoder in this environment (cv2 / imageio absent): pass a .npy of RGB frames or a directory of images")
     if path.endswith(".npy"):
-        frames = np.load(path)
+        frames = np.load(path, mmap_mode="r")[sl]
     elif path.endswith(".npz"):
         z = np.load(path)
-        frames = z[list(z.keys())[0]]
+        frames = z[list(z.keys())[0]][sl]
     elif os.path.isdir(path):
-        names = sorted(n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg")))
+        names = sorted(n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg")))[sl]
         frames = np.stack([np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names])
     else:
         frames = np.asarray(Image.open(path).convert("RGB"))[None]
@@ -110,14 +127,22 @@ def main():
         torch.manual_seed(2020)  # every rank (and every run) draws the same initialisation
     branch = PlaneRCNN_Branch(cfg, load_weights=not args.random_init)
     model = branch.predictor.model
-    frames_rgb = read_frames(args.input)
+    from articulation3d_amd.parallel import shard_range
+
+    n_frames = count_frames(args.input)
+    lo, hi = shard_range(n_frames, rank, world)
+    frames_rgb = read_frames(args.input, lo, hi)  # this rank's block only (rank 0 reads the rest later, for the optimiser)
     if args.calibrate_bn:
+        if lo > 0:  # the statistics come from the FIRST two frames of the clip on every rank
+            frames_rgb_head = read_frames(args.input, 0, 2)
+        else:
+            frames_rgb_head = frames_rgb[:2]
         from articulation3d_amd import ops
         from articulation3d_amd.utils.synthetic import calibrate_batchnorm
 
-        _x4, head = ops.preprocess_resize_u8(torch.from_numpy(frames_rgb[:2]).to(model.device), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), want_u8=True)
+        _x4, head = ops.preprocess_resize_u8(torch.from_numpy(np.ascontiguousarray(frames_rgb_head)).to(model.device), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), want_u8=True)
         calibrate_batchnorm(model, head.flip(-1).contiguous())  # resized RGB -> BGR uint8
-    preds = detect_clip(model, frames_rgb, batch=args.batch, conf_threshold=args.conf_threshold, source_rgb=True)
+    preds = detect_clip(model, frames_rgb, batch=args.batch, conf_threshold=args.conf_threshold, source_rgb=True, num_frames=n_frames)
     if world > 1:
         import torch.distributed as dist
 
@@ -125,6 +150,7 @@ def main():
         dist.destroy_process_group()
         if rank != 0:  # every rank holds the gathered detections; the temporal stage and the files are rank 0's
             return
+        frames_rgb = read_frames(args.input)  # the optimiser's sweeps look at the whole clip
     planes = track_planes(preds)
     opt_preds = optimize_planes(preds, planes, "3dc", frames=frames_rgb)
 
