@@ -68,8 +68,17 @@ constexpr int xw_lds_bytes(int NP) { return (2 * NP * XW_PX + 3 * NP * XW_PW) * 
 
 // F16: the fp16x2 arithmetic (a3d_conv_desc.precision == 3) -- two operand planes, three product terms (h.h, h.l, l.h), activation rows
 // scaled per image from d.in_amax, w_x3 = the filter pre-split by a3d_split_f16x2_chunk with d.w_scale.
-template <bool F16>
+// PH4 (fp16x2 only; a3d_conv_desc.phase == 5): ALL FOUR output phases of a 3x3 pad-1 convolution over a nearest-x2 upsampled input in
+// one launch.  The GEMM is a 3x3 convolution on the source grid whose 4 Cout columns are the phases' pre-summed 2x2 filters placed
+// at their positions inside the 3x3 neighbourhood (phase (dy, dx) uses taps kh - dy, kw - dx in {0, 1}; the other taps are zero).
+// Columns are ordered so that every wave holds all four phases: column j = 128 g + 32 phase + c  <->  output channel 32 g + c,
+// i.e. channel block n of a wave IS phase n.  A tap that lies outside a phase's window contributes nothing, so the wave skips that
+// block's MFMAs (uniform branch): corner taps multiply one block, edge taps two, the centre all four -- exactly the 16 tap-phase
+// products of the four-launch form, in the same order per output (bit-identical results), but every activation chunk is loaded and
+// split ONCE for the phases that share it (9 tap loads instead of 16) and all waves do equal work on every tap.
+template <bool F16, bool PH4 = false>
 __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
+    static_assert(!PH4 || F16, "the fused four-phase form belongs to the fp16x2 arithmetic");
     constexpr int NP = F16 ? 2 : 3;
     constexpr int XW_XST = NP * XW_PX, XW_WST = NP * XW_PW;  // one stage
     constexpr int TM = 2, TN = 4, BM = XW_BM, BN = XW_BN, BKT = XW_BK, LKB = XW_BK;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         const int b = mm / hw, r = mm - b * hw;
         const int oh = r / d.Wo, ow = r - oh * d.Wo;
         int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
-        if (d.phase) {  // 2x2 taps of output phase (dy,dx) of an upsampled 3x3 conv, on the source grid (conv_gemm_v2.hip)
+        if (!PH4 && d.phase) {  // 2x2 taps of output phase (dy,dx) of an upsampled 3x3 conv, on the source grid (conv_gemm_v2.hip)
             ih0 = oh - 1 + ((d.phase - 1) >> 1);
             iw0 = ow - 1 + ((d.phase - 1) & 1);
         }
@@ -244,10 +253,48 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     }
 
     int wst = 0;  // W stage of the chunk being multiplied
+    // PH4: the tap of the chunk being multiplied and the phases (= channel blocks) whose 2x2 window holds it
+    const int cpt = PH4 ? CinT / BKT : 1;  // chunks per tap
+    int mul_c = 0, mul_tap = 0;
+    auto tap_phases = [](const int tap) -> unsigned {
+        const int th = tap / 3, tw = tap - 3 * th;
+        const unsigned rows = th == 0 ? 0x3u : (th == 1 ? 0xFu : 0xCu);  // phases with dy <= kh <= dy + 1 (bit = 2 dy + dx)
+        const unsigned cols = tw == 0 ? 0x5u : (tw == 1 ? 0xFu : 0xAu);  // ... and dx <= kw <= dx + 1
+        return rows & cols;
+    };
     // one iteration; xst = X stage of chunk c (compile-time), Bc / Bn = the b sets of chunk c / c+1, xs = the staged chunk c+1
     auto iteration = [&](const int xst, FragA &A0, FragA &A1, FragB &Bc, FragB &Bn, f32x4 (&xs)[XR]) {
         const int wnext = wst == 2 ? 0 : wst + 1;
         Split s;
+        if constexpr (PH4) {
+            // the same chunk schedule with each channel block's three terms behind a wave-uniform test (no scheduling fences: the two
+            // waves of a SIMD cover each other's loader work)
+            const unsigned act = __builtin_amdgcn_readfirstlane(tap_phases(mul_tap));
+            if (++mul_c == cpt) {
+                mul_c = 0;
+                ++mul_tap;
+            }
+            if (act & 1u) { XW_TERM(0, A0, Bc, 0, 0) XW_TERM(0, A0, Bc, 0, 1) XW_TERM(0, A0, Bc, 1, 0) }
+            split(xs[0], 0, s);
+            put(xst ^ 1, 0, s);
+            rdA(A1, wst, 1);
+            if (act & 2u) { XW_TERM(1, A1, Bc, 0, 0) XW_TERM(1, A1, Bc, 0, 1) XW_TERM(1, A1, Bc, 1, 0) }
+            split(xs[1], 1, s);
+            put(xst ^ 1, 1, s);
+            rdA(A0, wst, 2);
+            __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();
+            if (act & 4u) { XW_TERM(2, A0, Bc, 0, 0) XW_TERM(2, A0, Bc, 0, 1) XW_TERM(2, A0, Bc, 1, 0) }
+            dma_w();
+            load_chunk(xs);
+            rdA(A1, wst, 3);
+            rdB(Bn, xst ^ 1, 0);
+            rdB(Bn, xst ^ 1, 1);
+            if (act & 8u) { XW_TERM(3, A1, Bc, 0, 0) XW_TERM(3, A1, Bc, 0, 1) XW_TERM(3, A1, Bc, 1, 0) }
+            rdA(A0, wnext, 0);
+            wst = wnext;
+            return;
+        }
         // ---- n = 0
         XW_TERM(0, A0, Bc, 0, 0)
         split(xs[0], 0, s);
@@ -377,6 +424,12 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
                 }
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
                 vmax = fmaxf(vmax, a3d_absmax4(v));
+                if constexpr (PH4) {  // column 128 g + 32 phase + c -> pixel (2 oh + dy, 2 ow + dx), channel 32 g + c of y [B, 2Ho, 2Wo, Cout / 4]
+                    const int co = (n >> 7) * 32 + (n & 31), co_n = d.Cout >> 2;
+                    const size_t row = ((size_t)b * (2 * d.Ho) + (2 * oh + (ni >> 1))) * (size_t)(2 * d.Wo) + (2 * ow + (ni & 1));
+                    *reinterpret_cast<f32x4 *>(d.y + row * co_n + co) = v;
+                    continue;
+                }
                 store_out(d, v, m, n, b, oh, ow);
             }
         }
@@ -391,7 +444,29 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 // Returns A3D_ERR_UNSUPPORTED when the layer should take conv_x3_kernel (conv_bf16x3.hip): no pre-split weights, a shallow reduction,
 // a narrow or small problem (256-wide channel tiles mostly padding, or too few 256 x 256 tiles to fill the 256 CUs twice), 32-bit
 // offset limits.
+// The fused four-phase form (a3d_conv_desc.phase == 5): see conv_x3w_kernel's PH4.
+static int launch_ph4(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return A3D_ERR_ARG;
+    if (d->stem || d->ups || d->m_dev || d->splitk != 1 || d->res || d->gate || d->pixshuf) return A3D_ERR_ARG;
+    if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_ARG;
+    const int CinT = d->Cin + d->Cin2;
+    if ((d->Cin & 15) || (CinT & 31) || d->Kpad != 9 * CinT || (d->Cout & 127)) return A3D_ERR_ARG;  // (Cout = 4 x real channels, 32 | real channels)
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + XW_BM - 1) / XW_BM, ntiles = (d->Cout + XW_BN - 1) / XW_BN;
+    static a3d_attr_once attr_ph4;
+    if (attr_ph4.needed()) {
+        if (hipFuncSetAttribute((const void *)conv_x3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(2)) != hipSuccess) return A3D_ERR_LAUNCH;
+        attr_ph4.mark();
+    }
+    a3d_note_variant("conv_h2w_kernel ph4");
+    hipLaunchKernelGGL((conv_x3w_kernel<true, true>), dim3(mtiles * ntiles, 1), dim3(512), xw_lds_bytes(2), s, *d, M, ntiles, mtiles * ntiles);
+    return a3d_check_launch();
+}
+
 int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->phase == 5) return launch_ph4(d, s);
     if (!d->w_x3 || d->tune == 8) return A3D_ERR_UNSUPPORTED;
     if (d->stem || d->ups || d->m_dev || d->splitk < 1) return A3D_ERR_UNSUPPORTED;
     if (d->splitk > 1 && (!d->workspace || d->phase || d->gate)) return A3D_ERR_UNSUPPORTED;

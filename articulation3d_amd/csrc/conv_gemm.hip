@@ -220,7 +220,7 @@ static int conv_check(const a3d_conv_desc *d) {
         if (d->Kpad < d->KH * d->KW * (d->Cin + d->Cin2)) return A3D_ERR_ARG;
     }
     if (d->pixshuf && (d->Cout & 15)) return A3D_ERR_ARG;
-    if (d->phase < 0 || d->phase > 4) return A3D_ERR_ARG;
+    if (d->phase < 0 || d->phase > 5 || (d->phase == 5 && d->precision != 3)) return A3D_ERR_ARG;  // (5: the fused four-phase form, fp16x2 only)
     if (d->gate && (d->pixshuf || d->phase)) return A3D_ERR_ARG;
     if (d->splitk > 1 && !d->workspace) return A3D_ERR_ARG;
     if ((size_t)d->B * d->H * d->W >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;

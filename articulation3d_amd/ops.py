@@ -183,6 +183,29 @@ def pack_conv_ups_phases(weight: torch.Tensor, bias=None, bn=None, act=ACT_NONE,
     return out
 
 
+def pack_conv_ups_fused(phases: Sequence[PackedConv]) -> Optional[PackedConv]:
+    """The four phase filters of pack_conv_ups_phases as ONE 3x3 source-grid convolution with 4 x Cout columns (a3d_conv_desc.phase
+    == 5): column 128 g + 32 p + c = phase p of output channel 32 g + c, whose 2x2 taps sit at rows kh - dy, columns kw - dx of
+    the 3x3 neighbourhood; scale / shift replicated in the same column order.  None when the channel count does not fit (32 | Cout)."""
+    p0 = phases[0]
+    Cout, CinT = p0.cols, p0.Cin
+    if Cout % 32 or CinT % 32 or any(q.cols != Cout or q.Cin != CinT or q.phase != i + 1 for i, q in enumerate(phases)):
+        return None
+    dev = p0.w.device
+    w = torch.zeros((4 * Cout, 3, 3, CinT), device=dev, dtype=torch.float32)
+    co = torch.arange(Cout, device=dev)
+    for ph, q in enumerate(phases):
+        dy, dx = ph >> 1, ph & 1
+        col = (co // 32) * 128 + 32 * ph + (co % 32)
+        w[col, dy:dy + 2, dx:dx + 2, :] = q.w[:Cout].view(Cout, 2, 2, CinT)
+    col_of = torch.empty(4 * Cout, dtype=torch.int64, device=dev)  # real channel of every GEMM column
+    j = torch.arange(4 * Cout, device=dev)
+    col_of = (j // 128) * 32 + (j % 32)
+    scale = None if p0.scale is None else p0.scale[col_of].contiguous()
+    shift = None if p0.shift is None else p0.shift[col_of].contiguous()
+    return PackedConv(w.reshape(4 * Cout, 9 * CinT).contiguous(), scale, shift, 3, 3, 1, 1, CinT, 4 * Cout, 9 * CinT, p0.act, phase=5, presplit=True)
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
@@ -362,7 +385,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         Ho_ = x.shape[1] if p.phase else (Hl_ + 2 * p.pad - p.KH) // p.stride + 1
         Wo_ = x.shape[2] if p.phase else (Wl_ + 2 * p.pad - p.KW) // p.stride + 1
         per_in = x.shape[1] * x.shape[2] * max(x.shape[3], 0 if x2 is None else x2.shape[3]) * 4
-        per_out = Ho_ * Wo_ * p.cols * 4 * (4 if p.phase else 1) * max(1, int(splitk))
+        per_out = Ho_ * Wo_ * p.cols * 4 * (4 if 0 < p.phase < 5 else 1) * max(1, int(splitk))
         per_v = ((Hl_ + 1) // 2) * ((Wl_ + 1) // 2) * (x.shape[3] + (0 if x2 is None else x2.shape[3])) * 4 if p.w_wino is not None else 0
         per = max(per_in, per_out, per_v, 1)
         if B * per > _ADDR_LIMIT:
@@ -422,6 +445,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     if p.phase:
         assert not ups and out is not None, "phase convs run on the source grid and fill a shared [B,2H,2W,C] output"
         Ho, Wo = H, W
+        if p.phase == 5:
+            assert precision == 3 and tuple(out.shape) == (B, 2 * H, 2 * W, p.cols // 4), "the fused four-phase form is an fp16x2 launch"
     if out is None:
         shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
@@ -591,7 +616,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
-        executed = 2.0 * B * Ho * Wo * p.cols * k_real
+        executed = 2.0 * B * Ho * Wo * p.cols * (4 * p.Cin if p.phase == 5 else k_real)  # (fused phases: 4 of the 9 taps per column)
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
         CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)]))
         return out
@@ -599,10 +624,26 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     return out
 
 
-def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3 pad-1 conv over the nearest-x2 upsampling of (x || x2), as four source-grid 2x2 convs (pack_conv_ups_phases)."""
+UPS_FUSED = os.environ.get("A3D_UPS_FUSED", "1") != "0"  # (False: always the four-launch form; same bits)
+UPS_FUSED_MIN_BLOCKS = int(os.environ.get("A3D_UPS_FUSED_MIN_BLOCKS", "256"))
+
+
+def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None, fused: Optional[bool] = None) -> torch.Tensor:
+    """3x3 pad-1 conv over the nearest-x2 upsampling of (x || x2), as four source-grid 2x2 convs (pack_conv_ups_phases) -- in the
+    default arithmetic as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5, conv_x3w_kernel's PH4) wherever its 256 x
+    256 blocks fill the chip at least once; smaller maps keep the four narrow launches.  The two forms agree bit for bit
+    (test_fused_upsampled_conv_equals_the_four_phase_launches), so the choice may depend on the batch."""
     B, H, W, _ = x.shape
     out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
+    if fused is None:
+        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and (-(-(B * H * W) // 256)) * (-(-4 * phases[0].cols // 256)) >= UPS_FUSED_MIN_BLOCKS
+    if fused:
+        pf = getattr(phases[0], "_fused", None)
+        if pf is None:
+            pf = pack_conv_ups_fused(phases)
+            phases[0]._fused = pf if pf is not None else False
+        if pf:
+            return conv2d(x, pf, x2=x2, out=out, precision=3)
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out

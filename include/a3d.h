@@ -97,7 +97,14 @@ typedef struct a3d_conv_desc {
                          nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
                          taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
                          phases write the interleaved pixels (2oh+dy, 2ow+dx) of y [B,2Ho,2Wo,Cout] -- 4/9 of the FLOPs
-                         of convolving the upsampled tensor (depth decoder, depth_head.py:40-46)                   */
+                         of convolving the upsampled tensor (depth decoder, depth_head.py:40-46).
+                         5 = ALL FOUR phases in one launch (fp16x2 only, precision 3 with w_x3): KH = KW = 3, stride 1, pad 1 on
+                         the source grid, Cout = 4 x the real channel count C (32 | C), y [B,2Ho,2Wo,C]; GEMM column
+                         128 g + 32 p + c holds phase p = 2 dy + dx of output channel 32 g + c, its filter = that phase's
+                         pre-summed 2x2 taps at rows kh - dy, columns kw - dx of the 3x3 neighbourhood (zero elsewhere;
+                         scale / shift in the same column order).  The kernel skips the zero blocks: the 16 tap-phase
+                         products of the four-launch form in the same order per output -- bit-identical -- with every
+                         activation chunk loaded and split once for the phases that share it (round 3)                */
     const float *w_wino; /* optional Winograd-domain weights U = G g G^T, [16][Cout][Cin+Cin2] (3x3 s1 p1 only):
                             when given (and workspace holds a3d_conv_workspace_bytes) the layer runs as
                             F(2x2,3x3): 2.25x fewer MFMA cycles, same result within fp32 rounding           */

@@ -585,6 +585,35 @@ def test_upsampled_conv_as_four_source_grid_phases(ops):
     assert rel(y.permute(0, 3, 1, 2), ref) < 5e-6
 
 
+@pytest.mark.parametrize("case", [(3, 30, 40, 128, 128, 128), (2, 61, 79, 256, 0, 64), (5, 15, 20, 256, 256, 128), (1, 8, 10, 128, 128, 32)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_fused_upsampled_conv_equals_the_four_phase_launches(ops, case):
+    """The depth decoder's upsampled convs as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5: every wave holds all
+    four phases and skips the tap-phase blocks that are zero): outputs and recorded maxima equal the four-launch form bit for bit,
+    and both are fp32-grade against the float64 convolution of the upsampled tensor."""
+    B, H, W, C1, C2, Cout = case
+    torch.manual_seed(13)
+    a = torch.randn(B, H, W, C1, device="cuda") * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+    c2 = torch.randn(B, H, W, C2, device="cuda") if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5)
+    b = torch.randn(Cout) * 0.1
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-3)
+    phases = ops.pack_conv_ups_phases(w, b, bn, ops.ACT_LEAKY)
+    four = ops.conv2d_ups(a, phases, x2=c2, fused=False)
+    assert ops.last_conv_variant().startswith("conv_h2_kernel")
+    one = ops.conv2d_ups(a, phases, x2=c2, fused=True)
+    assert ops.last_conv_variant() == "conv_h2w_kernel ph4", ops.last_conv_variant()
+    assert one.shape == (B, 2 * H, 2 * W, Cout)
+    assert torch.equal(one, four) and torch.equal(one._a3d_amax, four._a3d_amax)
+    xin = a if c2 is None else torch.cat([a, c2], 3)
+    up = F.interpolate(xin.permute(0, 3, 1, 2).double(), scale_factor=2, mode="nearest")
+    ref = F.batch_norm(F.conv2d(up, w.double().cuda(), b.double().cuda(), padding=1), bn[2].double().cuda(), bn[3].double().cuda(),
+                       bn[0].double().cuda(), bn[1].double().cuda(), False, 0.0, 1e-3)
+    ref = F.leaky_relu(ref, 0.01).permute(0, 2, 3, 1)
+    for i in range(B):
+        assert float((one[i].double() - ref[i]).norm() / ref[i].norm()) < 2e-6
+
+
 @pytest.mark.parametrize("splitk", [1, 7, 64])
 def test_linear_splitk_chw_reorder(ops, splitk):
     torch.manual_seed(4)

@@ -17,8 +17,8 @@ for B, H, W, Cin, Cout in SHAPES:
     x = torch.randn(B, H, W, Cin, device="cuda")
     pk = ops.pack_conv(torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_RELU)
     # (the two forms are timed in turn, one call each per round: timed one after the other, the second reads 10-15 % slow)
-    kws = (dict(wino=True), dict(wino=False))
-    res, ts = [], [[], []]
+    kws = (dict(wino=True), dict(wino=False), dict(wino=False, tune=9))  # (tune 9: the wide 256 x 256 direct kernel, whatever K)
+    res, ts = [], [[] for _ in kws]
     for kw in kws:
         y = ops.conv2d(x, pk, precision=3, **kw)
         res.append([ops.last_conv_variant(), None, y])
@@ -30,7 +30,9 @@ for B, H, W, Cin, Cout in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             ts[i].append(e0.elapsed_time(e1))
-    for i in range(2):
+    for i in range(len(kws)):
         res[i][1] = sorted(ts[i])[4]
     err = float((res[0][2] - res[1][2]).abs().max() / res[1][2].abs().max())
-    print(f"{B}x{H}x{W}x{Cin}->{Cout}: winograd [{res[0][0]}] {res[0][1]:.3f} ms | direct [{res[1][0]}] {res[1][1]:.3f} ms | rel diff {err:.1e}", flush=True)
+    same = bool(torch.equal(res[1][2], res[2][2]))
+    print(f"{B}x{H}x{W}x{Cin}->{Cout}: winograd [{res[0][0]}] {res[0][1]:.3f} ms | direct [{res[1][0]}] {res[1][1]:.3f} ms | wide direct [{res[2][0]}] "
+          f"{res[2][1]:.3f} ms (bits equal to narrow: {same}) | rel diff {err:.1e}", flush=True)
