@@ -194,6 +194,7 @@ SIGNATURES = {
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),
     "a3d_absmax_rows": (C.c_int, [fptr, fptr, C.c_int, C.c_size_t, fptr]),
+    "a3d_mask_rle": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr]),
     "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
@@ -213,6 +214,7 @@ SIGNATURES = {
     "a3d_linear_small": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_paste_lsq": (C.c_int, [C.POINTER(PasteDesc), fptr]),
     "a3d_plane_offset_dense": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fptr]),
+    "a3d_plane_offset_dense_u8": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fptr]),
     "a3d_detections_pack": (C.c_int, [C.POINTER(PackDesc), fptr]),
     "a3d_record_floats": (C.c_int, [C.c_int]),
     # training step

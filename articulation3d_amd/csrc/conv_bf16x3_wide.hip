@@ -27,6 +27,7 @@
 // Registers: 8 x 16 accumulators + two b sets (24 each) + two a sets (12 each) + 16 staging = 216 of the 256 that two waves per
 // SIMD leave each wave.  LDS: 2 x 24 KiB (X) + 3 x 24 KiB (W) + scale | shift.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 typedef __bf16 wx_bf16x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +64,13 @@ __device__ __forceinline__ void wx_split2h(const f32x4 v, const float s, wx_h16x
 }
 
 constexpr int XW_BM = 256, XW_BN = 256, XW_BK = 16;
+// PH4: the phases (bit 2 dy + dx) whose 2x2 window inside the 3x3 neighbourhood holds tap kh = tap / 3, kw = tap % 3
+constexpr unsigned xw_tap_phases(const int tap) {
+    const int th = tap / 3, tw = tap - 3 * th;
+    const unsigned rows = th == 0 ? 0x3u : (th == 1 ? 0xFu : 0xCu);  // dy <= kh <= dy + 1
+    const unsigned cols = tw == 0 ? 0x5u : (tw == 1 ? 0xFu : 0xAu);  // dx <= kw <= dx + 1
+    return rows & cols;
+}
 constexpr int XW_PX = XW_BM * XW_BK, XW_PW = XW_BN * XW_BK;  // one operand plane of one stage (bf16 elements; 32-byte rows)
 constexpr int xw_lds_bytes(int NP) { return (2 * NP * XW_PX + 3 * NP * XW_PW) * 2 + 2 * XW_BN * 4; }
 
@@ -255,46 +263,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     int wst = 0;  // W stage of the chunk being multiplied
     // PH4: the tap of the chunk being multiplied and the phases (= channel blocks) whose 2x2 window holds it
     const int cpt = PH4 ? CinT / BKT : 1;  // chunks per tap
-    int mul_c = 0, mul_tap = 0;
-    auto tap_phases = [](const int tap) -> unsigned {
-        const int th = tap / 3, tw = tap - 3 * th;
-        const unsigned rows = th == 0 ? 0x3u : (th == 1 ? 0xFu : 0xCu);  // phases with dy <= kh <= dy + 1 (bit = 2 dy + dx)
-        const unsigned cols = tw == 0 ? 0x5u : (tw == 1 ? 0xFu : 0xAu);  // ... and dx <= kw <= dx + 1
-        return rows & cols;
-    };
     // one iteration; xst = X stage of chunk c (compile-time), Bc / Bn = the b sets of chunk c / c+1, xs = the staged chunk c+1
     auto iteration = [&](const int xst, FragA &A0, FragA &A1, FragB &Bc, FragB &Bn, f32x4 (&xs)[XR]) {
         const int wnext = wst == 2 ? 0 : wst + 1;
         Split s;
-        if constexpr (PH4) {
-            // the same chunk schedule with each channel block's three terms behind a wave-uniform test (no scheduling fences: the two
-            // waves of a SIMD cover each other's loader work)
-            const unsigned act = __builtin_amdgcn_readfirstlane(tap_phases(mul_tap));
-            if (++mul_c == cpt) {
-                mul_c = 0;
-                ++mul_tap;
-            }
-            if (act & 1u) { XW_TERM(0, A0, Bc, 0, 0) XW_TERM(0, A0, Bc, 0, 1) XW_TERM(0, A0, Bc, 1, 0) }
-            split(xs[0], 0, s);
-            put(xst ^ 1, 0, s);
-            rdA(A1, wst, 1);
-            if (act & 2u) { XW_TERM(1, A1, Bc, 0, 0) XW_TERM(1, A1, Bc, 0, 1) XW_TERM(1, A1, Bc, 1, 0) }
-            split(xs[1], 1, s);
-            put(xst ^ 1, 1, s);
-            rdA(A0, wst, 2);
-            __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __syncthreads();
-            if (act & 4u) { XW_TERM(2, A0, Bc, 0, 0) XW_TERM(2, A0, Bc, 0, 1) XW_TERM(2, A0, Bc, 1, 0) }
-            dma_w();
-            load_chunk(xs);
-            rdA(A1, wst, 3);
-            rdB(Bn, xst ^ 1, 0);
-            rdB(Bn, xst ^ 1, 1);
-            if (act & 8u) { XW_TERM(3, A1, Bc, 0, 0) XW_TERM(3, A1, Bc, 0, 1) XW_TERM(3, A1, Bc, 1, 0) }
-            rdA(A0, wnext, 0);
-            wst = wnext;
-            return;
-        }
         // ---- n = 0
         XW_TERM(0, A0, Bc, 0, 0)
         split(xs[0], 0, s);
@@ -356,6 +328,55 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         wst = wnext;
     };
 
+    // PH4: one chunk of a tap whose phase set ACT is a compile-time constant (nine sets: four corners with one phase, four edges with
+    // two, the centre with all four).  The schedule is the dense one with the loader work re-dealt over the ACTIVE blocks' terms, so
+    // every MFMA pair still carries its share of the split / LDS / vector-memory instructions; A0 holds the first active block's
+    // weights on entry, `nf` = first active block of the NEXT chunk (the next tap's at a tap boundary).
+#define PH_T(N, A, PA, PB, ...) XW_TERM(N, A, Bc, PA, PB) __VA_ARGS__ XW_MIX(12) XW_FENCE
+    auto iter_ph4 = [&](auto act_c, const int xst, FragA &A0, FragA &A1, FragB &Bc, FragB &Bn, f32x4 (&xs)[XR], const int nf) __attribute__((always_inline)) {
+        constexpr unsigned ACT = decltype(act_c)::value;
+        constexpr int NA = __builtin_popcount(ACT);
+        constexpr int b0 = __builtin_ctz(ACT), b1 = NA > 1 ? __builtin_ctz(ACT & (ACT - 1)) : 0;
+        const int wnext = wst == 2 ? 0 : wst + 1;
+        Split s;
+        if constexpr (NA == 4) {
+            PH_T(0, A0, 0, 0, split(xs[0], 0, s);)
+            PH_T(0, A0, 0, 1, put(xst ^ 1, 0, s);)
+            PH_T(0, A0, 1, 0, rdA(A1, wst, 1);)
+            PH_T(1, A1, 0, 0, split(xs[1], 1, s);)
+            PH_T(1, A1, 0, 1, put(xst ^ 1, 1, s);)
+            PH_T(1, A1, 1, 0, rdA(A0, wst, 2);)
+            __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();
+            PH_T(2, A0, 0, 0, dma_w();)
+            PH_T(2, A0, 0, 1, load_chunk(xs);)
+            PH_T(2, A0, 1, 0, rdA(A1, wst, 3);)
+            PH_T(3, A1, 0, 0, rdB(Bn, xst ^ 1, 0); rdB(Bn, xst ^ 1, 1);)
+            PH_T(3, A1, 0, 1, rdA(A0, wnext, nf);)
+            PH_T(3, A1, 1, 0, )
+        } else if constexpr (NA == 2) {
+            PH_T(b0, A0, 0, 0, split(xs[0], 0, s);)
+            PH_T(b0, A0, 0, 1, put(xst ^ 1, 0, s); split(xs[1], 1, s);)
+            PH_T(b0, A0, 1, 0, put(xst ^ 1, 1, s); rdA(A1, wst, b1);)
+            __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();
+            PH_T(b1, A1, 0, 0, dma_w(); rdB(Bn, xst ^ 1, 0);)
+            PH_T(b1, A1, 0, 1, load_chunk(xs); rdB(Bn, xst ^ 1, 1);)
+            PH_T(b1, A1, 1, 0, rdA(A0, wnext, nf);)
+        } else {
+            static_assert(NA == 1, "corner, edge or centre tap");
+            PH_T(b0, A0, 0, 0, split(xs[0], 0, s); put(xst ^ 1, 0, s);)
+            PH_T(b0, A0, 0, 1, split(xs[1], 1, s); put(xst ^ 1, 1, s);)
+            __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __syncthreads();
+            PH_T(b0, A0, 1, 0, dma_w(); XW_FENCE load_chunk(xs); rdB(Bn, xst ^ 1, 0); rdB(Bn, xst ^ 1, 1);)  // (DMA before the loads: the counted wait)
+            rdA(A0, wnext, nf);  // (A0 was in use until the last term)
+            XW_FENCE
+        }
+        wst = wnext;
+    };
+#undef PH_T
+
     // prologue: W(0), W(1) by DMA; X(0) split into X stage 0; X(1), X(2) staged in registers; b(0), a(0)[0] read
     FragA A0, A1;
     FragB B0, B1;
@@ -378,9 +399,25 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     rdA(A0, 0, 0);
     XW_FENCE
 
+    if constexpr (PH4) {
+        // tap-outer, straight-line over the nine taps (each with its compile-time phase set); the chunks of a tap -- an even number:
+        // 32 | Cin + Cin2 -- share the set
+#define PH_RUN(TAP)                                                                                              \
+    {                                                                                                            \
+        constexpr unsigned act = xw_tap_phases(TAP);                                                             \
+        constexpr int nf_same = __builtin_ctz(act), nf_last = TAP < 8 ? __builtin_ctz(xw_tap_phases((TAP + 1) % 9)) : 0; \
+        for (int c = 0; c < cpt; c += 2) {                                                                       \
+            iter_ph4(std::integral_constant<unsigned, act>{}, 0, A0, A1, B0, B1, xsB, nf_same);                  \
+            iter_ph4(std::integral_constant<unsigned, act>{}, 1, A0, A1, B1, B0, xsA, c + 2 < cpt ? nf_same : nf_last); \
+        }                                                                                                        \
+    }
+        PH_RUN(0) PH_RUN(1) PH_RUN(2) PH_RUN(3) PH_RUN(4) PH_RUN(5) PH_RUN(6) PH_RUN(7) PH_RUN(8)
+#undef PH_RUN
+    } else {
     for (int it = kbeg; it < nk; it += 2) {  // (Kpad % 32 == 0 on every packed layer; an odd chunk count would multiply one all-zero chunk: loads / DMA past nk read 0)
         iteration(0, A0, A1, B0, B1, xsB);
         iteration(1, A0, A1, B1, B0, xsA);
+    }
     }
 #undef XW_REST
 #undef XW_MIX

@@ -286,30 +286,45 @@ extern "C" int a3d_paste_lsq(const a3d_paste_desc *d, void *stream) {
 // Stand-alone plane-offset least squares from already-pasted dense masks (one image):
 // PlaneRCNN_Branch.override_depth, arti_vis.py:125-149.  One workgroup per detection.
 // ------------------------------------------------------------------------------------------------
+// MT = float (0 / 1 masks as create_instances holds them) or unsigned char (the pasted bool masks as they are: no float copy of
+// 1.2 MB per mask).  Same pixel -> thread assignment, same accumulation order and same ray values as before for both (the rays
+// ((double)px - cx) / fx, cast to float, are tabulated per column / row instead of being divided out per pixel).
+template <typename MT>
 __global__ __launch_bounds__(256) void plane_offset_dense_kernel(const float *__restrict__ depth,
-                                                                 const float *__restrict__ masks,
+                                                                 const MT *__restrict__ masks,
                                                                  const float *__restrict__ normals,
                                                                  float *__restrict__ out, int H, int W, float fx,
                                                                  float cx, float cy) {
     __shared__ double sred[4];
     __shared__ int redc[4];
+    __shared__ float rayx[2048], rayy[2048];
     const int d = blockIdx.x;
     const size_t npix = (size_t)H * W;
-    const float *m = masks + (size_t)d * npix;
+    const MT *m = masks + (size_t)d * npix;
     const float *pl = normals + (size_t)d * 3;
     const float p0 = pl[0], p1 = -pl[2], p2 = pl[1];
     const float den = fmaxf(sqrtf(p0 * p0 + p1 * p1 + p2 * p2), 1e-8f);
     const float n0 = p0 / den, n1 = p1 / den, n2 = p2 / den;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) rayx[i] = (float)(((double)i - (double)cx) / (double)fx);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) rayy[i] = (float)(((double)i - (double)cy) / (double)fx);
+    __syncthreads();
     double sum = 0.0;
     int c = 0;
+    int py = threadIdx.x / W, px = threadIdx.x - py * W;  // pixel i = threadIdx.x + 256 k, advanced without divisions
+    const int dy = (int)blockDim.x / W, dx = (int)blockDim.x - dy * W;
     for (size_t i = threadIdx.x; i < npix; i += blockDim.x) {
-        if (m[i] != 0.f) {
-            const int py = (int)(i / W), px = (int)(i - (size_t)py * W);
+        if (m[i] != (MT)0) {
             const float dv = depth[i];
-            const float X = (float)(((double)px - (double)cx) / (double)fx) * dv;
-            const float Y = (float)(((double)py - (double)cy) / (double)fx) * dv;
+            const float X = rayx[px] * dv;
+            const float Y = rayy[py] * dv;
             sum += (double)(n0 * X + n1 * Y + n2 * dv);
             ++c;
+        }
+        px += dx;
+        py += dy;
+        if (px >= W) {
+            px -= W;
+            ++py;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -339,10 +354,94 @@ __global__ __launch_bounds__(256) void plane_offset_dense_kernel(const float *__
 
 extern "C" int a3d_plane_offset_dense(const float *depth, const float *masks, const float *normals, float *out, int D,
                                       int H, int W, float focal, float cx, float cy, void *stream) {
-    if (!depth || !masks || !normals || !out || D < 0) return A3D_ERR_ARG;
+    if (!depth || !masks || !normals || !out || D < 0 || H > 2048 || W > 2048) return A3D_ERR_ARG;
     if (D == 0) return A3D_OK;
     a3d_begin();
-    hipLaunchKernelGGL(plane_offset_dense_kernel, dim3(D), dim3(256), 0, (hipStream_t)stream, depth, masks, normals, out,
+    hipLaunchKernelGGL(plane_offset_dense_kernel<float>, dim3(D), dim3(256), 0, (hipStream_t)stream, depth, masks, normals, out,
                        H, W, focal, cx, cy);
+    return a3d_check_launch();
+}
+
+// The pasted bool masks as they are (one byte per pixel), 1024 threads per detection, four pixels per thread and step (one 32-bit
+// mask load; the depth quad only where a byte is set).  Per-thread double sums, then a wave / workgroup tree.
+__global__ __launch_bounds__(1024) void plane_offset_dense_u8_kernel(const float *__restrict__ depth, const unsigned char *__restrict__ masks,
+                                                                     const float *__restrict__ normals, float *__restrict__ out, int H, int W,
+                                                                     float fx, float cx, float cy) {
+    __shared__ double sred[16];
+    __shared__ int redc[16];
+    __shared__ float rayx[2048], rayy[2048];
+    const int d = blockIdx.x;
+    const int npix = H * W;
+    const unsigned char *m = masks + (size_t)d * npix;
+    const float *pl = normals + (size_t)d * 3;
+    const float p0 = pl[0], p1 = -pl[2], p2 = pl[1];
+    const float den = fmaxf(sqrtf(p0 * p0 + p1 * p1 + p2 * p2), 1e-8f);
+    const float n0 = p0 / den, n1 = p1 / den, n2 = p2 / den;
+    for (int i = threadIdx.x; i < W; i += 1024) rayx[i] = (float)(((double)i - (double)cx) / (double)fx);
+    for (int i = threadIdx.x; i < H; i += 1024) rayy[i] = (float)(((double)i - (double)cy) / (double)fx);
+    __syncthreads();
+    double sum = 0.0;
+    int c = 0;
+    const bool quads = ((npix | W) & 3) == 0 && (reinterpret_cast<size_t>(m) & 3) == 0;  // rows hold whole quads (uniform)
+    if (quads) {
+        for (int q = threadIdx.x; q < (npix >> 2); q += 1024) {
+            const unsigned w = *reinterpret_cast<const unsigned *>(m + 4 * (size_t)q);
+            if (!w) continue;
+            const int i = 4 * q, py = i / W, px = i - py * W;
+            const float ry = rayy[py];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((w >> (8 * k)) & 0xFFu) {
+                    const float dv = depth[i + k];
+                    sum += (double)(n0 * (rayx[px + k] * dv) + n1 * (ry * dv) + n2 * dv);
+                    ++c;
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < npix; i += 1024) {
+            if (m[i]) {
+                const int py = i / W, px = i - py * W;
+                const float dv = depth[i];
+                sum += (double)(n0 * (rayx[px] * dv) + n1 * (rayy[py] * dv) + n2 * dv);
+                ++c;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        c += __shfl_xor(c, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sred[threadIdx.x >> 6] = sum;
+        redc[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        int cc = 0;
+        for (int w = 0; w < 16; ++w) {
+            tot += sred[w];
+            cc += redc[w];
+        }
+        float o0 = p0, o1 = p1, o2 = p2;
+        if (cc > 0) {
+            const float offn = (float)(tot / (double)cc);
+            o0 = n0 * offn;
+            o1 = n1 * offn;
+            o2 = n2 * offn;
+        }
+        out[d * 3 + 0] = o0;
+        out[d * 3 + 1] = o2;  // (back to the reference's output axes, arti_vis.py:145-147: as plane_offset_dense_kernel)
+        out[d * 3 + 2] = -o1;
+    }
+}
+
+extern "C" int a3d_plane_offset_dense_u8(const float *depth, const unsigned char *masks, const float *normals, float *out, int D,
+                                         int H, int W, float focal, float cx, float cy, void *stream) {
+    if (!depth || !masks || !normals || !out || D < 0 || H > 2048 || W > 2048) return A3D_ERR_ARG;
+    if (D == 0) return A3D_OK;
+    a3d_begin();
+    hipLaunchKernelGGL(plane_offset_dense_u8_kernel, dim3(D), dim3(1024), 0, (hipStream_t)stream, depth, masks, normals, out, H, W, focal, cx, cy);
     return a3d_check_launch();
 }

@@ -512,6 +512,11 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         # (whole-layer times at 64 frames, tools/h2_wino_vs_direct.py: 60x80x128 -> 128 0.435 Winograd | 0.352 direct; p2 256 -> 256
         # 3.99 | 4.85).  A function of the layer only.
         use_wino = False
+    if use_wino and precision == 3 and WINO_MAX_HW and H * W > WINO_MAX_HW and p.presplit and (-(-p.cols // 256) * 256 <= p.cols + p.cols // 4):
+        # (experiment knob, a function of the layer and the image size only: 3x3 layers on maps larger than A3D_WINO_MAX_HW pixels take
+        # the wide DIRECT kernel -- same time as Winograd alone on the p2 / p3 levels, a fifth of its HBM traffic)
+        use_wino = False
+        d.tune = 9
     ws = None
     if use_wino:
         d.w_wino = p.w_wino.data_ptr()
@@ -624,15 +629,17 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     return out
 
 
+WINO_MAX_HW = int(os.environ.get("A3D_WINO_MAX_HW", "0"))
 UPS_FUSED = os.environ.get("A3D_UPS_FUSED", "1") != "0"  # (False: always the four-launch form; same bits)
-UPS_FUSED_MIN_BLOCKS = int(os.environ.get("A3D_UPS_FUSED_MIN_BLOCKS", "256"))
+UPS_FUSED_MIN_BLOCKS = int(os.environ.get("A3D_UPS_FUSED_MIN_BLOCKS", "0"))
 
 
 def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None, fused: Optional[bool] = None) -> torch.Tensor:
     """3x3 pad-1 conv over the nearest-x2 upsampling of (x || x2), as four source-grid 2x2 convs (pack_conv_ups_phases) -- in the
-    default arithmetic as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5, conv_x3w_kernel's PH4) wherever its 256 x
-    256 blocks fill the chip at least once; smaller maps keep the four narrow launches.  The two forms agree bit for bit
-    (test_fused_upsampled_conv_equals_the_four_phase_launches), so the choice may depend on the batch."""
+    default arithmetic as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5, conv_x3w_kernel's PH4).  The two forms agree
+    bit for bit (test_fused_upsampled_conv_equals_the_four_phase_launches), so the choice may depend on the batch
+    (A3D_UPS_FUSED_MIN_BLOCKS).  Measured at 64 frames (tools/ups_bench.py, four launches | one): 8x10 0.122 | 0.083 ms, 15x20 0.230 |
+    0.144, 30x40 0.401 | 0.400, 60x80 1.328 | 1.364, 120x160 -> 64 channels 3.26 | 2.76; the step 1305 -> 1324 frames/s."""
     B, H, W, _ = x.shape
     out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
     if fused is None:

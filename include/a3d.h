@@ -327,6 +327,9 @@ int a3d_paste_lsq(const a3d_paste_desc *d, void *stream);
  * (pkg/utils/arti_vis.py:125-149).  depth [H,W], masks [D,H,W] (non-zero = inside), normals [D,3] -> out [D,3]. */
 int a3d_plane_offset_dense(const float *depth, const float *masks, const float *normals, float *out, int D, int H,
                            int W, float focal, float cx, float cy, void *stream);
+/* The same with the pasted masks as they are (uint8 / bool bytes, non-zero = set): no float copy of the masks.  Identical results. */
+int a3d_plane_offset_dense_u8(const float *depth, const unsigned char *masks, const float *normals, float *out, int D, int H, int W,
+                              float focal, float cx, float cy, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fixed-size detection records = payload of the frame-sharded all-gather.  One record
@@ -352,6 +355,13 @@ typedef struct a3d_pack_desc {
 
 int a3d_record_floats(int MS);
 int a3d_detections_pack(const a3d_pack_desc *d, void *stream);
+
+/* COCO run-length encoding of pasted masks: the `segmentation` field of the reference's per-frame record
+ * (pkg/utils/arti_vis.py:66-67 -> instances_to_coco_json -> pycocotools mask.encode; decoded again at :179-186).  masks [D,H,W] uint8
+ * (non-zero = set), H * W <= 393 216.  pos[d, k] = the k-th COLUMN-major index i >= 1 with m[i] != m[i-1] (increasing), count[d] = how many
+ * there are (only the first `cap` are stored: re-run with cap >= max count if it was exceeded), first[d] = m[0] != 0.  The run
+ * lengths are the differences of {0, pos..., H*W}, with a leading 0 when first is set (cocoapi's convention). */
+int a3d_mask_rle(const unsigned char *masks, int D, int H, int W, int cap, int *pos, int *count, int *first, void *stream);
 
 /* ================================================================================================
  * Training step (BASELINE configs[4]: config/step1_bbox.yaml).

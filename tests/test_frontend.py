@@ -81,3 +81,38 @@ def test_detect_clip_from_reader_frames_equals_host_side_resize(hip_model, oracl
     for p, q in zip(a, b):
         assert len(p) == len(q) > 0 and torch.equal(p.pred_boxes.tensor, q.pred_boxes.tensor) and torch.equal(p.pred_masks, q.pred_masks)
         assert torch.equal(p.pred_planes, q.pred_planes)
+
+
+@pytest.mark.gpu
+def test_device_rle_encode_equals_the_host_codec():
+    """a3d_mask_rle + rle.encode_device (the `segmentation` strings of PlaneRCNN_Branch.process, arti_vis.py:66-67) against the host
+    restatement of cocoapi's encoder: identical dicts on blobs, empty / full masks, a set first pixel, boundaries at column ends, and
+    a mask with more run boundaries than the first buffer holds (checkerboard: one per pixel)."""
+    import numpy as np
+    import torch
+
+    from articulation3d_amd.utils import rle
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.default_rng(5)
+    H, W = 480, 640
+    masks = np.zeros((9, H, W), dtype=np.uint8)
+    yy, xx = np.mgrid[:H, :W]
+    for d in range(4):  # blobs
+        cy, cx, ry, rx = rng.uniform(50, 430), rng.uniform(50, 590), rng.uniform(10, 200), rng.uniform(10, 250)
+        masks[d] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).astype(np.uint8)
+    masks[4] = 1                      # full
+    masks[6, 0, 0] = 1                # only the first pixel (leading zero-length run of zeros)
+    masks[6, H - 1, 0] = 1            # a run that ends exactly at a column end
+    masks[6, 0, 1] = 1                # ... and one that starts at the next column's top: they merge in column-major order
+    masks[7, :, W - 1] = 1            # last column
+    masks[8] = ((yy + xx) & 1).astype(np.uint8)  # checkerboard: H*W - 1 boundaries
+    got = rle.encode_device(torch.from_numpy(masks).cuda())
+    for d in range(9):
+        want = rle.encode(masks[d])
+        assert got[d] == want, d
+        assert (rle.decode(got[d]) == masks[d]).all()
+    got_bool = rle.encode_device(torch.from_numpy(masks[:4].astype(bool)).cuda())
+    assert got_bool == got[:4]
+    assert rle.encode_device(torch.zeros((0, H, W), dtype=torch.uint8, device="cuda")) == []
