@@ -239,6 +239,8 @@ SIGNATURES = {
     "a3d_project_hypotheses": (C.c_int, [C.POINTER(SweepDesc), fptr]),
     "a3d_mask_iou_matrix": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_sgd_momentum": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
+    "a3d_f32_to_bf16_scaled": (C.c_int, [fptr, fptr, C.c_size_t, C.c_float, fptr]),
+    "a3d_bf16_to_f32": (C.c_int, [fptr, fptr, C.c_size_t, fptr]),
 }
 
 STRUCT_IDS = {0: ConvDesc, 1: RpnDesc, 2: BoxDetDesc, 3: RoiAlignDesc, 4: PasteDesc, 5: PackDesc, 6: WgradDesc,

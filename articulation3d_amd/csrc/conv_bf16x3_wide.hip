@@ -519,7 +519,12 @@ int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
         // equivalent TFLOP/s); K = 2048 equal; K <= 1024 equal to 15 % slower -- with ONE workgroup per CU nothing overlaps the
         // prologue and the 256 x 256 epilogue (residual reads, stores), which a 16..64-iteration loop does not amortise, where
         // the narrow kernel's three workgroups per CU cover each other's.  Hence deep reductions only.
-        if (d->Kpad < 4096) return A3D_ERR_UNSUPPORTED;
+        // fp16x2, measured again per layer (tools/narrow_wide_ab.py, 64 frames, narrow | wide ms): shallow reductions go wide too when
+        // the layer has no residual to fetch and at least ~1000 of the 256 x 256 blocks -- fc2 64000 x 1024 -> 1024 0.586 | 0.487, the
+        // p2 lateral 256 -> 256 0.870 | 0.781, strided 256 -> 512 0.487 | 0.474; with a residual (256 -> 1024 0.274 | 0.310) or fewer
+        // blocks (1024 -> 256 at 30x40 0.190 | 0.209) the narrow kernel's three workgroups per CU stay ahead.  Same bits either way.
+        const bool shallow_ok = d->precision == 3 && !d->res && d->splitk == 1 && d->Kpad >= 256 && d->Cout >= 256 && (long)mtiles * ntiles >= 1000;
+        if (d->Kpad < 4096 && !shallow_ok) return A3D_ERR_UNSUPPORTED;
         if (d->Cout < 192 || ntiles * XW_BN > d->Cout + d->Cout / 4) return A3D_ERR_UNSUPPORTED;
         if (d->splitk == 1 && (long)mtiles * ntiles < 2 * 256) return A3D_ERR_UNSUPPORTED;  // (split-K launches stream the weights: any M)
     }

@@ -472,3 +472,40 @@ extern "C" int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, 
     hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, lr, momentum, wd, grad_scale, first);
     return a3d_check_launch();
 }
+
+
+// ---- bf16 payload of the data-parallel gradient all-reduce (BASELINE configs[4]: "bf16 ... grad all-reduce over xGMI") ------------
+// torch's DDP bf16_compress_hook: the gradient is divided by the world size, rounded to bf16 (nearest even), summed by the collective
+// in bf16 and widened back.  Two HBM-bound passes over the flat gradient buffer; the collective moves half the bytes (82 MB, not 164).
+__global__ __launch_bounds__(256) void f32_to_bf16_scaled_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, size_t n4, float scale) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(src)[i] * scale;
+        reinterpret_cast<b4 *>(dst)[i] = __builtin_convertvector(v, b4);
+    }
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16 *__restrict__ src, float *__restrict__ dst, size_t n4) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4 *>(dst)[i] = __builtin_convertvector(reinterpret_cast<const b4 *>(src)[i], f32x4);
+}
+
+extern "C" int a3d_f32_to_bf16_scaled(const float *src, void *dst, size_t n, float scale, void *stream) {
+    if (!src || !dst || (n & 3)) return A3D_ERR_ARG;
+    if (n == 0) return A3D_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    a3d_begin();
+    hipLaunchKernelGGL(f32_to_bf16_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16 *)dst, n / 4, scale);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_bf16_to_f32(const void *src, float *dst, size_t n, void *stream) {
+    if (!src || !dst || (n & 3)) return A3D_ERR_ARG;
+    if (n == 0) return A3D_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    a3d_begin();
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)src, dst, n / 4);
+    return a3d_check_launch();
+}

@@ -132,7 +132,8 @@ class DetectorTrainer:
     `model` is the product PlaneRCNN (its frozen stem / res2 modules are used as they are; everything trainable is
     copied into the flat buffer at construction and written back by `export_state_dict`)."""
 
-    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "fp32"):
+    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "fp32",
+                 grad_payload: Optional[str] = None):
         """precision: "fp32" (fp32 MFMA everywhere) or "bf16" -- the reference's autocast setting: every trainable conv / linear
         multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
         weights, activations, gradients, losses and the optimiser stay fp32."""
@@ -140,6 +141,8 @@ class DetectorTrainer:
         # "bf16x3": fp32-grade arithmetic on the bf16 pipe for every forward / data-gradient launch -- csrc/conv_bf16x3.hip for the
         # direct layers, the split-operand Winograd GEMM (csrc/conv_wino.hip 2x) for the 3x3 ones, whose filters are split once per
         # step in _prepare_filters -- and for every weight gradient
+        # gradient all-reduce payload: bf16 in the bf16 step (configs[4]: DDP's bf16_compress_hook semantics), fp32 otherwise
+        self.grad_payload = grad_payload or ("bf16" if precision == "bf16" else "fp32")
         self.prec = {"fp32": 0, "bf16": 1, "bf16x3": "bf16x3"}[precision]
         self.wgrad_prec = {"fp32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self.s = solver or SolverCfg()
@@ -476,7 +479,7 @@ class DetectorTrainer:
 
     def optimizer_step(self):
         s = self.s
-        scale = allreduce_gradients(self.grads, self.pg)  # ONE collective: the flat gradient buffer
+        scale = allreduce_gradients(self.grads, self.pg, payload=self.grad_payload)  # ONE collective: the flat gradient buffer
         T.sgd_momentum(self.params, self.grads, self.momentum, lr=lr_at(self.iter, s), momentum=s.momentum, weight_decay=s.weight_decay,
                        grad_scale=scale, first=self.iter == 0)
         self.iter += 1

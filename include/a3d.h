@@ -513,6 +513,12 @@ int a3d_box_loss(const a3d_box_loss_desc *d, void *stream);
 int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
                      int first, void *stream);
 
+/* bf16 payload of the data-parallel gradient all-reduce (BASELINE configs[4]; torch DDP's bf16_compress_hook behind
+ * tools/train_net.py:110): dst_bf16[i] = bf16(src[i] * scale) (round to nearest even; scale = 1 / world size), and the widening
+ * back after the collective.  n % 4 == 0. */
+int a3d_f32_to_bf16_scaled(const float *src, void *dst_bf16, size_t n, float scale, void *stream);
+int a3d_bf16_to_f32(const void *src_bf16, float *dst, size_t n, void *stream);
+
 /* ================================================================================================
  * Hypothesis sweeps of the temporal optimiser.  Replace the per-hypothesis / per-frame Python loops
  * inside optimize_planes_3dc and optimize_planes_3d_trans (pkg/utils/opt_utils.py:400-476, 540-611, 700-768, 838-905):

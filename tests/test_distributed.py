@@ -152,7 +152,16 @@ def _grad_worker(rank, world, port, q):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # rank r holds (r+1) * base
     scale = allreduce_gradients(g)
     want = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
-    q.put((rank, bool(torch.equal(g, want)) and abs(scale - 1.0 / world) < 1e-12))
+    ok = bool(torch.equal(g, want)) and abs(scale - 1.0 / world) < 1e-12
+    # bf16 payload (configs[4]; DDP's bf16_compress_hook): mean of the bf16-rounded, pre-divided gradients, widened back; factor 1
+    g = (torch.arange(1000, dtype=torch.float32) * 0.37 + 0.123) * (rank + 1)
+    scale = allreduce_gradients(g, payload="bf16")
+    parts = [((torch.arange(1000, dtype=torch.float32) * 0.37 + 0.123) * (r + 1) * (1.0 / world)).to(torch.bfloat16) for r in range(world)]
+    want16 = parts[0]
+    for p_ in parts[1:]:
+        want16 = want16 + p_  # (bf16 sum, as the collective forms it)
+    ok = ok and scale == 1.0 and bool(torch.equal(g, want16.to(torch.float32)))
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 

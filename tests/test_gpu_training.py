@@ -652,3 +652,19 @@ def test_reference_training_loop_is_a_drop_in(oracle, oracle_params):
     assert len(changed) > 50 and all(torch.equal(after[k], a[k]) for k in a)
     out = model.inference_batched(torch.from_numpy(frames).cuda())
     assert out.depth is None and int(out.proposals[4].min()) > 0
+
+
+def test_bf16_gradient_payload_casts_equal_torchs():
+    """a3d_f32_to_bf16_scaled / a3d_bf16_to_f32 (the bf16 payload of the gradient all-reduce, parallel.allreduce_gradients) round and
+    widen exactly like torch's casts (round to nearest even), incl. the 1 / world pre-division of DDP's bf16_compress_hook."""
+    from articulation3d_amd import _lib
+
+    torch.manual_seed(3)
+    g = (torch.randn(1 << 20, device="cuda") * torch.logspace(-6, 3, 1 << 20, device="cuda")).contiguous()
+    g16 = torch.empty(g.numel(), device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().a3d_f32_to_bf16_scaled(g.data_ptr(), g16.data_ptr(), g.numel(), 0.125, st), "a3d_f32_to_bf16_scaled")
+    assert torch.equal(g16, (g * 0.125).to(torch.bfloat16))
+    back = torch.empty_like(g)
+    _lib.check(_lib.lib().a3d_bf16_to_f32(g16.data_ptr(), back.data_ptr(), g.numel(), st), "a3d_bf16_to_f32")
+    assert torch.equal(back, g16.to(torch.float32))
