@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile on the GPU box: bench line, rocprofv3 kernel trace + stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in their own
 # passes), matrix-pipe occupancy.  Summaries land in gpurun_out/ (copy the ones to be judged into profiles/).
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points"
