@@ -161,6 +161,11 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     // Two register staging sets: the loads of chunk c are issued at iteration c-3, split into LDS at iteration c-1 and
     // multiplied at iteration c, so a buffer load has two full iterations (2 x 6*TN*2 MFMAs per wave) to land.
     f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
+    // fp16x2 with the filter by DMA: a THIRD activation staging set -- loads are issued three chunks ahead instead of two.  These
+    // layers are bound by the bytes a CU keeps in flight (PMC: waves parked at s_waitcnt 60 % of their cycles on the K = 256 layers,
+    // DESIGN.md section 5a); the kernel has 155 of the 168 VGPRs that three waves per SIMD allow, i.e. room for exactly one more set.
+    constexpr bool X3SETS = F16 && WDMA;
+    f32x4 xsC[XR];
     auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         if (STEM) {
             const unsigned livebit = (kc < nk) ? 1u : 0u;
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
     load_chunk(xsB, wsB);  // chunk 1
     load_chunk(xsA, wsA);  // chunk 2
     if constexpr (WDMA) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (X3SETS) load_chunk(xsC, wsA);  // chunk 3 (behind the wait: it stays in flight)
     __syncthreads();
 
     const int frow = lane & 31;
@@ -354,9 +360,36 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);  // <= 3 VALU (addresses)
         }
     };
+    if constexpr (X3SETS) {
+        // chunk c+1 waits in set (c+1) % 3 = B, A, C, B, A, C ..; the LDS stage alternates: the pattern repeats every six chunks.
+        // (the counted vmcnt of a step does not change: every step still issues XR loads and one filter DMA group)
+        int it = 0;
+        for (; it + 6 <= nk; it += 6) {
+            step(0, xsB, wsB, fa0, fb0, fa1, fb1);
+            step(1, xsA, wsA, fa1, fb1, fa0, fb0);
+            step(0, xsC, wsA, fa0, fb0, fa1, fb1);
+            step(1, xsB, wsB, fa1, fb1, fa0, fb0);
+            step(0, xsA, wsA, fa0, fb0, fa1, fb1);
+            step(1, xsC, wsA, fa1, fb1, fa0, fb0);
+        }
+        const int rem = nk - it;  // 0 .. 5; an odd chunk count multiplies one all-zero chunk (loads past nk read as 0)
+        if (rem > 0) {
+            step(0, xsB, wsB, fa0, fb0, fa1, fb1);
+            step(1, xsA, wsA, fa1, fb1, fa0, fb0);
+        }
+        if (rem > 2) {
+            step(0, xsC, wsA, fa0, fb0, fa1, fb1);
+            step(1, xsB, wsB, fa1, fb1, fa0, fb0);
+        }
+        if (rem > 4) {
+            step(0, xsA, wsA, fa0, fb0, fa1, fb1);
+            step(1, xsC, wsA, fa1, fb1, fa0, fb0);
+        }
+    } else {
     for (int it = 0; it < nk; it += 2) {  // (an odd chunk count multiplies one all-zero chunk: loads past nk read as 0)
         step(0, xsB, wsB, fa0, fb0, fa1, fb1);
         step(1, xsA, wsA, fa1, fb1, fa0, fb0);
+    }
     }
 #undef X3_TERM
 
