@@ -49,10 +49,18 @@ class GatherHandle:
         return scatter_compact(rows, counts, R), counts
 
 
+def _index_to(idx, device) -> torch.Tensor:
+    """A host index list on `device` WITHOUT a host-blocking copy: a pageable source would make the copy wait for everything the
+    stream holds (the next batch's kernels) before the host continues; pinned + non_blocking only orders it on the stream."""
+    t = torch.tensor(idx, dtype=torch.int64)
+    if torch.device(device).type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def compact_index(counts, R: int, device) -> torch.Tensor:
     """Flat slot-row indices (slot * R + r, r < count[slot]) of the live records, frame-major.  counts: host list of ints."""
-    idx = [s * R + r for s, c in enumerate(counts) for r in range(min(int(c), R))]
-    return torch.tensor(idx, device=device, dtype=torch.int64)
+    return _index_to([s * R + r for s, c in enumerate(counts) for r in range(min(int(c), R))], device)
 
 
 def scatter_compact(rows: torch.Tensor, counts: torch.Tensor, R: int) -> torch.Tensor:
@@ -153,7 +161,7 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
         counts = h[:, 1:].contiguous()                      # [G, rows]
         live = [int(v) for v in counts.clamp(max=R).sum(1).tolist()]
         mx = max(live)
-        all_cnt = counts.reshape(-1).to(dev)
+        all_cnt = counts.reshape(-1).to(dev, non_blocking=True)  # (pinned source on the device path: no host wait)
         if mx == 0:
             out = (rec.new_zeros((0, F)), all_cnt)
         else:
@@ -166,7 +174,7 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
                 dist.all_gather_into_tensor(got, send, async_op=True).wait()  # (the current stream waits; the host does not)
             else:
                 dist.all_gather_into_tensor(got, send)
-            keep = torch.tensor([g * mx + i for g in range(G) for i in range(live[g])], device=dev, dtype=torch.int64)
+            keep = _index_to([g * mx + i for g in range(G) for i in range(live[g])], dev)
             out = (got[keep], all_cnt)
         if back is not None:
             out = (out[0].to(back), out[1].to(back))
