@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("y_amax", fptr),
         ("w_scale", C.c_float),
         ("wino_m", fptr),
+        ("io_bf16", C.c_int),
     ]
 
 
@@ -112,7 +113,7 @@ class WgradDesc(C.Structure):
         ("x", fptr), ("dy", fptr), ("scale", fptr), ("dw", fptr), ("workspace", fptr),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-        ("splitk", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int),
+        ("splitk", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("io_bf16", C.c_int),
     ]
 
 

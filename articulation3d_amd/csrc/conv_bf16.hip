@@ -24,14 +24,36 @@ __device__ __forceinline__ f32x4 bf_load4(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
+// bf16 STORAGE (a3d_conv_desc.io_bf16): four stored bf16 values <-> f32x4.  Widening is exact; narrowing rounds to nearest even.
+typedef unsigned int bf_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 bf_widen4(const bf_u32x2 v) {
+    f32x4 o;
+    o[0] = __builtin_bit_cast(float, v[0] << 16);
+    o[1] = __builtin_bit_cast(float, v[0] & 0xFFFF0000u);
+    o[2] = __builtin_bit_cast(float, v[1] << 16);
+    o[3] = __builtin_bit_cast(float, v[1] & 0xFFFF0000u);
+    return o;
+}
+__device__ __forceinline__ f32x4 bf_read4(const float *base, size_t idx, bool is_bf16) {  // element index idx (multiple of 4)
+    if (is_bf16) return bf_widen4(*reinterpret_cast<const bf_u32x2 *>(reinterpret_cast<const __bf16 *>(base) + idx));
+    return *reinterpret_cast<const f32x4 *>(base + idx);
+}
+__device__ __forceinline__ void bf_write4(float *base, size_t idx, const f32x4 v, bool is_bf16) {
+    if (is_bf16) *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(base) + idx) = __builtin_convertvector(v, bf16x4);
+    else *reinterpret_cast<f32x4 *>(base + idx) = v;
+}
 
-template <int TN>
+// XB: the activations are STORED as bf16 (io_bf16 bit 0).  A lane then loads 8 channels (16 bytes) and the bits go to LDS as they are:
+// half the loads of the fp32-stored form, no conversion.
+template <int TN, bool XB = false>
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
     constexpr int TM = 2, BKT = 32;
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int LKB = BKT + 8;               // bf16 elements per LDS row (80 bytes)
     constexpr int TPR = BKT / 4, RPP = 256 / TPR;  // 8 lanes x float4 per row, 32 rows per loader pass
-    constexpr int XR = BM / RPP, WR = BN / RPP;
+    constexpr int XE = XB ? 8 : 4, XES = XB ? 2 : 4;  // activation elements per lane load, bytes per stored element
+    constexpr int TPRX = BKT / XE, RPPX = 256 / TPRX;
+    constexpr int XR = BM / RPPX, WR = BN / RPP;
     constexpr int BUF = (BM + BN) * LKB;
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
     __shared__ __attribute__((aligned(16))) float ss[2 * BN];
@@ -43,7 +65,9 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
     const int m0 = mt * BM, n0 = nt * BN;
     const int nk = d.Kpad / BKT;
     const int lr = tid / TPR, lc = (tid % TPR) * 4;
-    const int cs4 = d.Cin * 4;
+    const int lrx = tid / TPRX, lcx = (tid % TPRX) * XE;
+    const bool yb = d.io_bf16 & 2, rb = d.io_bf16 & 4, gb = d.io_bf16 & 8;  // tensors stored as bf16
+    const int cs4 = d.Cin * XES;  // bytes per input pixel
     const __amdgpu_buffer_rsrc_t rx = bf_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rw = bf_rsrc(d.w, (unsigned)((size_t)d.Cout * d.Kpad * 4));
 
@@ -51,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
     unsigned vmask[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-        const int m = m0 + lr + RPP * i;
+        const int m = m0 + lrx + RPPX * i;
         const bool rok = m < M;
         const int mm = rok ? m : 0;
         const int hw = d.Ho * d.Wo;
@@ -62,7 +86,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         for (int kh = 0; kh < d.KH; ++kh)
             for (int kw = 0; kw < d.KW; ++kw)
                 mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
-        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lc * 4;
+        rowoff[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + lcx * XES;
         vmask[i] = mask;
     }
     int woff[WR];
@@ -76,9 +100,12 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
     auto load_chunk = [&]() {
         const int tap = kh * d.KW + kw;
         const unsigned livebit = (kc < nk) ? 1u : 0u;
-        const int tapoff = (kh * d.W + kw) * cs4 + c0 * 4;
+        const int tapoff = (kh * d.W + kw) * cs4 + c0 * XES;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) xs[i] = bf_load4(rx, ((vmask[i] >> (tap & 31)) & livebit) ? rowoff[i] + tapoff : -1, 0);
+        for (int i = 0; i < XR; ++i) {
+            const bool on = (vmask[i] >> (tap & 31)) & livebit;
+            xs[i] = bf_load4(rx, on ? rowoff[i] + tapoff : -1, 0);  // (XB: the four dwords are 8 stored bf16 values)
+        }
         const int soff = kc * (BKT * 4);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = bf_load4(rw, livebit ? woff[i] : -1, soff);
@@ -96,7 +123,10 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         __bf16 *X = lds + buf * BUF;
         __bf16 *Wt = X + BM * LKB;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) *reinterpret_cast<bf16x4 *>(X + (lr + RPP * i) * LKB + lc) = __builtin_convertvector(xs[i], bf16x4);
+        for (int i = 0; i < XR; ++i) {
+            if constexpr (XB) *reinterpret_cast<f32x4 *>(X + (lrx + RPPX * i) * LKB + lcx) = xs[i];
+            else *reinterpret_cast<bf16x4 *>(X + (lrx + RPPX * i) * LKB + lcx) = __builtin_convertvector(xs[i], bf16x4);
+        }
 #pragma unroll
         for (int i = 0; i < WR; ++i) *reinterpret_cast<bf16x4 *>(Wt + (lr + RPP * i) * LKB + lc) = __builtin_convertvector(ws[i], bf16x4);
     };
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
-                    rv[rg] = *reinterpret_cast<const f32x4 *>(d.res + res_row * (size_t)d.Cout + min(n, d.Cout - 4));
+                    rv[rg] = bf_read4(d.res, res_row * (size_t)d.Cout + min(n, d.Cout - 4), rb);
                 }
             }
 #pragma unroll
@@ -164,7 +194,16 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
                 v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
-                store_out(d, v, m, n, b, oh, ow);
+                if (d.io_bf16) {  // (plain output layout only: the launcher refuses pixshuf / phase with bf16 storage)
+                    const size_t o = (size_t)m * d.Cout + n;
+                    if (d.gate) {
+                        const f32x4 g = bf_read4(d.gate, o, gb);
+                        for (int i = 0; i < 4; ++i) v[i] = g[i] > 0.f ? v[i] : 0.f;
+                    }
+                    bf_write4(d.y, o, v, yb);
+                } else {
+                    store_out(d, v, m, n, b, oh, ow);
+                }
             }
         }
     }
@@ -176,12 +215,14 @@ void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
     a3d_note_variant("conv_bf16_kernel<%d>", TN);
-    hipLaunchKernelGGL((conv_bf16_kernel<TN>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    if (d->io_bf16 & 1) hipLaunchKernelGGL((conv_bf16_kernel<TN, true>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    else hipLaunchKernelGGL((conv_bf16_kernel<TN, false>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
 }
 }  // namespace
 
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->io_bf16 & ~15) return A3D_ERR_ARG;
     if ((d->Cin & 31) || d->Kpad != d->KH * d->KW * d->Cin || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
     const int M = d->B * d->Ho * d->Wo;

@@ -149,7 +149,9 @@ __device__ __forceinline__ void wg_split3(const wg_f32x8 v, wg_bf16x8 &h, wg_bf1
 // X3 = false: precision 1 (operands rounded to bf16, chunk of 32 pixels).  X3 = true: precision 2, fp32-grade -- both
 // operands split exactly into hi | mid | lo bf16 planes in LDS and six MFMAs per 16-pixel k step (conv_bf16x3.hip has the
 // arithmetic); chunk of 16 pixels so that 3 planes x 2 operands x 2 buffers stay at 72 KB (2 workgroups per CU).
-template <bool X3>
+// IO (X3 = false only): a3d_wgrad_desc.io_bf16 -- bit 0: x, bit 1: dy stored as bf16 (a compile-time property: each form keeps only
+// the staging registers it uses).
+template <bool X3, int IO = 0>
 __global__ __launch_bounds__(256, X3 ? 2 : 3) void conv_wgrad_bf16_kernel(const a3d_wgrad_desc d, const int P, const int mtiles, const int ntiles,
                                                                          const int chunk) {
     constexpr int BKP = X3 ? 16 : 32, LKB = BKP + 8, NPL = X3 ? 3 : 1, G = BKP / 16, S = BKP / 16;
@@ -168,37 +170,85 @@ __global__ __launch_bounds__(256, X3 ? 2 : 3) void conv_wgrad_bf16_kernel(const 
     const int ch = tid & 127, kg = tid >> 7;  // channel inside the tile; pixel groups kg*G .. kg*G+G-1 (8 pixels each)
     const bool a_ok = co0 + ch < d.Cout, b_ok = ci0 + ch < d.Cin;
     const int HoWo = d.Ho * d.Wo;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.dy), 0, (int)((size_t)P * d.Cout * 4), 0x00020000);
+    static_assert(!X3 || IO == 0, "bf16-stored operands belong to the bf16 arithmetic");
+    constexpr bool xb = IO & 1, yb = IO & 2;  // operands stored as bf16
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.dy), 0, (int)(((size_t)P * d.Cout * 4) >> (yb ? 1 : 0)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.x), 0, (int)((size_t)d.B * d.H * d.W * d.Cin * 4), 0x00020000);
-
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d.x), 0, (int)(((size_t)d.B * d.H * d.W * d.Cin * 4) >> (xb ? 1 : 0)), 0x00020000);
+    // fp32-stored operand: a thread owns ONE channel (tid % 128) for G groups of 8 pixels: 8 G dword loads, rounded to bf16 on the way
+    // into LDS.  bf16-stored operand (X3 = false only): a thread owns a channel PAIR (tid % 64) for ONE group of 8 pixels (tid / 64):
+    // 8 dword loads -- half as many, each still a full dword -- whose low / high halves are the two channels' pixels; no conversion.
+    const int cp = tid & 63, pg16 = tid >> 6;
+    const bool a_ok2 = co0 + 2 * cp + 1 < d.Cout, b_ok2 = ci0 + 2 * cp + 1 < d.Cin;
     wg_f32x8 ra[G], rb[G];
+    unsigned qa[8], qb[8];
     auto load = [&](int p0) {
+        if constexpr (!yb || !xb || X3) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int pg = p0 + (kg * G + g) * 8;
-            int b = pg / HoWo, r = pg - b * HoWo;
-            int oh = r / d.Wo, ow = r - oh * d.Wo;
+            for (int g = 0; g < G; ++g) {
+                const int pg = p0 + (kg * G + g) * 8;
+                int b = pg / HoWo, r = pg - b * HoWo;
+                int oh = r / d.Wo, ow = r - oh * d.Wo;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int p = pg + k;
-                const bool live = p < p_end;
-                const int iy = oh * d.stride + kh - d.pad, ix = ow * d.stride + kw - d.pad;
-                const bool in = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-                ra[g][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (live && a_ok) ? (p * d.Cout + co0 + ch) * 4 : -1, 0, 0));
-                rb[g][k] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rx, (in && b_ok) ? (((b * d.H + iy) * d.W + ix) * d.Cin + ci0 + ch) * 4 : -1, 0, 0));
-                if (++ow == d.Wo) {  // next pixel of the run
-                    ow = 0;
-                    if (++oh == d.Ho) {
-                        oh = 0;
-                        ++b;
+                for (int k = 0; k < 8; ++k) {
+                    const int p = pg + k;
+                    const bool live = p < p_end;
+                    const int iy = oh * d.stride + kh - d.pad, ix = ow * d.stride + kw - d.pad;
+                    const bool in = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                    if constexpr (!yb || X3) ra[g][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (live && a_ok) ? (p * d.Cout + co0 + ch) * 4 : -1, 0, 0));
+                    if constexpr (!xb || X3)
+                        rb[g][k] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(rx, (in && b_ok) ? (((b * d.H + iy) * d.W + ix) * d.Cin + ci0 + ch) * 4 : -1, 0, 0));
+                    if (++ow == d.Wo) {  // next pixel of the run
+                        ow = 0;
+                        if (++oh == d.Ho) {
+                            oh = 0;
+                            ++b;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (!X3) {
+            if constexpr (yb || xb) {
+                const int pg = p0 + pg16 * 8;
+                int b = pg / HoWo, r = pg - b * HoWo;
+                int oh = r / d.Wo, ow = r - oh * d.Wo;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int p = pg + k;
+                    const bool live = p < p_end;
+                    const int iy = oh * d.stride + kh - d.pad, ix = ow * d.stride + kw - d.pad;
+                    const bool in = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                    if constexpr (yb) qa[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ry, (live && a_ok2) ? (p * d.Cout + co0 + 2 * cp) * 2 : -1, 0, 0);
+                    if constexpr (xb) qb[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, (in && b_ok2) ? (((b * d.H + iy) * d.W + ix) * d.Cin + ci0 + 2 * cp) * 2 : -1, 0, 0);
+                    if (++ow == d.Wo) {
+                        ow = 0;
+                        if (++oh == d.Ho) {
+                            oh = 0;
+                            ++b;
+                        }
                     }
                 }
             }
         }
     };
+    auto store_pairs = [&](__bf16 *plane, const unsigned (&q)[8]) {  // [channel][pixel]: the pair's two channels, 8 pixels each
+        typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+        wg_u32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = (q[2 * k] & 0xFFFFu) | (q[2 * k + 1] << 16);
+            hi[k] = (q[2 * k] >> 16) | (q[2 * k + 1] & 0xFFFF0000u);
+        }
+        *reinterpret_cast<wg_u32x4 *>(plane + (2 * cp) * LKB + pg16 * 8) = lo;
+        *reinterpret_cast<wg_u32x4 *>(plane + (2 * cp + 1) * LKB + pg16 * 8) = hi;
+    };
     auto store = [&](int buf) {
+        if constexpr (!X3) {
+            if constexpr (yb) store_pairs(&lds[buf][0][0], qa);
+            if constexpr (xb) store_pairs(&lds[buf][1][0], qb);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int off = ch * LKB + (kg * G + g) * 8;
@@ -213,8 +263,8 @@ __global__ __launch_bounds__(256, X3 ? 2 : 3) void conv_wgrad_bf16_kernel(const 
                 *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][PL + off]) = m;
                 *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][2 * PL + off]) = l;
             } else {
-                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][off]) = __builtin_convertvector(ra[g], wg_bf16x8);
-                *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][off]) = __builtin_convertvector(rb[g], wg_bf16x8);
+                if constexpr (!yb) *reinterpret_cast<wg_bf16x8 *>(&lds[buf][0][off]) = __builtin_convertvector(ra[g], wg_bf16x8);
+                if constexpr (!xb) *reinterpret_cast<wg_bf16x8 *>(&lds[buf][1][off]) = __builtin_convertvector(rb[g], wg_bf16x8);
             }
         }
     };
@@ -304,10 +354,18 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     int chunk = (P + d->splitk - 1) / d->splitk;
     chunk = (chunk + 31) / 32 * 32;  // a multiple of both kernels' k-chunk (16 / 32 pixels)
     a3d_begin();
+    if (d->io_bf16 && (d->precision != 1 || (d->io_bf16 & ~3))) return A3D_ERR_ARG;  // bf16-stored operands: the bf16 arithmetic only
     if (d->precision == 1 || d->precision == 2) {
         if ((size_t)P * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
         const dim3 grid(mtiles * ntiles * d->KH * d->KW, d->splitk);
-        if (d->precision == 1) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
+        if (d->precision == 1) {
+            switch (d->io_bf16) {
+            case 1: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 1>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;
+            case 2: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 2>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;
+            case 3: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 3>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;
+            default: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 0>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;
+            }
+        }
         else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
     } else
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);

@@ -371,13 +371,18 @@ _ADDR_LIMIT = (1 << 32) - 1  # the kernels address every operand with 32-bit buf
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None, out_dtype=None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4]).
+
+    bf16 STORAGE (training step, precision 1 only): x / res / gate may be torch.bfloat16 tensors and `out_dtype=torch.bfloat16`
+    makes the layer store its output as bf16 (a3d_conv_desc.io_bf16) -- half the HBM bytes of every such tensor.
 
     A launch addresses each operand through a 32-bit buffer descriptor.  Batches whose largest tensor (input, output, residual,
     Winograd tiles, split-K partial sums) reaches 4 GiB -- ~86 frames x 1000 proposals at the box head's fc1, ~218 frames at a
     256-channel 120x160 layer -- run as consecutive launches over blocks of images.  Every image's result is a function of that
     image alone (per-image scales, fixed layer algorithm), so the blocks reproduce the single launch bit for bit."""
+    if out_dtype is not None or x.dtype == torch.bfloat16 or (res is not None and res.dtype == torch.bfloat16) or (gate is not None and gate.dtype == torch.bfloat16):
+        return _conv2d_bf16_storage(x, p, res=res, res_ups=res_ups, act=act, out=out, gate=gate, precision=precision, out_dtype=out_dtype)
     _req(x)
     B = x.shape[0]
     if B > 1:
@@ -414,6 +419,39 @@ def _conv2d_blocks(x, p, nb, hw_out, *, x2, res, out, gate, m_dev, **kw):
         recorded.append(getattr(o, "_a3d_amax", None))
     if getattr(out, "_a3d_amax", None) is None and all(r is not None for r in recorded):
         out._a3d_amax = torch.cat(recorded)
+    return out
+
+
+def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, precision, out_dtype) -> torch.Tensor:
+    """The training step's bf16 (autocast) arithmetic with tensors stored as bf16 where the caller says so: plain conv / linear
+    layers only (no stem, upsampling, concat, split-K, Winograd), precision 1."""
+    if precision != 1:
+        raise RuntimeError("bf16-stored tensors belong to the bf16 arithmetic (precision=1): the fp32-grade modes keep fp32 tensors")
+    ok = lambda t: t is None or (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16))
+    if not (ok(x) and ok(res) and ok(gate) and ok(out)):
+        raise RuntimeError("expected contiguous fp32 / bf16 CUDA tensors")
+    B, H, W, Cin = x.shape
+    assert Cin == p.Cin and not (p.stem or p.pixshuf or p.phase), "plain layers only"
+    Ho = (H + 2 * p.pad - p.KH) // p.stride + 1
+    Wo = (W + 2 * p.pad - p.KW) // p.stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, p.cols), device=x.device, dtype=out_dtype or torch.float32)
+    if B * max(H * W * Cin, Ho * Wo * p.cols) * 4 > _ADDR_LIMIT:
+        raise RuntimeError("tensor past the 32-bit addressing limit of one launch: split the batch")
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.res, d.y = _p(x), _p(p.w), _p(p.scale), _p(p.shift), _p(res), _p(out)
+    d.B, d.H, d.W, d.Cin, d.Cin2 = B, H, W, Cin, 0
+    d.Ho, d.Wo, d.Cout = Ho, Wo, p.cols
+    d.KH, d.KW, d.stride, d.pad = p.KH, p.KW, p.stride, p.pad
+    d.Kpad, d.ups, d.act = p.Kpad, 0, p.act if act is None else act
+    d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), 0, 0, 1
+    if gate is not None:
+        assert tuple(gate.shape) == tuple(out.shape), (gate.shape, out.shape)
+        d.gate = gate.data_ptr()
+    d.precision = 1
+    b16 = lambda t: t is not None and t.dtype == torch.bfloat16
+    d.io_bf16 = (1 if b16(x) else 0) | (2 if b16(out) else 0) | (4 if b16(res) else 0) | (8 if b16(gate) else 0)
+    _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out
 
 

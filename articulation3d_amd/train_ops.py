@@ -21,7 +21,10 @@ def choose_wgrad_slices(P: int, tiles: int) -> int:
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int, pad: int,
                scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None, precision: int = 0) -> torch.Tensor:
     """dw [Cout, KH*KW*Cin] (=/+=) weight gradient of y = conv(x) given dy (NHWC tensors)."""
-    _req(x), _req(dy), _req(dw)
+    # (precision 1 only: x / dy may be STORED as bf16 -- a3d_wgrad_desc.io_bf16; the kernel rounds them to bf16 anyway)
+    _req(x, x.dtype if (precision == 1 and x.dtype == torch.bfloat16) else torch.float32)
+    _req(dy, dy.dtype if (precision == 1 and dy.dtype == torch.bfloat16) else torch.float32)
+    _req(dw)
     B, H, W, Cin = x.shape
     B2, Ho, Wo, Cout = dy.shape
     assert B == B2 and dw.numel() == Cout * KH * KW * Cin, (x.shape, dy.shape, dw.shape)
@@ -33,6 +36,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     d.splitk = int(splitk) if splitk else choose_wgrad_slices(B * Ho * Wo, tiles)
     d.accumulate = int(accumulate)
     d.precision = int(precision)
+    d.io_bf16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if dy.dtype == torch.bfloat16 else 0)
     ws = torch.empty(_lib.lib().a3d_wgrad_workspace_bytes(C.byref(d)) // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
     _lib.check(_lib.lib().a3d_conv_wgrad_nhwc_f32(C.byref(d), _stream()), "a3d_conv_wgrad_nhwc_f32")

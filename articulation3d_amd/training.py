@@ -20,7 +20,8 @@ Design (MI355X-first, no autograd engine):
     (dead slots are zero rows without loss or gradient): the step never waits for the host.  Parity tests read the drawn
     index sets back and hand them to the oracle.
 Precision: fp32 by default; `precision="bf16"` is the reference config's autocast arithmetic (bf16 MFMA, fp32 accumulation,
-fp32 tensors and master weights) on every trainable layer.
+fp32 master weights) on every trainable layer, with the ResNet stages' activations and gradients STORED as bf16 (round 3:
+a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16; `storage="fp32"` keeps them fp32) and a bf16 gradient all-reduce payload.
 """
 from __future__ import annotations
 
@@ -133,7 +134,7 @@ class DetectorTrainer:
     copied into the flat buffer at construction and written back by `export_state_dict`)."""
 
     def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "fp32",
-                 grad_payload: Optional[str] = None):
+                 grad_payload: Optional[str] = None, storage: Optional[str] = None):
         """precision: "fp32" (fp32 MFMA everywhere) or "bf16" -- the reference's autocast setting: every trainable conv / linear
         multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
         weights, activations, gradients, losses and the optimiser stay fp32."""
@@ -143,6 +144,12 @@ class DetectorTrainer:
         # step in _prepare_filters -- and for every weight gradient
         # gradient all-reduce payload: bf16 in the bf16 step (configs[4]: DDP's bf16_compress_hook semantics), fp32 otherwise
         self.grad_payload = grad_payload or ("bf16" if precision == "bf16" else "fp32")
+        # storage of the ResNet stages' activations and gradients (res3-res5: the bulk of the step's activation bytes): bf16 in the bf16
+        # step -- what autocast itself keeps (conv outputs are bf16 tensors under torch.autocast) -- unless storage="fp32" is asked for.
+        # FPN / RPN / box-head tensors, the pyramid gradients (float atomics) and everything a loss kernel reads stay fp32.
+        self.storage = storage or ("bf16" if precision == "bf16" else "fp32")
+        assert self.storage in ("fp32", "bf16") and (self.storage == "fp32" or precision == "bf16"), "bf16 storage belongs to the bf16 step"
+        self._st = torch.bfloat16 if self.storage == "bf16" else None
         self.prec = {"fp32": 0, "bf16": 1, "bf16x3": "bf16x3"}[precision]
         self.wgrad_prec = {"fp32": 0, "bf16": 1, "bf16x3": 2}[precision]
         self.s = solver or SolverCfg()
@@ -330,10 +337,11 @@ class DetectorTrainer:
         for name, nblk, _mid, _cout in RES_STAGES:
             for i in range(nblk):
                 p = f"backbone.bottom_up.{name}.{i}."
-                sc = self._conv(x, L[p + "shortcut"].fwd()) if i == 0 else x
-                a = self._conv(x, L[p + "conv1"].fwd())
-                b = self._conv(a, L[p + "conv2"].fwd())
-                out = self._conv(b, L[p + "conv3"].fwd(), res=sc)
+                st = self._st  # (bf16 storage: these four tensors per block are the step's big activations)
+                sc = self._conv(x, L[p + "shortcut"].fwd(), out_dtype=st) if i == 0 else x
+                a = self._conv(x, L[p + "conv1"].fwd(), out_dtype=st)
+                b = self._conv(a, L[p + "conv2"].fwd(), out_dtype=st)
+                out = self._conv(b, L[p + "conv3"].fwd(), res=sc, out_dtype=st)
                 saved[p] = (x, a, b)
                 relu_outputs += [a, b, out]
                 x = out
@@ -447,15 +455,16 @@ class DetectorTrainer:
         dx_up = None  # gradient arriving at a stage output from the stage above (un-gated)
         for name, nblk, _mid, _cout in reversed(RES_STAGES):
             l = int(name[3:])
-            g = self._conv(dprev[l], L[f"backbone.fpn_lateral{l}"].bwd(), res=dx_up, gate=res[name])
+            st = self._st
+            g = self._conv(dprev[l], L[f"backbone.fpn_lateral{l}"].bwd(), res=dx_up, gate=res[name], out_dtype=st)
             for i in reversed(range(nblk)):
                 p = f"backbone.bottom_up.{name}.{i}."
                 x_in, a, b = saved[p]
                 c1, c2, c3 = L[p + "conv1"], L[p + "conv2"], L[p + "conv3"]
                 self._wgrad(c3, b, g)
-                db_ = self._conv(g, c3.bwd(), gate=b)
+                db_ = self._conv(g, c3.bwd(), gate=b, out_dtype=st)
                 self._wgrad(c2, a, db_)
-                da_ = self._conv(db_, c2.bwd(), gate=a)
+                da_ = self._conv(db_, c2.bwd(), gate=a, out_dtype=st)
                 self._wgrad(c1, x_in, da_)
                 if i == 0:
                     self._wgrad(L[p + "shortcut"], x_in, g)
@@ -465,7 +474,7 @@ class DetectorTrainer:
                     low = self._conv(da_, c1.bwd(), res=low, out=low)
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
-                    g = self._conv(da_, c1.bwd(), res=g, gate=x_in)
+                    g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))

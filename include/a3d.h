@@ -146,6 +146,10 @@ typedef struct a3d_conv_desc {
                               many workgroups each compute ONE Winograd plane's product into wino_m [16][tiles][Cout], and a second
                               launch folds the planes in the same order and applies the epilogue -- the same bits, a 16th of the
                               per-workgroup latency                                                                                 */
+    int io_bf16;           /* precision 1 only (the training step's autocast arithmetic): which tensors are STORED as bf16 in HBM
+                              instead of fp32 -- bit 0: x, bit 1: y, bit 2: res, bit 3: gate (x / y / res / gate then point at bf16
+                              data).  The kernel rounds its operands to bf16 anyway, so a bf16 x gives the same products; y is
+                              rounded to nearest even on the way out.  BASELINE configs[4]: bf16 activations and gradients.       */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -384,6 +388,7 @@ typedef struct a3d_wgrad_desc {
     int splitk;         /* >= 1 pixel slices (summed in slice order: deterministic) */
     int accumulate;     /* 1: dw += (weights shared by several call sites, e.g. the RPN head over 5 levels) */
     int precision;      /* 0: fp32 MFMA; 1: bf16 MFMA, fp32 accumulation; 2: fp32-grade 3-way bf16 split (see a3d_conv_desc.precision) */
+    int io_bf16;        /* precision 1 only: bit 0: x is stored as bf16, bit 1: dy is stored as bf16 (dw stays fp32)              */
 } a3d_wgrad_desc;
 size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
 int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);

@@ -668,3 +668,68 @@ def test_bf16_gradient_payload_casts_equal_torchs():
     back = torch.empty_like(g)
     _lib.check(_lib.lib().a3d_bf16_to_f32(g16.data_ptr(), back.data_ptr(), g.numel(), st), "a3d_bf16_to_f32")
     assert torch.equal(back, g16.to(torch.float32))
+
+
+def test_bf16_storage_kernels_equal_the_fp32_storage_launch_on_the_same_values(ops, T):
+    """a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16: tensors STORED as bf16.  The bf16 arithmetic rounds its operands to bf16 anyway,
+    so a launch on bf16-stored x / res / gate gives exactly what the fp32-storage launch gives on the same (already rounded) values,
+    and a bf16-stored output is that result rounded to nearest even."""
+    torch.manual_seed(8)
+    for (B, H, W, Cin, Cout, k, st) in ((3, 30, 40, 256, 128, 1, 1), (2, 31, 39, 128, 128, 3, 1), (2, 30, 40, 256, 512, 1, 2)):
+        x16 = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
+        pk = ops.pack_conv(torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5), torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+        Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+        res16 = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+        gate16 = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+        ref = ops.conv2d(x16.float(), pk, res=res16.float(), precision=1)
+        assert ops.last_conv_variant().startswith("conv_bf16_kernel")
+        got = ops.conv2d(x16, pk, res=res16, precision=1)                       # bf16 in, fp32 out
+        assert got.dtype == torch.float32 and torch.equal(got, ref)
+        got16 = ops.conv2d(x16, pk, res=res16, precision=1, out_dtype=torch.bfloat16)
+        assert got16.dtype == torch.bfloat16 and torch.equal(got16, ref.to(torch.bfloat16))
+        refg = ops.conv2d(x16.float(), pk, res=res16.float(), gate=gate16.float(), precision=1, act=ops.ACT_NONE)
+        gotg = ops.conv2d(x16, pk, res=res16.float(), gate=gate16, precision=1, act=ops.ACT_NONE, out_dtype=torch.bfloat16)  # mixed storage
+        assert torch.equal(gotg, refg.to(torch.bfloat16))
+        # weight gradient with bf16-stored x / dy (and mixed)
+        dy16 = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+        dw_ref = torch.empty((Cout, k * k * Cin), device="cuda")
+        T.conv_wgrad(x16.float(), dy16.float(), dw_ref, KH=k, KW=k, stride=st, pad=k // 2, precision=1)
+        for xa, dya in ((x16, dy16), (x16, dy16.float()), (x16.float(), dy16)):
+            dw = torch.empty_like(dw_ref)
+            T.conv_wgrad(xa, dya, dw, KH=k, KW=k, stride=st, pad=k // 2, precision=1)
+            assert torch.equal(dw, dw_ref)
+    with pytest.raises(RuntimeError):  # bf16 storage belongs to the bf16 arithmetic
+        ops.conv2d(x16, pk, precision=3)
+
+
+def test_bf16_step_stores_its_resnet_activations_and_gradients_as_bf16(hip_model, oracle):
+    """BASELINE configs[4] ("bf16"): in the bf16 step the ResNet stages' activations and gradients live in HBM as bf16 (what
+    torch.autocast keeps), the gradient all-reduce payload is bf16, master weights / FPN / RPN / box-head tensors stay fp32.
+    Against the same step with fp32 storage, on the same sampled sets: RPN losses within 1 %, objectness gradients within 5 %."""
+    from articulation3d_amd.training import DetectorTrainer
+    from oracle import train_oracle as TO
+
+    frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
+    tg = TO.synthetic_targets(2)
+    gb, gc = [t[0] for t in tg], [t[1] for t in tg]
+    tf = DetectorTrainer(hip_model, seed=5, precision="bf16", storage="fp32")
+    lf, aux = tf.forward_backward(frames, gb, gc)
+    rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
+    samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=[ri[i, : int(rc[i])].long() for i in range(2)])
+    gf = {k: v.cpu() for k, v in tf.export_grads().items()}
+    tb = DetectorTrainer(hip_model, seed=5, precision="bf16")
+    assert tb.storage == "bf16" and tb.grad_payload == "bf16" and tf.storage == "fp32"
+    lb, auxb = tb.forward_backward(frames, gb, gc, samples=samples)
+    gbf = {k: v.cpu() for k, v in tb.export_grads().items()}
+    assert all(t.dtype == torch.bfloat16 for t in auxb["relu_outputs"][:39])       # res3-res5: 13 blocks x (a, b, out)
+    assert all(t.dtype == torch.float32 for t in aux["relu_outputs"])
+    assert auxb["feats"]["p2"].dtype == torch.float32 and tb.params.dtype == torch.float32 and tb.grads.dtype == torch.float32
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):
+        assert abs(lb[k].item() - lf[k].item()) < 0.01 * abs(lf[k].item()) + 1e-3, (k, lb[k].item(), lf[k].item())
+    rpn = [k for k in gf if k.startswith("proposal_generator.rpn_head.")]
+    errs = {k: l2rel(gbf[k], gf[k]) for k in rpn}
+    print("bf16 storage vs fp32 storage (bf16 arithmetic), RPN-head gradients rel L2:", {k.split("rpn_head.")[1]: round(v, 4) for k, v in errs.items()})
+    assert max(v for k, v in errs.items() if "objectness" in k) < 0.05
+    assert all(bool(torch.isfinite(v).all()) for v in gbf.values())
+    for k in gf:
+        assert 0.5 < float(gbf[k].norm() / (gf[k].norm() + 1e-30)) < 2.0, k

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (reference: IMS_PER_BATCH 16 over 8 GPUs)")
     ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--storage", default=None, choices=["fp32", "bf16"], help="res3-res5 activations / gradients in HBM (default: bf16 in the bf16 step)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 = autocast arithmetic (bf16 MFMA, fp32 accumulate); bf16x3 = fp32-grade 3-way bf16 split on the non-Winograd layers")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE oracle step (autograd on the host cores)")
@@ -71,7 +72,7 @@ def main():
     from articulation3d_amd.utils.synthetic import synthetic_frames
 
     model, _cfg = build_detector(0.5, dev)
-    tr = DetectorTrainer(model, seed=2020 + rank, precision=args.precision)
+    tr = DetectorTrainer(model, seed=2020 + rank, precision=args.precision, storage=args.storage)
     B = args.batch
     frames = torch.from_numpy(synthetic_frames(B, seed=2020 + rank)).to(dev)
     tg = synthetic_targets(B, 2020 + rank)
