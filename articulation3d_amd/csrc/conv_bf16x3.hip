@@ -318,8 +318,14 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
             if constexpr (WDMA) {
                 if constexpr (DPWN == 2) __asm__ volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else __asm__ volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                // A BARE barrier.  __syncthreads() carries a workgroup fence, and in front of a fence the compiler completes every
+                // LDS-DMA it has seen issued (it emitted vmcnt(2) here: the DMA of chunk it+2, one step old, had to land as well --
+                // an L2 round trip exposed in every chunk, the 60 % of parked wave-cycles PMC showed on these layers).
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
             }
-            __syncthreads();
             X3_TERM(1, 0)
             read_frags(cur ^ 1, fan, fbn);
             if constexpr (WDMA) {
@@ -408,12 +414,14 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
         float *T = reinterpret_cast<float *>(lds + (wave >> 1) * BUF) + (wave & 1) * 1024;
         const int pr = lane & 31, ph = lane >> 5;
         const int qr = lane >> 3, qc = lane & 7;
+        float vmaxs[TM][4];
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const int mb = m0 + (wm * TM + mi) * 32;
             const int mp = mb + pr;
             const float unx = (F16 && mp < M) ? 1.f / a3d_in_scale(d, mp / hwo) : 1.f, unw = F16 ? 1.f / sw : 1.f;
-            float vmax[4] = {0.f, 0.f, 0.f, 0.f};
+            float (&vmax)[4] = vmaxs[mi];
+            vmax[0] = vmax[1] = vmax[2] = vmax[3] = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
@@ -453,7 +461,22 @@ __global__ __launch_bounds__(256, 3) void conv_x3_kernel(const a3d_conv_desc d, 
                     *reinterpret_cast<f32x4 *>(d.y + orow * d.Cout + n) = v;
                 }
             }
-            if (d.y_amax) {
+        }
+        // The maxima are recorded behind the wave's LAST store: the pre-check read of an image's slot queues at the L2 behind the
+        // atomics of every other workgroup, and in front of the second row block it held that block's stores back.
+        const int mb0 = m0 + wm * TM * 32;
+        const bool whole = d.y_amax && mb0 < M && mb0 / hwo == min(mb0 + TM * 32 - 1, M - 1) / hwo;  // all the wave's rows in one image: ONE note
+        if (whole) {
+            float v = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) v = fmaxf(v, fmaxf(fmaxf(vmaxs[mi][0], vmaxs[mi][1]), fmaxf(vmaxs[mi][2], vmaxs[mi][3])));
+            a3d_note_amax(d.y_amax, mb0 / hwo, v, true);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int mb = m0 + (wm * TM + mi) * 32;
+            const float (&vmax)[4] = vmaxs[mi];
+            if (d.y_amax && !whole) {
                 const int mlast = min(mb + 31, M - 1);
                 if (mb < M && mb / hwo == mlast / hwo) {  // the tile's rows belong to one image (uniform per wave): one reduction
                     a3d_note_amax(d.y_amax, mb / hwo, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
@@ -541,6 +564,10 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
         d = &dd;
     }
     if (d->precision == 3 && (!d->in_amax || !(d->w_scale > 0.f))) return A3D_ERR_ARG;
+    if (d->precision == 3 && (d->tune == 0 || d->tune == 13)) {  // HBM-bound 1x1 layers, Cin <= 256: x read once (bit-identical results)
+        const int rx = a3d_conv_launch_xs_h2(d, s);
+        if (rx != A3D_ERR_UNSUPPORTED) return rx;
+    }
     const int rw = a3d_conv_launch_bf16x3_wide(d, s);  // wide and large layers with pre-split weights (bit-identical results)
     if (rw != A3D_ERR_UNSUPPORTED) return rw;
     if (d->stem) {  // the 7x7 stem (x is [B,H,W,4]): its own loader, 128 x 64 tiles

@@ -131,6 +131,9 @@ void a3d_note_variant(const char *fmt, ...) __attribute__((format(printf, 1, 2))
 // v2 kernel family (conv_gemm_v2.hip): buffer-addressed, branch-free gather + software-pipelined main loop.
 // Returns A3D_ERR_UNSUPPORTED when the descriptor needs the general kernel.
 int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
+// fp16x2 pointwise layers with Cin <= 256, activations stationary in registers (conv_xs_h2.hip); tune 13 forces it on any eligible
+// layer, tune 14 keeps it off.  A3D_ERR_UNSUPPORTED: not such a layer.
+int a3d_conv_launch_xs_h2(const a3d_conv_desc *d, hipStream_t s);
 
 // Persistent pointwise kernel (conv_pw.hip): 1x1 stride-1 layers with K <= 2048 and enough tiles to keep a persistent
 // grid busy.  Returns A3D_ERR_UNSUPPORTED otherwise.  `force` skips the grid-size heuristic (A/B measurements).

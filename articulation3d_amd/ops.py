@@ -640,7 +640,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             e0.record()
             _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
             e1.record()
-            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin, "f32"))
+            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin, "f32", _stream()))
             return out
         if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
             e0, e1, e2 = ev(), ev(), ev()
@@ -650,9 +650,9 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             e1.record()
             _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
             e2.record()
-            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none"))
+            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none", _stream()))
             CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin,
-                                {2: "bf16x6", 3: "f16x3"}.get(int(d.precision), "f32")))
+                                {2: "bf16x6", 3: "f16x3"}.get(int(d.precision), "f32"), _stream()))
             return out
         e0, e1 = ev(), ev()
         e0.record()
@@ -661,7 +661,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
         executed = 2.0 * B * Ho * Wo * p.cols * (4 * p.Cin if p.phase == 5 else k_real)  # (fused phases: 4 of the 9 taps per column)
         fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
-        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)]))
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)], _stream()))
         return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out

@@ -283,6 +283,28 @@ def test_fp16x2_wide_and_narrow_direct_kernels_agree_bit_for_bit(ops):
     assert torch.equal(wide, narrow)
 
 
+@pytest.mark.parametrize("case", [(8, 120, 160, 64, 256, True), (8, 120, 160, 64, 256, False), (8, 60, 80, 128, 512, True), (5, 37, 41, 128, 128, False),
+                                  (4, 30, 40, 256, 1024, True), (2, 60, 80, 256, 256, False), (64, 15, 20, 256, 128, True), (1, 3, 5, 64, 128, True),
+                                  (37, 1, 1, 128, 256, False)])
+def test_activation_stationary_pointwise_kernel_agrees_bit_for_bit_with_the_tiled_one(ops, case):
+    """conv_h2xs_kernel (conv_xs_h2.hip: a wave keeps its 32 pixels' channels in registers and walks over all of N; the filter streams
+    through an LDS ring) against conv_h2_kernel on the same layer: same split, same k order, same epilogue -- outputs AND recorded
+    per-image maxima are identical, so the launcher may choose by layer size.  Ragged pixel counts (waves that straddle two images,
+    a last tile with rows past the end), the tail split along N and every Cin the kernel takes."""
+    B, H, W, Cin, Cout, with_res = case
+    torch.manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-2, 2, B, device="cuda")[:, None, None, None]
+    res = torch.randn(B, H, W, Cout, device="cuda") if with_res else None
+    pk = ops.pack_conv(torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5, torch.randn(Cout) * 0.1, None, 1, 0, ops.ACT_RELU)
+    a = ops.conv2d(x, pk, res=res, precision=3, tune=13)
+    assert ops.last_conv_variant() == f"conv_h2xs_kernel<{Cin}>", ops.last_conv_variant()
+    b = ops.conv2d(x, pk, res=res, precision=3, tune=14)
+    assert ops.last_conv_variant().startswith(("conv_h2_kernel", "conv_h2w_kernel")), ops.last_conv_variant()
+    assert torch.equal(a, b)
+    assert torch.equal(ops.amax_of(a), ops.amax_of(b))
+    assert float(ops.amax_of(a).max()) > 0
+
+
 def test_plane_split_winograd_equals_the_one_launch_form_bit_for_bit(ops):
     """Small fp16x2 Winograd problems run one plane per workgroup into a3d_conv_desc.wino_m and fold afterwards (wino_fold_kernel): the
     same multiply-adds in the same order as the one-launch kernel -- outputs and recorded maxima are identical."""

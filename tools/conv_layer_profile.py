@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 t, ops.CONV_TIMING = ops.CONV_TIMING, None
 tot = 0.0
 print(f"{'kernel':36s} {'shape':44s} {'GFLOP exec':>10s} {'ms':>8s} {'fp32-eq TF/s':>12s}")
-for name, fl, a, b, shape, ex, pipe in t:
+for name, fl, a, b, shape, ex, pipe, _st in t:
     ms = a.elapsed_time(b)
     tot += ms
     print(f"{name[:36]:36s} {shape:44s} {ex / 1e9:10.2f} {ms:8.3f} {ex / ms / 1e9:12.1f}")

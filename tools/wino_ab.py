@@ -16,7 +16,7 @@ def bench(B, H, W, Cin, Cout, tunes=(201, 203, 205)):
         for _ in range(6):
             y = ops.conv2d(x, p, wino=True, tune=t)
         torch.cuda.synchronize()
-        tm = [a.elapsed_time(b) for n, fl, a, b, sh in ops.CONV_TIMING if n.startswith("wino_gemm")][1:]
+        tm = [a.elapsed_time(b) for n, fl, a, b, *_ in ops.CONV_TIMING if n.startswith("wino_gemm")][1:]
         ops.CONV_TIMING = None
         if ref is None: ref = y.clone()
         out.setdefault(t, []).append(min(tm))
