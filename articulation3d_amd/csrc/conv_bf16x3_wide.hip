@@ -426,12 +426,16 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 
     const bool has_res = d.res != nullptr && d.splitk == 1;
     const int hwo = d.Ho * d.Wo;
+    float vmaxs[TM];
+    int bimgs[TM];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
         const bool mok = m < M;
         const int bimg = mok ? m / hwo : 0;  // image / ROI of this lane's output pixel
-        float vmax = 0.f;
+        bimgs[mi] = mok ? bimg : -1;
+        float &vmax = vmaxs[mi];
+        vmax = 0.f;
         if (mok) {
         // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
         const float unx = F16 ? 1.f / a3d_in_scale(d, bimg) : 1.f, unw = F16 ? 1.f / sw : 1.f;
@@ -471,9 +475,25 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
             }
         }
         }
-        // (every lane of the wave gets here; split-K: the reducer.  Lanes l and l+32 hold the same row: one of them reports it -- with
-        // one image per row, as in the FC layers, every report is a pre-checked atomic)
-        if (d.y_amax && d.splitk == 1) a3d_note_amax(d.y_amax, bimg, fmaxf(vmax, __shfl_xor(vmax, 32, 64)), mok && lane < 32);
+    }
+    // The maxima are recorded behind the wave's LAST store (the pre-check read of a slot waits for every store issued before it and
+    // queues at the L2 behind the other workgroups' atomics: between the row blocks it held the second block's stores back).  Every
+    // lane of the wave gets here; split-K: the reducer records.  Lanes l and l+32 hold the same row: one of them reports it -- with one
+    // image per row, as in the FC layers, every report is a pre-checked atomic.  Row blocks of one image share one report.
+    if (d.y_amax && d.splitk == 1) {
+        bool merged = false;
+        if constexpr (TM == 2) {
+            if (__all(bimgs[0] == bimgs[1] && bimgs[0] >= 0)) {
+                const float v = fmaxf(vmaxs[0], vmaxs[1]);
+                a3d_note_amax(d.y_amax, bimgs[0], fmaxf(v, __shfl_xor(v, 32, 64)), lane < 32);
+                merged = true;
+            }
+        }
+        if (!merged) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                a3d_note_amax(d.y_amax, max(bimgs[mi], 0), fmaxf(vmaxs[mi], __shfl_xor(vmaxs[mi], 32, 64)), bimgs[mi] >= 0 && lane < 32);
+        }
     }
 }
 }  // namespace

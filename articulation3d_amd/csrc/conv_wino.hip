@@ -84,6 +84,91 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
     }
 }
 
+// fp16x2 arithmetic (a3d_conv_desc.precision == 3): the same transform, but V leaves the kernel ALREADY SPLIT into the two fp16 planes
+// the matrix pipe multiplies -- (B^T d B) * s = h + l with s = wino_v_scale of the tile's image (a power of two from the recorded input
+// maxima: the split the GEMM used to perform in its loop, element for element the same bits) -- in the chunk-major layout the GEMM's
+// LDS-DMA wants: Vs [16 planes][C/32 chunks][h | l][T tiles][32 k] fp16.  The bytes are those of the fp32 tensor (2 + 2 per element).
+// A thread transforms 4 channels; the two threads of an 8-channel k slot swap halves so that one stores the slot's 8 h values and the
+// other its 8 l values (16 B each).  What it buys: wino_gemm_x3w_kernel<.., F16> moves V global -> LDS without registers, without the
+// 2.7 vector instructions per MFMA the split cost there (PMC), without VGPR -> LDS stores.
+typedef _Float16 wi_h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wi_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wi_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restrict__ x, const float *__restrict__ x2, unsigned char *__restrict__ Vs,
+                                                            const float *__restrict__ in_amax, const float *__restrict__ in_amax2, int B, int H, int W,
+                                                            int Cin, int Cin2, int ups, int Ty, int Tx) {
+    const int C = Cin + Cin2;
+    const int Hl = ups ? 2 * H : H, Wl = ups ? 2 * W : W;
+    const size_t T = (size_t)B * Ty * Tx;
+    const size_t tile = T * 64;  // bytes of one (plane, chunk, h | l) tile
+    const int KC = C >> 5;
+    // A wave = 8 consecutive tiles x one 32-channel chunk (lane = 8 * tile + channel quad): a store instruction then writes two runs of
+    // 512 B (the h rows and the l rows of the 8 tiles); with a wave = one tile x all channels it wrote 64-byte pieces a whole tile
+    // apart, and the kernel fell from 5.3 to 3.0 TB/s.  Loads: 128 contiguous bytes per pixel.
+    const size_t witems = ((T + 7) / 8) * KC;
+    const int lane = threadIdx.x & 63;
+    for (size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < witems; w += (size_t)gridDim.x * (blockDim.x >> 6)) {
+        const int kcw = (int)(w % KC);
+        const size_t t = (w / KC) * 8 + (lane >> 3);
+        if (t >= T) continue;  // (whole tiles drop out: the two lanes of a k slot stay together)
+        const int c = kcw * 32 + (lane & 7) * 4;
+        const int tx = (int)(t % Tx);
+        const size_t r = t / Tx;
+        const int ty = (int)(r % Ty);
+        const int b = (int)(r / Ty);
+        const bool second = c >= Cin;
+        const float *src = second ? x2 : x;
+        const int cs = second ? Cin2 : Cin, cc = second ? c - Cin : c;
+        float am = in_amax[b];
+        if (in_amax2) am = fmaxf(am, in_amax2[b]);
+        const float sv = 0.25f * a3d_pow2_scale(am);  // wino_v_scale
+        f32x4 d[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ly = 2 * ty - 1 + p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lx = 2 * tx - 1 + q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ly < (unsigned)Hl && (unsigned)lx < (unsigned)Wl) {
+                    const int sy = ups ? ly >> 1 : ly, sx = ups ? lx >> 1 : lx;
+                    v = *reinterpret_cast<const f32x4 *>(src + (((size_t)b * H + sy) * W + sx) * cs + cc);
+                }
+                d[p][q] = v;
+            }
+        }
+        f32x4 m[4][4];  // B^T d
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            m[0][q] = d[0][q] - d[2][q];
+            m[1][q] = d[1][q] + d[2][q];
+            m[2][q] = d[2][q] - d[1][q];
+            m[3][q] = d[1][q] - d[3][q];
+        }
+        const bool odd = (c >> 2) & 1;  // second half of its 8-channel k slot: stores the slot's l values; the first half stores the h values
+        const int kc = c >> 5, slot = (c & 31) >> 3;
+        unsigned char *o = Vs + ((size_t)kc * 2 + (odd ? 1 : 0)) * tile + t * 64 + slot * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // (B^T d) B
+            const f32x4 vv[4] = {m[u][0] - m[u][2], m[u][1] + m[u][2], m[u][2] - m[u][1], m[u][1] - m[u][3]};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 xs = vv[v] * sv;
+                const wi_h16x4 h = __builtin_convertvector(xs, wi_h16x4);
+                const wi_h16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wi_h16x4);
+                const wi_u32x2 hb = __builtin_bit_cast(wi_u32x2, h), lb = __builtin_bit_cast(wi_u32x2, l);
+                const wi_u32x2 give = odd ? hb : lb;  // the half the partner stores
+                wi_u32x2 got;
+                got[0] = __shfl_xor(give[0], 1, 64);
+                got[1] = __shfl_xor(give[1], 1, 64);
+                // first half: [own h (channels c..c+3) | partner's h (c+4..c+7)]; second half: [partner's l (c-4..c-1) | own l]
+                const wi_u32x4 out = odd ? wi_u32x4{got[0], got[1], lb[0], lb[1]} : wi_u32x4{hb[0], hb[1], got[0], got[1]};
+                *reinterpret_cast<wi_u32x4 *>(o + (size_t)(u * 4 + v) * KC * 2 * tile) = out;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. 16-plane GEMM with the output transform folded into the accumulators.
 // ------------------------------------------------------------------------------------------------
@@ -554,7 +639,10 @@ __device__ __forceinline__ void wdma16(__amdgpu_buffer_rsrc_t r, __bf16 *lds_dst
 
 constexpr int X3W_BN = 128, X3W_LKB = 32;
 constexpr int x3w_buf(int WM, int NP) { return NP * (32 * WM + X3W_BN) * X3W_LKB; }  // 16-bit elements of one stage: X and W, NP planes each
-constexpr int x3w_lds_bytes(int WM, int NP) { return 2 * x3w_buf(WM, NP) * 2 + 2 * X3W_BN * 4; }
+// stages of the operand ring: the bf16x3 form double-buffers (V passes through registers); the fp16x2 form receives BOTH operands
+// pre-split by LDS-DMA and keeps 3 (two workgroups per CU) or 4 (one) stages in flight
+constexpr int x3w_stages(int WM, int NP) { return NP == 2 ? (WM == 2 ? 3 : 4) : 2; }
+constexpr int x3w_lds_bytes(int WM, int NP) { return x3w_stages(WM, NP) * x3w_buf(WM, NP) * 2 + 2 * X3W_BN * 4; }
 
 // WM = wave rows: 2 -> 64 tiles x 128 channels, 256 threads, two workgroups per CU; 4 -> 128 tiles x 128 channels, 512 threads, one
 // workgroup per CU (every 64-tile block streams all of U3 -- 6 B per weight -- from L2: 30 GB per p2 layer; 128-tile blocks halve it)
@@ -571,8 +659,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     constexpr int PLX = BM * LKB, PLW = BN * LKB, BUF = x3w_buf(WM, NP);
     constexpr int DPW = 8 * NP / NW;  // weight DMA instructions per wave and chunk
     static_assert(XR == 2, "the counted vmcnt waits below assume two V loads per chunk");
+    constexpr int NST = x3w_stages(WM, NP);
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    float *ss = reinterpret_cast<float *>(lds + 2 * BUF);
+    float *ss = reinterpret_cast<float *>(lds + NST * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -615,6 +704,23 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             wdma16(ru, Wt + p * PLW + g * 16 * LKB, wvoff, base + __builtin_amdgcn_readfirstlane(p * u3tile + g * 1024));
         }
         ++dma_c;
+    };
+    // fp16x2: V arrives pre-split too -- wino_input_h2_kernel wrote it as fp16 planes, chunk-major [16][C/32][2][T][32], scaled per image
+    // (wino_v_scale) -- and takes the same road as the filter: a (f, chunk, plane) tile of this workgroup's BM rows is a contiguous run
+    // of BM / 16 DMA instructions (16 rows x 64 B each), two instructions per wave and chunk, with the filter's slot swizzle.  No V
+    // registers, no split in the loop, no VGPR -> LDS stores.  (Rows past T read the next plane's rows or zeros: never stored.)
+    constexpr int DPV = 2;
+    static_assert(2 * (BM / 16) == DPV * NW, "two V DMA instructions per wave and chunk");
+    auto dma_v = [&](const int buf, const int c) {  // c = flat (f, kc) index of the chunk (clamped like the filter's)
+        __bf16 *X = lds + buf * BUF;
+        const size_t tile = (size_t)a.T * 64;  // bytes of one (f, chunk, plane) tile
+        const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(reinterpret_cast<const char *>(a.V) + (size_t)min(c, NIT - 1) * 2 * tile, (unsigned)(2 * tile));
+#pragma unroll
+        for (int i = 0; i < DPV; ++i) {
+            const int j = wave * DPV + i;
+            const int p = j / (BM / 16), g = j % (BM / 16);
+            wdma16(rv, X + p * PLX + g * 16 * LKB, wvoff, __builtin_amdgcn_readfirstlane(p * (int)tile + (t0 + g * 16) * 64));
+        }
     };
     f32x4 xsA[XR], xsB[XR];
     int ld_f = pf, ld_kc = 0;
@@ -827,8 +933,63 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         X3W_FENCE
     };
 
-    // prologue: W(0), W(1) by DMA; V(0) split into stage 0; V(1), V(2) staged in registers; S0(0) read
     Frags F0, F1;
+    if constexpr (F16) {
+        // fp16x2 schedule.  Chunk c lives in stage c % NST.  An iteration = the two 16-deep steps of one chunk (three product terms of
+        // two MFMAs each) with ONE barrier between them.  Behind that barrier every wave has read all fragments of chunk c (S0(c)
+        // during the previous iteration, S1(c) during step 0), so the DMA of chunk c + NST goes straight into the stage of chunk c:
+        // it has NST - 1 iterations to land (two stages gave one: 12 MFMAs ~ 0.2 us against an L2 round trip of 0.5 - 1 us -- the
+        // waves sat at this wait in every chunk).  The barrier is a BARE s_barrier: __syncthreads() carries a fence, and in front of a
+        // fence the compiler completes every LDS-DMA in flight.
+        constexpr int OPS = DPW + DPV;  // vector-memory instructions per wave and chunk
+        int st = 0;                     // stage of the chunk being multiplied
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            dma_v(i, dma_c);
+            dma_w(i);
+        }
+        __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * OPS) : "memory");
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (scale / shift staged above)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            rdA(F0, 0, 0, p);
+            rdB(F0, 0, 0, p);
+        }
+        int cf = 0, ckc = 0;
+        for (int it = 0; it < nit; ++it) {
+            X3W_TERM(F0, 0, 0)
+            rdA(F1, st, 1, 0);
+            rdB(F1, st, 1, 0);
+            rdB(F1, st, 1, 1);
+            X3W_TERM(F0, 0, 1)
+            rdA(F1, st, 1, 1);
+            X3W_TERM(F0, 1, 0)
+            __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPS) : "memory");  // chunk it + 1 has landed (younger: NST - 2 chunks)
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_v(st, dma_c);  // chunk it + NST into the stage of chunk it
+            dma_w(st);
+            st = st == NST - 1 ? 0 : st + 1;
+            X3W_TERM(F1, 0, 0)
+            rdA(F0, st, 0, 0);
+            rdB(F0, st, 0, 0);
+            rdB(F0, st, 0, 1);
+            X3W_TERM(F1, 0, 1)
+            rdA(F0, st, 0, 1);
+            X3W_TERM(F1, 1, 0)
+            if constexpr (!PS) {
+                if (++ckc == KC) {
+                    ckc = 0;
+                    fold(mf, cf++);
+                }
+            }
+        }
+        // the DMAs past the last chunk land anywhere in the ring, the epilogue's tiles use the V areas of stages 0 and 1
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+    // prologue: W(0), W(1) by DMA; V(0) split into stage 0; V(1), V(2) staged in registers; S0(0) read
     dma_w(0);
     dma_w(1);
     load_chunk(xsA);
@@ -874,6 +1035,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             }
         }
         X3W_FENCE
+    }
     }
 #undef X3W_MIX
 #undef X3W_TERM
@@ -1135,6 +1297,12 @@ static int wino_launch_input(const a3d_conv_desc *d, hipStream_t s) {
     const size_t total = T * (C / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
+    if (d->precision == 3) {  // fp16x2: V pre-split into the two fp16 planes, chunk-major (what wino_gemm_x3w_kernel<.., true> DMAs)
+        if ((C & 31) || !d->in_amax) return A3D_ERR_ARG;
+        hipLaunchKernelGGL(wino_input_h2_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, reinterpret_cast<unsigned char *>(d->workspace), d->in_amax,
+                           d->in_amax2, d->B, d->H, d->W, d->Cin, d->Cin2, d->ups, Ty, Tx);
+        return A3D_OK;
+    }
     hipLaunchKernelGGL(wino_input_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, d->workspace, d->B, d->H, d->W,
                        d->Cin, d->Cin2, d->ups, Ty, Tx);
     return A3D_OK;
@@ -1180,7 +1348,9 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         // decouple), except where the 128-tile blocks finish in ONE round of the chip (small maps, a few hundred ROIs).  Measured
         // (ms, 64-tile | 128-tile): p2 256 -> 256 2.67 | 2.66, 60x80x256 0.73 | 0.75, 30x40x256 0.26 | 0.29, 15x20x512 0.25 | 0.24,
         // 276 ROIs 0.20 | 0.19.  Same kernel template, same operation order: bit-identical.
-        const int wmx = wm_force3 ? wm_force3 : (blocks4 <= 256 ? 4 : 2);
+        // (with both operands by DMA through a 3- / 4-stage ring: p2 256 -> 256 2.42 | 2.25, 60x80 0.68 | 0.69, 30x40 0.21 | 0.22, 276 ROIs
+        // 0.117 | 0.115 -- the 128-tile form issues 4 instead of 6 DMA instructions per wave and chunk and wins on the largest maps too)
+        const int wmx = wm_force3 ? wm_force3 : ((blocks4 <= 256 || blocks4 >= 2400) ? 4 : 2);
         static a3d_attr_once attr3;
         if (attr3.needed()) {
             if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||

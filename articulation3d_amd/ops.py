@@ -607,6 +607,9 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             shared = _WINO_SHARE.get(x.data_ptr())
             if shared is not None and (shared[0].shape != x.shape or d.tune != 0):
                 shared = None
+            # (the tiles' FORMAT belongs to the arithmetic: fp16x2 consumers read V pre-split into fp16 planes, the others fp32)
+            if shared is not None and shared[1] is not None and len(shared) > 2 and shared[2] != int(d.precision):
+                shared = None
         if shared is not None:
             d.w_wino_cm = None  # consumers of a shared input take the two-launch form so that V exists once for all of them
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
@@ -625,6 +628,10 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
                 d.wino_m = wino_m.data_ptr()
     if shared is not None:
         have_v, shared[1] = shared[1] is not None, ws
+        if len(shared) > 2:
+            shared[2] = int(d.precision)
+        else:
+            shared.append(int(d.precision))
         if CONV_TIMING is None:
             if not have_v:
                 _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
