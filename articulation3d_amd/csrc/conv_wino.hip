@@ -88,8 +88,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 // the matrix pipe multiplies -- (B^T d B) * s = h + l with s = wino_v_scale of the tile's image (a power of two from the recorded input
 // maxima: the split the GEMM used to perform in its loop, element for element the same bits) -- in the chunk-major layout the GEMM's
 // LDS-DMA wants: Vs [16 planes][C/32 chunks][h | l][T tiles][32 k] fp16.  The bytes are those of the fp32 tensor (2 + 2 per element).
-// A thread transforms 4 channels; the two threads of an 8-channel k slot swap halves so that one stores the slot's 8 h values and the
-// other its 8 l values (16 B each).  What it buys: wino_gemm_x3w_kernel<.., F16> moves V global -> LDS without registers, without the
+// What it buys: wino_gemm_x3w_kernel<.., F16> moves V global -> LDS without registers, without the
 // 2.7 vector instructions per MFMA the split cost there (PMC), without VGPR -> LDS stores.
 typedef _Float16 wi_h16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int wi_u32x2 __attribute__((ext_vector_type(2)));
@@ -145,9 +144,12 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restr
             m[2][q] = d[2][q] - d[1][q];
             m[3][q] = d[1][q] - d[3][q];
         }
-        const bool odd = (c >> 2) & 1;  // second half of its 8-channel k slot: stores the slot's l values; the first half stores the h values
-        const int kc = c >> 5, slot = (c & 31) >> 3;
-        unsigned char *o = Vs + ((size_t)kc * 2 + (odd ? 1 : 0)) * tile + t * 64 + slot * 16;
+        // a thread stores its 4 channels' h values (8 B) into the h rows and the l values into the l rows: the 8 lanes of a tile fill one
+        // 64-byte row, the 8 tiles of the wave one 512-byte run per instruction.  (Pairing lanes into 16-byte stores cost 32 LDS
+        // permutes and ~140 selects per thread and was slower.)
+        const int kc = c >> 5;
+        unsigned char *oh = Vs + (size_t)kc * 2 * tile + t * 64 + (c & 31) * 2;
+        const size_t pstride = (size_t)KC * 2 * tile;  // one Winograd plane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // (B^T d) B
             const f32x4 vv[4] = {m[u][0] - m[u][2], m[u][1] + m[u][2], m[u][2] - m[u][1], m[u][1] - m[u][3]};
@@ -156,14 +158,9 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restr
                 const f32x4 xs = vv[v] * sv;
                 const wi_h16x4 h = __builtin_convertvector(xs, wi_h16x4);
                 const wi_h16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wi_h16x4);
-                const wi_u32x2 hb = __builtin_bit_cast(wi_u32x2, h), lb = __builtin_bit_cast(wi_u32x2, l);
-                const wi_u32x2 give = odd ? hb : lb;  // the half the partner stores
-                wi_u32x2 got;
-                got[0] = __shfl_xor(give[0], 1, 64);
-                got[1] = __shfl_xor(give[1], 1, 64);
-                // first half: [own h (channels c..c+3) | partner's h (c+4..c+7)]; second half: [partner's l (c-4..c-1) | own l]
-                const wi_u32x4 out = odd ? wi_u32x4{got[0], got[1], lb[0], lb[1]} : wi_u32x4{hb[0], hb[1], got[0], got[1]};
-                *reinterpret_cast<wi_u32x4 *>(o + (size_t)(u * 4 + v) * KC * 2 * tile) = out;
+                *reinterpret_cast<wi_h16x4 *>(oh) = h;
+                *reinterpret_cast<wi_h16x4 *>(oh + tile) = l;
+                oh += pstride;
             }
         }
     }
