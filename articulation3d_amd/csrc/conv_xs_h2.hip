@@ -268,8 +268,10 @@ int a3d_conv_launch_xs_h2(const a3d_conv_desc *d, hipStream_t s) {
     if (M * d->Cin * 4 >= ((size_t)1 << 31) || (size_t)d->Cout * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
     // Where it pays (measured, tools/xs_check.py): Cin 64 and 128 once the pixel tiles fill the chip's 512 workgroup slots -- 64 -> 256 +
     // residual 0.68 -> 0.55 ms (5.1 TB/s), 128 -> 512 + residual 0.43 -> 0.34 ms.  At Cin 256 the 128 fragment registers leave 64-wide N
-    // steps and the two forms tie (0.27 | 0.26 ms on 256 -> 1024 + residual): those layers stay with the tiled kernel unless tune 13 asks.
-    if (d->tune != 13 && (M < 128 * 512 || d->Cin > 128)) return A3D_ERR_UNSUPPORTED;
+    // steps and the two forms tie on the layers without a residual (256 -> 256 at 120x160: 0.83 | 0.83 ms): those stay with the tiled kernel
+    // unless tune 13 asks.
+    // (Cin 256 with a residual and Cout >= 512 -- res4's expansions -- 0.256 -> 0.222 ms once the maxima moved behind the last store.)
+    if (d->tune != 13 && (M < 128 * 512 || (d->Cin > 128 && !(d->res && d->Cout >= 512)))) return A3D_ERR_UNSUPPORTED;
     switch (d->Cin) {
     case 64: return launch_xs<4, 4, 1>(d, s);
     case 128: return launch_xs<8, 2, 2>(d, s);
