@@ -27,8 +27,11 @@ from ..poolers import ROIPooler
 from .axis_head import build_axis_head
 from .plane_head import build_plane_head
 
-# heads run as concurrent branches when the batch holds at most this many ROI rows in total (schedule only: same bits)
-HEADS_CONCURRENT_ROWS = int(os.environ.get("A3D_HEADS_CONCURRENT_ROWS", "1024"))
+# heads run as concurrent branches on small batches (streams.SMALL_BATCH frames) and, beyond those, when the batch holds at most this
+# many ROI rows in total (schedule only: same bits).  Default 0 since round 3: with the Winograd GEMMs' DMA ring a 64-frame clip at
+# threshold 0.5 (276 rows) runs 44.36 ms per step with the heads one after the other and 44.43 ms with them side by side, and one after
+# the other the plane and axis heads share one Winograd input transform.
+HEADS_CONCURRENT_ROWS = int(os.environ.get("A3D_HEADS_CONCURRENT_ROWS", "0"))
 
 
 class BatchedDetections:

@@ -363,10 +363,11 @@ def main():
         d[2] += 1
         d[3] += executed
         stream_sec[st] = stream_sec.get(st, 0.0) + sec
-    # The dominant kernel is chosen among the launches of the MAIN stream (the one that carries most of the kernel time: backbone, FPN,
-    # RPN, box head).  The depth decoder and the small-batch ROI heads run on side streams beside it: an event pair there brackets a kernel
-    # that SHARES the chip, and the sum over such launches counts the same wall time several times (the 22 launches of the ROI heads'
-    # Winograd GEMM read 10.7 ms per step that way against 3.3 ms alone, profiles/r03_kernel_summary_alone.md).
+    # The dominant kernel = the largest sum of launch durations over ALL its launches in the timed region (what a rocprofv3 --stats of this
+    # command ranks first, and its average duration is the figure that summary shows).  The depth decoder and the small-batch ROI heads
+    # run on side streams beside the trunk: an event pair there brackets a kernel that SHARES the chip, so such launches read long
+    # (the ROI heads' 16 Winograd GEMMs: 0.12 ms each alone, ~0.4 ms here).  `main_stream` repeats the figures over the launches of the
+    # trunk's stream only -- the same kernel with the chip (mostly) to itself.
     main_stream = max(stream_sec.items(), key=lambda kv: kv[1])[0]
     for name, flops, e0, e1, _shape, executed, pipe, st in timing:
         if st == main_stream:
@@ -375,7 +376,7 @@ def main():
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
             d[3] += executed
-    dom = max(per_main.items(), key=lambda kv: kv[1][1])
+    dom = max(per.items(), key=lambda kv: kv[1][1])
     dname, (dflops, dsec, dn, dexec, dpipe) = dom
     conv_sec = sum(v[1] for v in per.values())
     peak = PIPE_PEAK.get(dpipe, FP32_MFMA_PEAK_TFLOPS)
@@ -390,10 +391,14 @@ def main():
         "fp32_equivalent_tflops": round(dexec / dsec / 1e12, 2),
         "fp32_equivalent_vs_fp32_mfma_peak": round(dexec / dsec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),  # (what the fp32-input MFMA could do at best)
         "algorithmic_tflops": round(dflops / dsec / 1e12, 2), "algorithmic_speedup": round(dflops / dexec, 4) if dexec else None,
-        "chosen_among": "launches on the main stream (side-stream launches share the chip: see all_conv_kernels for every kernel)",
         "launches": dn, "avg_launch_ms": round(1e3 * dsec / dn, 4), "avg_launch_gflop_executed_fp32_equivalent": round(dexec / dn / 1e9, 3),
         "avg_launch_gflop_algorithmic": round(dflops / dn / 1e9, 3), "share_of_step_time": round(dsec / elapsed, 3),
     }
+    if dname in per_main and per_main[dname][1] > 0:
+        mf, ms_, mn, mx, _ = per_main[dname]
+        roofline["main_stream"] = {"launches": mn, "avg_launch_ms": round(1e3 * ms_ / mn, 4), "achieved": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12, 2),
+                                   "frac": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12 / peak, 4),
+                                   "note": "the same kernel over its launches on the trunk's stream only (side-stream launches share the chip and read long)"}
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (3, 2)) if os.path.exists(q)), "")
     if tpath:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
@@ -404,10 +409,9 @@ def main():
             roofline["traffic"] = k["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "committed " + os.path.relpath(tpath, ROOT) + ": separate rocprofv3 --pmc passes of this command, NOT measured in this run"
     if getattr(model, "small_batch_overlap", 0) >= B:
-        roofline["overlap_note"] = ("the depth decoder runs on a second HIP stream beside the ROI branch (A3D_DEPTH_OVERLAP) and the ROI heads run as "
-                                    "concurrent branches while the batch holds <= 1024 ROI rows (A3D_HEADS_CONCURRENT_ROWS): launch durations of those "
-                                    "branches are those of kernels SHARING the chip, so per-kernel rates here are lower bounds; kernels alone: "
-                                    "A3D_DEPTH_OVERLAP=0 A3D_HEADS_CONCURRENT_ROWS=0, profiles/r02_kernel_summary_alone.md")
+        roofline["overlap_note"] = ("the depth decoder runs on a second HIP stream beside the ROI branch (A3D_DEPTH_OVERLAP; +1.3 % frames/s): launch durations "
+                                    "of kernels that run while it does are those of kernels SHARING the chip, so per-kernel rates here are lower bounds; "
+                                    "kernels alone: A3D_DEPTH_OVERLAP=0, profiles/r03_kernel_summary_alone.md")
     roofline["all_conv_kernels"] = {k: {"pipe": v[4], "fp32_equivalent_tflops": round(v[3] / v[1] / 1e12, 2) if v[3] else 0.0,
                                         "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None,
                                         "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
