@@ -632,45 +632,68 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             shared[2] = int(d.precision)
         else:
             shared.append(int(d.precision))
-        if CONV_TIMING is None:
-            if not have_v:
-                _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
-            _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
-            return out
-    if CONV_TIMING is not None:
-        k_real = 147 if p.stem else p.KH * p.KW * p.Cin
-        shape = f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"
-        ev = lambda: torch.cuda.Event(enable_timing=True)
-        tiles = B * ((Ho + 1) // 2) * ((Wo + 1) // 2)
-        if fused_wino:
-            e0, e1 = ev(), ev()
-            e0.record()
-            _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
-            e1.record()
-            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin, "f32", _stream()))
-            return out
-        if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
-            e0, e1, e2 = ev(), ev(), ev()
-            e0.record()
-            if shared is None or not have_v:
-                _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
-            e1.record()
-            _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
-            e2.record()
-            CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none", _stream()))
-            CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin,
-                                {2: "bf16x6", 3: "f16x3"}.get(int(d.precision), "f32"), _stream()))
-            return out
+    # CONV_TIMING_ONLY (a set of variant labels): event pairs only around the launches whose label -- remembered from the last fully
+    # instrumented pass over the same layer and shape -- is in the set; every other launch goes out as if nothing were measured
+    # (700 event pairs per 64-frame step cost 0.8 ms of its 44).
+    timing = CONV_TIMING is not None
+    tkey = None
+    if timing:
+        tkey = (id(p), B, H, W, bool(ups), int(splitk), int(d.precision), int(d.tune), res is not None, x2 is not None, shared is not None)
+        if CONV_TIMING_ONLY is not None:
+            known = _TIMED_VARIANTS.get(tkey)
+            timing = known is None or bool(known & CONV_TIMING_ONLY)
+    if shared is not None and not timing:
+        if not have_v:
+            _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+        _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
+        return out
+    if timing:
+        n_before = len(CONV_TIMING)
+        try:
+            return _conv2d_timed(d, p, out, shared, have_v if shared is not None else False, use_wino, fused_wino, B, H, W, Ho, Wo, Cin, Cin2, ups, splitk)
+        finally:
+            _TIMED_VARIANTS[tkey] = frozenset(t[0] for t in CONV_TIMING[n_before:])
+    _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    return out
+
+
+CONV_TIMING_ONLY: Optional[frozenset] = None
+_TIMED_VARIANTS: dict = {}
+
+
+def _conv2d_timed(d, p, out, shared, have_v, use_wino, fused_wino, B, H, W, Ho, Wo, Cin, Cin2, ups, splitk):
+    """The launch of _conv2d_launch with HIP events around each kernel (CONV_TIMING)."""
+    k_real = 147 if p.stem else p.KH * p.KW * p.Cin
+    shape = f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride}{' ups' if ups else ''}{' sk%d' % splitk if splitk > 1 else ''}"
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    tiles = B * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+    if fused_wino:
         e0, e1 = ev(), ev()
         e0.record()
         _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
         e1.record()
-        # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
-        executed = 2.0 * B * Ho * Wo * p.cols * (4 * p.Cin if p.phase == 5 else k_real)  # (fused phases: 4 of the 9 taps per column)
-        fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
-        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)], _stream()))
+        CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e0, e1, shape, 2.0 * tiles * 16 * p.cols * p.Cin, "f32", _stream()))
         return out
+    if use_wino:  # the two launches of the Winograd form are timed separately (they are separate kernels)
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        if shared is None or not have_v:
+            _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+        e1.record()
+        _lib.check(_lib.lib().a3d_wino_gemm(C.byref(d), _stream()), "a3d_wino_gemm")
+        e2.record()
+        CONV_TIMING.append(("wino_input_kernel", 0.0, e0, e1, shape, 0.0, "none", _stream()))
+        CONV_TIMING.append((last_conv_variant(), 2.0 * B * Ho * Wo * p.cols * k_real, e1, e2, shape, 2.0 * tiles * 16 * p.cols * p.Cin,
+                            {2: "bf16x6", 3: "f16x3"}.get(int(d.precision), "f32"), _stream()))
+        return out
+    e0, e1 = ev(), ev()
+    e0.record()
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    e1.record()
+    # algorithmic FLOPs of a phase launch = its share (1/4) of the 3x3 conv over the upsampled tensor
+    executed = 2.0 * B * Ho * Wo * p.cols * (4 * p.Cin if p.phase == 5 else k_real)  # (fused phases: 4 of the 9 taps per column)
+    fl = 2.0 * B * Ho * Wo * p.cols * (9 * p.Cin) if p.phase else executed
+    CONV_TIMING.append((last_conv_variant(), fl, e0, e1, shape, executed, {0: "f32", 1: "bf16", 2: "bf16x6", 3: "f16x3"}[int(d.precision)], _stream()))
     return out
 
 

@@ -280,14 +280,29 @@ def main():
         step()
     drain()
     barrier()
-    ops.CONV_TIMING = []  # HIP events around every conv-GEMM launch, on the launch stream
+    # One fully instrumented step OUTSIDE the timed region (HIP events around every conv-GEMM launch, on the launch stream): the
+    # per-kernel table (`all_conv_kernels`) and the ranking that names the dominant kernel.  Inside the timed region only the
+    # dominant kernel's launches carry events -- ~700 event pairs per step cost 0.8 ms of its 44, and the headline does not pay
+    # for the table.
+    ops.CONV_TIMING = []
+    step()
+    drain()
+    barrier()
+    survey, ops.CONV_TIMING = ops.CONV_TIMING, None
+    tot = {}
+    for t in survey:
+        tot[t[0]] = tot.get(t[0], 0.0) + t[2].elapsed_time(t[3])
+    dominant = max(tot.items(), key=lambda kv: kv[1])[0]
+    ops.CONV_TIMING_ONLY = frozenset({dominant})
+    ops.CONV_TIMING = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    timing, ops.CONV_TIMING = ops.CONV_TIMING, None
+    timing, ops.CONV_TIMING, ops.CONV_TIMING_ONLY = ops.CONV_TIMING, None, None
+    timing = [t for t in timing if t[0] == dominant]  # (a launch seen for the first time is instrumented whatever its label)
     elapsed = max_over_ranks(elapsed)
     total_frames = B * world * args.steps
     fps = total_frames / elapsed
@@ -362,12 +377,13 @@ def main():
         d[1] += sec
         d[2] += 1
         d[3] += executed
-        stream_sec[st] = stream_sec.get(st, 0.0) + sec
     # The dominant kernel = the largest sum of launch durations over ALL its launches in the timed region (what a rocprofv3 --stats of this
     # command ranks first, and its average duration is the figure that summary shows).  The depth decoder and the small-batch ROI heads
     # run on side streams beside the trunk: an event pair there brackets a kernel that SHARES the chip, so such launches read long
     # (the ROI heads' 16 Winograd GEMMs: 0.12 ms each alone, ~0.4 ms here).  `main_stream` repeats the figures over the launches of the
     # trunk's stream only -- the same kernel with the chip (mostly) to itself.
+    for t in survey:  # (the trunk's stream = the one that carries most of the conv time of a whole step)
+        stream_sec[t[7]] = stream_sec.get(t[7], 0.0) + t[2].elapsed_time(t[3])
     main_stream = max(stream_sec.items(), key=lambda kv: kv[1])[0]
     for name, flops, e0, e1, _shape, executed, pipe, st in timing:
         if st == main_stream:
@@ -412,12 +428,22 @@ def main():
         roofline["overlap_note"] = ("the depth decoder runs on a second HIP stream beside the ROI branch (A3D_DEPTH_OVERLAP; +1.3 % frames/s): launch durations "
                                     "of kernels that run while it does are those of kernels SHARING the chip, so per-kernel rates here are lower bounds; "
                                     "kernels alone: A3D_DEPTH_OVERLAP=0, profiles/r03_kernel_summary_alone.md")
+    per_all = {}
+    for name, flops, e0, e1, _shape, executed, pipe, st in survey:
+        d = per_all.setdefault(name, [0.0, 0.0, 0, 0.0, pipe])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+        d[3] += executed
     roofline["all_conv_kernels"] = {k: {"pipe": v[4], "fp32_equivalent_tflops": round(v[3] / v[1] / 1e12, 2) if v[3] else 0.0,
                                         "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None,
-                                        "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
-                                        "launches_per_step": v[2] // args.steps} for k, v in sorted(per.items())}
-    roofline["conv_kernels_share_of_step_time"] = round(conv_sec / elapsed, 3)
-    roofline["whole_step_fp32_equivalent_tflops"] = round(sum(v[3] for v in per.values()) / elapsed / 1e12, 2)
+                                        "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1], 3),
+                                        "launches_per_step": v[2]} for k, v in sorted(per_all.items())}
+    roofline["all_conv_kernels_source"] = "ONE fully instrumented step run before the timed region (the timed region instruments the dominant kernel only)"
+    conv_sec = sum(v[1] for v in per_all.values())
+    step_sec = elapsed / args.steps
+    roofline["conv_kernels_share_of_step_time"] = round(conv_sec / step_sec, 3)
+    roofline["whole_step_fp32_equivalent_tflops"] = round(sum(v[3] for v in per_all.values()) / step_sec / 1e12, 2)
 
     result = {
         "metric": "frames/sec through PlaneRCNN detector at 480x640",
