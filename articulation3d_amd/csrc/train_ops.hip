@@ -155,12 +155,21 @@ __global__ void colsum_partial_kernel(const float *__restrict__ dy, float *__res
     __syncthreads();
     if (sub == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void colsum_final_kernel(const float *__restrict__ ws, float *__restrict__ out, int C, int slices, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// (64 channels per workgroup, the slices dealt over 4 row phases and combined in a fixed order: up to 256 slices one after the
+// other per thread took longer than the first stage)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ ws, float *__restrict__ out, int C, int slices, int accumulate) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += ws[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int k = sub; k < slices; k += 4) s += ws[(size_t)k * C + c];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < C) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // (C % 4 == 0: a lane owns 4 channels and keeps four independent 16-byte loads in flight -- the scalar form above ran the wide layers'
@@ -207,7 +216,7 @@ extern "C" int a3d_colsum(const float *dy, float *out, float *workspace, int M, 
         hipLaunchKernelGGL(colsum_partial4_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, out, C, slices, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, workspace, out, C, slices, accumulate);
     return a3d_check_launch();
 }
 
