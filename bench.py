@@ -61,9 +61,11 @@ def rocprof_name(variant: str) -> str:
     if m:
         h2 = "true" if m.group(1) == "h2" else "false"  # (F16, and WDMA: module-cached filters arrive pre-split by LDS-DMA)
         return f"conv_x3_kernel<{m.group(2)}, {'true' if m.group(3) else 'false'}, {h2}, {h2}>"
-    m = re.match(r"conv_(x3|h2)w_kernel$", v)
-    if m:
-        return f"conv_x3w_kernel<{'true' if m.group(1) == 'h2' else 'false'}>"
+    m = re.match(r"conv_(x3|h2)w_kernel( ph4)?$", v)
+    if m:  # (<F16, fused four-phase form>)
+        return f"conv_x3w_kernel<{'true' if m.group(1) == 'h2' else 'false'}, {'true' if m.group(2) else 'false'}>"
+    if v == "wino_input_kernel":  # (the fp16x2 arithmetic's transform writes V pre-split: its own kernel)
+        return "wino_input_h2_kernel"
     m = re.match(r"conv_h2xs_kernel<(\d+)>$", v)  # (activation-stationary pointwise kernel: <Cin / 16, N groups, chunks per ring stage>)
     if m:
         return {"64": "conv_xs_kernel<4, 4, 1>", "128": "conv_xs_kernel<8, 2, 2>", "256": "conv_xs_kernel<16, 2, 2>"}[m.group(1)]
@@ -439,6 +441,18 @@ def main():
                                         "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None,
                                         "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1], 3),
                                         "launches_per_step": v[2]} for k, v in sorted(per_all.items())}
+    if tpath:  # HBM side of every kernel the committed counter passes saw: bytes per launch (FETCH + WRITE) over this run's average duration
+        for k, v in roofline["all_conv_kernels"].items():
+            rn = rocprof_name(k).replace(" ", "")
+            tk = next((w for n, w in tr.get("kernels", {}).items() if n.replace(" ", "") == rn), None)
+            if tk is None and k == "wino_input_kernel":
+                tk = tr.get("kernels", {}).get("wino_input_kernel")
+            # (only where the label and the kernel correspond one to one: a kernel that several labels share -- the wide direct kernel
+            # under "conv_h2w_kernel" and "... sk32" -- has ONE average in the counter summary, over launches of very different sizes)
+            if tk and v["launches_per_step"] and abs(tk.get("launches_per_step", 0) - v["launches_per_step"]) < 0.5:
+                v["hbm_bytes_per_launch"] = tk["hbm_bytes_per_launch"]
+                v["hbm_tb_per_s"] = round(tk["hbm_bytes_per_launch"] * v["launches_per_step"] / (v["ms_per_step"] * 1e-3) / 1e12, 2)
+                v["hbm_frac_of_8tb_s"] = round(v["hbm_tb_per_s"] / 8.0, 3)
     roofline["all_conv_kernels_source"] = "ONE fully instrumented step run before the timed region (the timed region instruments the dominant kernel only)"
     conv_sec = sum(v[1] for v in per_all.values())
     step_sec = elapsed / args.steps
