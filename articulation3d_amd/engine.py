@@ -56,7 +56,7 @@ class FlatSGD:
         self.trainer.momentum.copy_(sd["momentum"])
 
 
-def build_optimizer(cfg, model, precision: str = "fp32") -> FlatSGD:
+def build_optimizer(cfg, model, precision: str = "bf16x3") -> FlatSGD:
     """detectron2.solver.build_optimizer(cfg, model) for this package's model: SGD momentum / weight decay / warm-up multi-step
     schedule from cfg.SOLVER, bound to the model's trainer.  precision "bf16" = the reference's autocast arithmetic."""
     return FlatSGD(model.trainer(solver_from_cfg(cfg), precision=precision))

@@ -175,7 +175,7 @@ class PlaneRCNN(nn.Module):
         return self.training_forward(batched_inputs)
 
     # ------------------------------------------------------------------ training branch (planercnn.py:83-123)
-    def trainer(self, solver=None, precision: str = "fp32"):
+    def trainer(self, solver=None, precision: str = "bf16x3"):
         """The hand-written training step behind the reference's training-mode call: created on first use (it copies every
         trainable parameter into its flat buffer).  `articulation3d_amd.engine.build_optimizer` returns the optimiser bound to it."""
         if getattr(self, "_trainer", None) is None:

@@ -19,7 +19,7 @@ Design (MI355X-first, no autograd engine):
     RNG: a3d_sample_labels / a3d_sample_rois), all per-image counts stay in device vectors and tensors have fixed shapes
     (dead slots are zero rows without loss or gradient): the step never waits for the host.  Parity tests read the drawn
     index sets back and hand them to the oracle.
-Precision: fp32 by default; `precision="bf16"` is the reference config's autocast arithmetic (bf16 MFMA, fp32 accumulation,
+Precision: fp32-grade ("bf16x3") by default; `precision="fp32"` is the fp32-input MFMA; `precision="bf16"` is the reference config's autocast arithmetic (bf16 MFMA, fp32 accumulation,
 fp32 master weights) on every trainable layer, with the ResNet stages' activations and gradients STORED as bf16 (round 3:
 a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16; `storage="fp32"` keeps them fp32) and a bf16 gradient all-reduce payload.
 """
@@ -133,11 +133,13 @@ class DetectorTrainer:
     `model` is the product PlaneRCNN (its frozen stem / res2 modules are used as they are; everything trainable is
     copied into the flat buffer at construction and written back by `export_state_dict`)."""
 
-    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "fp32",
+    def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "bf16x3",
                  grad_payload: Optional[str] = None, storage: Optional[str] = None):
-        """precision: "fp32" (fp32 MFMA everywhere) or "bf16" -- the reference's autocast setting: every trainable conv / linear
-        multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation (forward, data and weight gradients); master
-        weights, activations, gradients, losses and the optimiser stay fp32."""
+        """precision: "bf16x3" (the default since round 3: fp32-GRADE products from exact 3-way bf16 operand splits, six bf16 MFMAs per
+        fp32 multiply-add -- no block exponents, so filters that change every step need no maxima; 140 | 319 images/s at 2 | 16
+        images per GPU against 123 | 270 of the fp32-input MFMA), "fp32" (fp32-input MFMA everywhere) or "bf16" -- the reference's
+        autocast setting: every trainable conv / linear multiplies bf16-rounded operands on the bf16 MFMA with fp32 accumulation
+        (forward, data and weight gradients); master weights, losses and the optimiser stay fp32."""
         assert precision in ("fp32", "bf16", "bf16x3")
         # "bf16x3": fp32-grade arithmetic on the bf16 pipe for every forward / data-gradient launch -- csrc/conv_bf16x3.hip for the
         # direct layers, the split-operand Winograd GEMM (csrc/conv_wino.hip 2x) for the 3x3 ones, whose filters are split once per

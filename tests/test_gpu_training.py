@@ -511,7 +511,7 @@ def test_bf16_training_step_tracks_fp32(hip_model, oracle):
     frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
     tg = TO.synthetic_targets(2)
     gb, gc = [t[0] for t in tg], [t[1] for t in tg]
-    t32 = DetectorTrainer(hip_model, seed=5)
+    t32 = DetectorTrainer(hip_model, seed=5, precision="fp32")
     l32, aux = t32.forward_backward(frames, gb, gc)
     rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
     samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=[ri[i, : int(rc[i])].long() for i in range(2)])
@@ -551,7 +551,7 @@ def test_bf16x3_training_step_matches_fp32(hip_model, oracle):
     frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
     tg = TO.synthetic_targets(2)
     gb, gc = [t[0] for t in tg], [t[1] for t in tg]
-    t32 = DetectorTrainer(hip_model, seed=5)
+    t32 = DetectorTrainer(hip_model, seed=5, precision="fp32")
     l32, aux = t32.forward_backward(frames, gb, gc)
     rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
     samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=[ri[i, : int(rc[i])].long() for i in range(2)])

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (reference: IMS_PER_BATCH 16 over 8 GPUs)")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"], help="res3-res5 activations / gradients in HBM (default: bf16 in the bf16 step)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 = autocast arithmetic (bf16 MFMA, fp32 accumulate); bf16x3 = fp32-grade 3-way bf16 split on the non-Winograd layers")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE oracle step (autograd on the host cores)")
     args = ap.parse_args()
