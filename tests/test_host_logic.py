@@ -290,3 +290,33 @@ def test_torch_ops_are_registered_without_a_cpu_kernel():
     with pytest.raises((NotImplementedError, RuntimeError)) as e:
         torch.ops.a3d.group_nms(torch.zeros(1, 1024, 4), torch.zeros(1, 1024, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), 0.5)
     assert "CPU" in str(e.value)
+
+
+def test_bench_labels_map_onto_the_kernels_of_the_committed_profile():
+    """The bench line names kernels by the dispatcher's labels; the rocprofv3 summary of the same command names template
+    instantiations.  bench.rocprof_name is the bridge the roofline object's `traffic` and the per-kernel HBM figures go over: every
+    conv label of the committed round-3 bench line must land on a kernel of the committed kernel trace, and the dominant kernel's
+    average launch duration must agree between the two (the contract of profiles/)."""
+    import csv
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv"))))
+    squeeze = lambda s: re.sub(r"\s+", "", s)
+    names = [squeeze(r["Name"]) for r in rows]
+    for label in line["roofline"]["all_conv_kernels"]:
+        if label.endswith("wino_fold_kernel"):
+            label = label.split(" planes")[0]
+        want = squeeze(bench.rocprof_name(label))
+        assert any(want in n for n in names), (label, want)
+    roof = line["roofline"]
+    want = squeeze(bench.rocprof_name(roof["kernel"]))
+    avg_us = next(float(r["AverageNs"]) / 1e3 for r, n in zip(rows, names) if want in n)
+    # (the stats file averages over the WHOLE process -- warm-up and calibration launches included --, the bench line over the timed
+    # region: they agree to the spread of launch sizes, not to the digit)
+    assert 0.7 < avg_us / (roof["avg_launch_ms"] * 1e3) < 1.3, (avg_us, roof["avg_launch_ms"])
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
