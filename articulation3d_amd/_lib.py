@@ -41,6 +41,8 @@ class ConvDesc(C.Structure):
         ("w_scale", C.c_float),
         ("wino_m", fptr),
         ("io_bf16", C.c_int),
+        ("x_h2", fptr),
+        ("x2_h2", fptr),
     ]
 
 
@@ -85,6 +87,7 @@ class RoiAlignDesc(C.Structure):
         ("P", C.c_int), ("sampling_ratio", C.c_int), ("aligned", C.c_int),
         ("out", fptr), ("out_level", fptr), ("order_ws", fptr),
         ("out_amax", fptr), ("level_amax", fptr * 4), ("window_count", fptr),
+        ("out_h2", fptr),
     ]
 
 
@@ -195,6 +198,7 @@ SIGNATURES = {
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),
     "a3d_absmax_rows": (C.c_int, [fptr, fptr, C.c_int, C.c_size_t, fptr]),
+    "a3d_presplit_f16x2": (C.c_int, [fptr, fptr, fptr, fptr, C.c_int, C.c_size_t, fptr]),
     "a3d_mask_rle": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr]),
     "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),

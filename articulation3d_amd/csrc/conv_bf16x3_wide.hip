@@ -73,6 +73,8 @@ constexpr unsigned xw_tap_phases(const int tap) {
 }
 constexpr int XW_PX = XW_BM * XW_BK, XW_PW = XW_BN * XW_BK;  // one operand plane of one stage (bf16 elements; 32-byte rows)
 constexpr int xw_lds_bytes(int NP) { return (2 * NP * XW_PX + 3 * NP * XW_PW) * 2 + 2 * XW_BN * 4; }
+constexpr int XD_NST = 4;  // XD: stages of the dual-DMA ring (each holds one chunk of BOTH operands)
+constexpr int xd_lds_bytes() { return XD_NST * (2 * XW_PX + 2 * XW_PW) * 2 + 2 * XW_BN * 4; }
 
 // F16: the fp16x2 arithmetic (a3d_conv_desc.precision == 3) -- two operand planes, three product terms (h.h, h.l, l.h), activation rows
 // scaled per image from d.in_amax, w_x3 = the filter pre-split by a3d_split_f16x2_chunk with d.w_scale.
@@ -84,9 +86,18 @@ constexpr int xw_lds_bytes(int NP) { return (2 * NP * XW_PX + 3 * NP * XW_PW) * 
 // block's MFMAs (uniform branch): corner taps multiply one block, edge taps two, the centre all four -- exactly the 16 tap-phase
 // products of the four-launch form, in the same order per output (bit-identical results), but every activation chunk is loaded and
 // split ONCE for the phases that share it (9 tap loads instead of 16) and all waves do equal work on every tap.
-template <bool F16, bool PH4 = false>
+// XD (fp16x2 only; a3d_conv_desc.x_h2): the ACTIVATIONS arrive pre-split as well -- [pixel][C/16][h | l][16] fp16, written by their producer
+// (a3d_roi_align_fpn's out_h2, a3d_presplit_f16x2) with the bits this kernel's loader would compute -- and take the filter's road:
+// global -> LDS by LDS-DMA, the image's half swizzle applied on the global side of each lane's address, zero padding by the buffer
+// range check.  No activation registers, no split arithmetic, no VGPR -> LDS stores: a chunk is 2 + 2 DMA instructions per wave beside
+// 24 MFMAs.  Ring of XD_NST = 4 stages (32 KiB each): chunk c lives in stage c % 4; ONE bare s_barrier per chunk, behind the last
+// fragment read of the chunk (a(c)[3], issued under block 2's MFMAs), after which the DMA of chunk c + 4 goes straight into the
+// stage of chunk c and has three iterations to land (fc1 streams its 3.2 GB of activations from HBM).  Same fragments, same term
+// order per output as the register-staged loop: bit-identical results (tests/test_gpu_parity.py).
+template <bool F16, bool PH4 = false, bool XD = false>
 __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
     static_assert(!PH4 || F16, "the fused four-phase form belongs to the fp16x2 arithmetic");
+    static_assert(!XD || F16, "pre-split activations belong to the fp16x2 arithmetic");
     constexpr int NP = F16 ? 2 : 3;
     constexpr int XW_XST = NP * XW_PX, XW_WST = NP * XW_PW;  // one stage
     constexpr int TM = 2, TN = 4, BM = XW_BM, BN = XW_BN, BKT = XW_BK, LKB = XW_BK;
@@ -94,9 +105,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     constexpr int PX = XW_PX, PW = XW_PW;
     static_assert(XR == 2, "the counted vmcnt waits below assume two activation loads per chunk");
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16 *const Xs = lds;                  // [2][3][256][16]
-    __bf16 *const Ws = lds + 2 * XW_XST;     // [3][3][256][16]
-    float *const ss = reinterpret_cast<float *>(lds + 2 * XW_XST + 3 * XW_WST);
+    constexpr int NXS = XD ? XD_NST : 2, NWS = XD ? XD_NST : 3;  // X / W stages
+    __bf16 *const Xs = lds;                    // [NXS][NP][256][16]
+    __bf16 *const Ws = lds + NXS * XW_XST;     // [NWS][NP][256][16]
+    float *const ss = reinterpret_cast<float *>(lds + NXS * XW_XST + NWS * XW_WST);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,8 +128,11 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     const int lcs = (lc & 7) | ((((lc >> 3) ^ (lr >> 3)) & 1) << 3);
     const int cs4 = d.Cin * 4;
     const int CinT = d.Cin + d.Cin2;
-    const __amdgpu_buffer_rsrc_t rx = wx_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
-    const __amdgpu_buffer_rsrc_t rx2 = wx_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    // (XD: the pre-split tensors hold the same number of bytes per pixel as the fp32 ones: Cin / 16 chunks x 64 B)
+    const void *const x0p = XD ? d.x_h2 : (const void *)d.x;
+    const void *const x1p = XD ? (d.x2_h2 ? d.x2_h2 : d.x_h2) : (const void *)(d.x2 ? d.x2 : d.x);
+    const __amdgpu_buffer_rsrc_t rx = wx_rsrc(x0p, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
+    const __amdgpu_buffer_rsrc_t rx2 = wx_rsrc(x1p, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const unsigned w3chunk = (unsigned)d.Cout * 32u * NP;  // bytes of one chunk of w_x3: NP planes x Cout rows x 32 B
     const __amdgpu_buffer_rsrc_t rw = wx_rsrc(d.w_x3, (unsigned)((size_t)nk_all * w3chunk));
 
@@ -203,7 +218,56 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
             wx_dma16(rw, Wt + p * PW + g * 32 * LKB, wvoff, base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + g * 1024));
         }
         ++dma_c;
-        dma_st = dma_st == 2 ? 0 : dma_st + 1;
+        dma_st = dma_st == NWS - 1 ? 0 : dma_st + 1;
+    };
+    // XD: the activation chunk by DMA.  One (chunk, plane) tile of the workgroup's 256 rows = 8 instructions of 32 rows; wave w issues
+    // instructions j = 2 w, 2 w + 1 (plane j / 8, row group j % 8): lane i -> row i / 2, LDS half i % 2, fetching the k half the image
+    // keeps there.  Its two rows' pixel offsets and tap masks are per-lane constants; the chunk's tap / channel offset is uniform.
+    int xd_off[2];
+    unsigned xd_mask[2];
+    if constexpr (XD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = (wave * 2 + i) & 7;
+            const int m = m0 + g * 32 + (lane >> 1);
+            const bool rok = m < M;
+            const int mm = rok ? m : 0;
+            const int hw = d.Ho * d.Wo;
+            const int b = mm / hw, r = mm - b * hw;
+            const int oh = r / d.Wo, ow = r - oh * d.Wo;
+            const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+            unsigned mask = 0;
+            for (int kh = 0; kh < d.KH; ++kh)
+                for (int kw = 0; kw < d.KW; ++kw)
+                    mask |= (rok && (unsigned)(ih0 + kh) < (unsigned)d.H && (unsigned)(iw0 + kw) < (unsigned)d.W) ? (1u << (kh * d.KW + kw)) : 0u;
+            xd_off[i] = ((b * d.H + ih0) * d.W + iw0) * cs4 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+            xd_mask[i] = mask;
+        }
+    }
+    int xd_st = 0;
+    auto dma_x = [&]() {  // next activation chunk (position kc / c0 / kh / kw, shared with load_chunk) into X stage xd_st
+        const int tap = kh * d.KW + kw;
+        const unsigned livebit = (kc < nk) ? 1u : 0u;
+        const bool second = c0 >= d.Cin;
+        const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
+        const int tapoff = __builtin_amdgcn_readfirstlane((kh * d.W + kw) * cs4 + (second ? c0 - d.Cin : c0) * 4);
+        const int p = wave >> 2;  // plane of this wave's two instructions
+        __bf16 *Xt = Xs + xd_st * XW_XST + p * PX;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = (wave * 2 + i) & 7;
+            wx_dma16(r, Xt + g * 32 * LKB, ((xd_mask[i] >> (tap & 31)) & livebit) ? xd_off[i] + tapoff : -1, p * 32);
+        }
+        ++kc;
+        c0 += BKT;
+        if (c0 >= CinT) {
+            c0 = 0;
+            if (++kw == d.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+        xd_st = xd_st == XD_NST - 1 ? 0 : xd_st + 1;
     };
 
     f32x16 acc[TN][TM];
@@ -263,6 +327,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     int wst = 0;  // W stage of the chunk being multiplied
     // PH4: the tap of the chunk being multiplied and the phases (= channel blocks) whose 2x2 window holds it
     const int cpt = PH4 ? CinT / BKT : 1;  // chunks per tap
+    // (Measured and not taken, round 4: the filter DMA pieces of the phases a tap does not multiply -- 7.1 of 16 pieces per chunk on
+    // average -- left out: 2.70 | 2.82 ms on the 120x160 stage, 1.43 | 1.40 on 60x80: the filter stream is not what bounds this loop.)
     // one iteration; xst = X stage of chunk c (compile-time), Bc / Bn = the b sets of chunk c / c+1, xs = the staged chunk c+1
     auto iteration = [&](const int xst, FragA &A0, FragA &A1, FragB &Bc, FragB &Bn, f32x4 (&xs)[XR]) {
         const int wnext = wst == 2 ? 0 : wst + 1;
@@ -377,9 +443,85 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     };
 #undef PH_T
 
-    // prologue: W(0), W(1) by DMA; X(0) split into X stage 0; X(1), X(2) staged in registers; b(0), a(0)[0] read
     FragA A0, A1;
     FragB B0, B1;
+    if constexpr (XD && !PH4) {
+        // ---- dual-DMA ring.  An iteration = one 16-deep chunk = four channel blocks of six MFMAs.  Fragments: b(c) and a(c)[0] were
+        // read during the previous iteration's last block; a(c)[n + 1] is read under block n.  Behind block 2 every wave has issued its
+        // last read of stage st: own reads drained (lgkmcnt), own DMA pieces of chunk c + 1 landed (counted vmcnt: all but the two
+        // youngest chunks), bare barrier -- then the DMA of chunk c + 4 into stage st, and block 3 reads b(c + 1), a(c + 1)[0].
+        constexpr int OPS = 4;  // vector-memory instructions per wave and chunk (2 activation + 2 filter pieces)
+        static_assert(NP == 2, "two filter DMA pieces per wave");
+        int st = 0;
+#pragma unroll
+        for (int i = 0; i < XD_NST; ++i) {
+            dma_x();
+            dma_w();
+        }
+        __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_NST - 1) * OPS) : "memory");
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (scale / shift staged above)
+        __builtin_amdgcn_s_barrier();
+        rdB(B0, 0, 0);
+        rdB(B0, 0, 1);
+        rdA(A0, 0, 0);
+        XW_FENCE
+        auto iter_xd = [&](FragB &Bc, FragB &Bn) {
+            const int sn = st == XD_NST - 1 ? 0 : st + 1;
+            XW_TERM(0, A0, Bc, 0, 0)
+            rdA(A1, st, 1);
+            XW_MIX(4)
+            XW_FENCE
+            XW_TERM(0, A0, Bc, 0, 1)
+            XW_TERM(0, A0, Bc, 1, 0)
+            XW_FENCE
+            XW_TERM(1, A1, Bc, 0, 0)
+            rdA(A0, st, 2);
+            XW_MIX(4)
+            XW_FENCE
+            XW_TERM(1, A1, Bc, 0, 1)
+            XW_TERM(1, A1, Bc, 1, 0)
+            XW_FENCE
+            XW_TERM(2, A0, Bc, 0, 0)
+            rdA(A1, st, 3);
+            XW_MIX(4)
+            XW_FENCE
+            XW_TERM(2, A0, Bc, 0, 1)
+            XW_TERM(2, A0, Bc, 1, 0)
+            XW_FENCE
+            __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((XD_NST - 2) * OPS) : "memory");
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef A3D_ABLATIONS  // timing-only variants (developer builds, A3D_HIPCC_FLAGS=-DA3D_ABLATIONS): tune bit 10 no activation DMA, 11 no filter DMA, 12 no barrier
+            if (!(d.tune & 4096)) __builtin_amdgcn_s_barrier();
+            XW_TERM(3, A1, Bc, 0, 0)
+            if (!(d.tune & 1024)) dma_x();
+            if (!(d.tune & 2048)) dma_w();
+#else
+            __builtin_amdgcn_s_barrier();
+            XW_TERM(3, A1, Bc, 0, 0)
+            dma_x();
+            dma_w();
+#endif
+            XW_MIX(8)
+            XW_FENCE
+            XW_TERM(3, A1, Bc, 0, 1)
+            rdB(Bn, sn, 0);
+            rdB(Bn, sn, 1);
+            XW_MIX(4)
+            XW_FENCE
+            XW_TERM(3, A1, Bc, 1, 0)
+            rdA(A0, sn, 0);
+            XW_MIX(4)
+            XW_FENCE
+            st = sn;
+        };
+        for (int it = kbeg; it < nk; it += 2) {
+            iter_xd(B0, B1);
+            iter_xd(B1, B0);
+        }
+        // the DMAs past the last chunk land somewhere in the ring (never in scale | shift): drain them before the LDS is given back
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+    // prologue: W(0), W(1) by DMA; X(0) split into X stage 0; X(1), X(2) staged in registers; b(0), a(0)[0] read
     dma_w();
     dma_w();
     load_chunk(xsA);
@@ -417,6 +559,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
     for (int it = kbeg; it < nk; it += 2) {  // (Kpad % 32 == 0 on every packed layer; an odd chunk count would multiply one all-zero chunk: loads / DMA past nk read 0)
         iteration(0, A0, A1, B0, B1, xsB);
         iteration(1, A0, A1, B1, B0, xsA);
+    }
     }
     }
 #undef XW_REST
@@ -522,7 +665,29 @@ static int launch_ph4(const a3d_conv_desc *d, hipStream_t s) {
     return a3d_check_launch();
 }
 
+// Pre-split activations (a3d_conv_desc.x_h2): both operands by LDS-DMA.  Any plain direct layer of the fp16x2 arithmetic qualifies
+// (1x1 / linear, 3x3, strided; one or two equal-width sources); there is no other kernel that reads this format, so everything else
+// is an argument error, not "unsupported".
+static int launch_xd(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
+    if (d->stem || d->ups || d->m_dev || d->splitk != 1 || d->pixshuf || d->gate || d->phase) return A3D_ERR_ARG;
+    if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2_h2)) return A3D_ERR_ARG;
+    if ((d->Cin & 15) || d->Kpad != d->KH * d->KW * (d->Cin + d->Cin2) || d->KH * d->KW > 32) return A3D_ERR_ARG;
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    const int M = d->B * d->Ho * d->Wo;
+    const int mtiles = (M + XW_BM - 1) / XW_BM, ntiles = (d->Cout + XW_BN - 1) / XW_BN;
+    static a3d_attr_once attr_xd;
+    if (attr_xd.needed()) {
+        if (hipFuncSetAttribute((const void *)conv_x3w_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, xd_lds_bytes()) != hipSuccess) return A3D_ERR_LAUNCH;
+        attr_xd.mark();
+    }
+    a3d_note_variant("conv_h2w_kernel xd");
+    hipLaunchKernelGGL((conv_x3w_kernel<true, false, true>), dim3(mtiles * ntiles, 1), dim3(512), xd_lds_bytes(), s, *d, M, ntiles, mtiles * ntiles);
+    return a3d_check_launch();
+}
+
 int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->x_h2 && d->phase != 5) return launch_xd(d, s);
     if (d->phase == 5) return launch_ph4(d, s);
     if (!d->w_x3 || d->tune == 8) return A3D_ERR_UNSUPPORTED;
     if (d->stem || d->ups || d->m_dev || d->splitk < 1) return A3D_ERR_UNSUPPORTED;

@@ -210,13 +210,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const a3d_conv_
 }
 
 static int conv_check(const a3d_conv_desc *d) {
-    if (!d || !d->x || !d->w || !d->y) return A3D_ERR_ARG;
+    if (!d || (!d->x && !d->x_h2) || !d->w || !d->y) return A3D_ERR_ARG;
+    if (d->x_h2 && d->precision != 3) return A3D_ERR_ARG;  // pre-split activations exist in the fp16x2 arithmetic only
     if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return A3D_ERR_ARG;
     if ((d->Cout & 3) || (d->Kpad & 31) || d->splitk < 1) return A3D_ERR_ARG;
     if (d->stem) {
         if (d->KH != 7 || d->KW != 7 || d->stride != 2 || d->pad != 3 || d->Kpad != 224 || d->Cin2 || d->ups) return A3D_ERR_ARG;
     } else {
-        if ((d->Cin & 31) || (d->Cin2 & 31) || (d->Cin2 && !d->x2)) return A3D_ERR_ARG;
+        if ((d->Cin & 31) || (d->Cin2 & 31) || (d->Cin2 && !d->x2 && !d->x2_h2)) return A3D_ERR_ARG;
         if (d->Kpad < d->KH * d->KW * (d->Cin + d->Cin2)) return A3D_ERR_ARG;
     }
     if (d->pixshuf && (d->Cout & 15)) return A3D_ERR_ARG;
@@ -276,6 +277,7 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
         if ((d->tune == 0 || d->tune == 8) && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
         return a3d_conv_launch_bf16x3(d, s);
     }
+    if (d->precision == 3 && d->x_h2) return a3d_conv_launch_bf16x3_wide(d, s);  // pre-split activations: the dual-DMA forms only
     if (d->precision == 3) {  // fp16x2 split: Winograd layers (wide kernels) when their pre-split filter is given, the rest direct
         if (d->tune == 0 && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
         return a3d_conv_launch_bf16x3(d, s);

@@ -19,7 +19,7 @@
 // one-load-at-a-time walk and the batched walk now run in the same time (2.59 ms before the spatial order, 2.39 with it), and
 // giving each wave its own contiguous run of bins instead of every fourth bin was slower (2.52 ms: the four waves of a
 // workgroup no longer share their neighbouring cells in L1).
-#include "a3d_common.h"
+#include "conv_common.h"  // a3d_pow2_scale: the block exponent of the fp16x2 split (out_h2)
 #ifndef A3D_ROI_NC
 #define A3D_ROI_NC 9
 #endif
@@ -43,6 +43,7 @@ struct RoiArgs {
     float *out_amax;            // optional [rows]: max |pooled[row]| over the finite pooled values (a3d_roialign_desc.out_amax)
     const float *level_amax[4]; // optional per level [B]: maxima of the pyramid level, for the window monitor below
     int *window_count;          // optional: number of live ROIs fainter than 2^-A3D_ROI_WINDOW_LOG2 of their level's maximum
+    unsigned char *out_h2;      // H2 form: [rows][P*P*C/16][h | l][16] fp16 (a3d_roialign_desc.out_h2) instead of `out`
 };
 #define A3D_ROI_WINDOW_LOG2 16
 
@@ -97,7 +98,18 @@ __global__ __launch_bounds__(256) void roi_order_kernel(const float *boxes, cons
     for (int r = threadIdx.x; r < R; r += 256) order[(size_t)b * R + r] = idx[r];  // ranks >= count hold dead slots (skipped by the walker)
 }
 
-__global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
+// H2 (a3d_roialign_desc.out_h2; the 7x7 box pooler in the default arithmetic): the pooled row leaves the kernel ALREADY split into the
+// two scaled fp16 planes the fp16x2 GEMM multiplies, in a3d_conv_desc.x_h2's layout, so that the box head's fc1 moves both operands
+// global -> LDS by LDS-DMA.  The scale is the power of two of the ROI's OWN maximum, which is only known once every bin is pooled:
+// the workgroup keeps its P*P*C pooled floats in LDS (49 KiB at 7 x 7 x 256: three workgroups per CU), reduces the maximum,
+// and then splits and stores the row -- the same bytes as the fp32 row (2 + 2 per element), the bits fc1's loader computed from it.
+// NW waves per workgroup: 7 for the 7x7 pooler (wave w pools column w of every bin row: the waves of a workgroup stay neighbours in
+// the pyramid, and 49 bins are 7 rounds with no idle wave), 4 otherwise.
+typedef _Float16 ra_h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ra_h16x8 __attribute__((ext_vector_type(8)));
+template <int NW, bool H2>
+__global__ __launch_bounds__(64 * NW, H2 ? 3 : 1) void roi_align_fpn_kernel(const RoiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pooled_lds[];  // H2: [P*P][C]
     int slot = blockIdx.x;
     if (a.order) {  // (image, rank) in XCD-contiguous order -> the slot at that rank of the image's spatial order
         const int logical = a3d_xcd_remap(blockIdx.x, a.nblk);
@@ -133,7 +145,12 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
     const int C4 = a.C >> 2;
     float *orow = a.out + (size_t)row * a.P * a.P * a.C;
     float lmax = 0.f;  // max |pooled| over this lane's stores (finite values only), reduced per ROI at the end
-    __shared__ float wave_max[4];
+    __shared__ float wave_max[NW];
+    auto emit = [&](const int bin, const int c, const f32x4 o) {  // channels c .. c + 3 of bin `bin`
+        lmax = fmaxf(lmax, a3d_absmax4(o));
+        if constexpr (H2) *reinterpret_cast<f32x4 *>(pooled_lds + (size_t)bin * a.C + c) = o;
+        else *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c) = o;
+    };
 
     // Separable form.  The samples of a bin form a gh x gw lattice and a bilinear weight factorises into a y part and
     // an x part, so  sum_samples sum_corners w*f  ==  sum_rows sum_cols WY[row] * WX[col] * f[row][col]  with
@@ -218,9 +235,7 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                     for (int kx = 0; kx < nx; ++kx) acc += (wy * WX[pw][kx]) * *reinterpret_cast<const f32x4 *>(frow + (size_t)kx * a.C);
                 }
             }
-            const f32x4 o = acc / count;
-            lmax = fmaxf(lmax, a3d_absmax4(o));
-            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + lane * 4) = o;
+            emit(bin, lane * 4, acc / count);
         };
         if (C4 == 64 && !a.serial) {
             // A bin's (ny x nx) cells are independent 1 KiB loads.  Walking them with run-time loop bounds made hipcc issue one load,
@@ -228,9 +243,9 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
             // first is consumed; accumulation order is unchanged (ky outer, kx inner): bit-identical results.  Measured and rejected:
             // a second register set that prefetches the next bin (144 VGPRs, 3 workgroups per CU instead of 4-5: 3.1 ms vs 2.6 ms).
             f32x4 v[NC];
-            for (int bin = wave; bin < nbins; bin += 4) finish(v, bin, issue(v, bin));
+            for (int bin = wave; bin < nbins; bin += NW) finish(v, bin, issue(v, bin));
         } else
-        for (int bin = wave; bin < nbins; bin += 4) {
+        for (int bin = wave; bin < nbins; bin += NW) {
             const int ph = bin / a.P, pw = bin - ph * a.P;
             const int ry0 = Y0[ph], ny = NY[ph], rx0 = X0[pw], nx = NX[pw];
             for (int c4 = lane; c4 < C4; c4 += 64) {
@@ -243,14 +258,12 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                         acc += (wy * WX[pw][kx]) * v;
                     }
                 }
-                const f32x4 o = acc / count;
-                lmax = fmaxf(lmax, a3d_absmax4(o));
-                *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = o;
+                emit(bin, c4 * 4, acc / count);
             }
         }
     } else
     // general path (very large sampling grids): per-sample evaluation, as torchvision writes it
-    for (int bin = wave; bin < a.P * a.P; bin += 4) {
+    for (int bin = wave; bin < a.P * a.P; bin += NW) {
         const int ph = bin / a.P, pw = bin - ph * a.P;
         for (int c4 = lane; c4 < C4; c4 += 64) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -284,9 +297,7 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
                     acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
                 }
             }
-            const f32x4 o = acc / count;
-            lmax = fmaxf(lmax, a3d_absmax4(o));
-            *reinterpret_cast<f32x4 *>(orow + (size_t)bin * a.C + c4 * 4) = o;
+            emit(bin, c4 * 4, acc / count);
         }
     }
     // The ROI's own maximum (fp16x2: the power-of-two scale of every layer that consumes this row).  One workgroup owns the ROI, so
@@ -294,24 +305,44 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(const RoiArgs a) {
     // scaled a faint ROI by the hottest cell of its image.  Window monitor: the ROI's features inherit an ABSOLUTE error of
     // ~2^-40 of their LEVEL's maximum from the backbone's per-image block exponents; relative to the ROI that is 2^-40 x
     // (level max / ROI max), i.e. fp32-grade while the ratio stays below ~2^16.  ROIs past that are counted, never silently passed.
-    if (a.out_amax) {
+    if (a.out_amax || H2) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
         if (lane == 0) wave_max[wave] = lmax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        __syncthreads();  // (H2: also orders every wave's pooled bins in LDS before the split pass below)
+        float m = wave_max[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, wave_max[w]);
+        if (threadIdx.x == 0 && a.out_amax) {
             a.out_amax[row] = m;
             if (a.window_count && a.level_amax[lv]) {
                 const float lm = a.level_amax[lv][b];
                 if (m > 0.f && lm < 1.7e38f && m * (float)(1 << A3D_ROI_WINDOW_LOG2) < lm) atomicAdd(a.window_count, 1);
             }
         }
+        if constexpr (H2) {
+            // x * s = h + l, s = the scale fc1 derives from out_amax[row] (a3d_in_scale): conv_bf16x3_wide.hip's wx_split2h on 8 channels
+            // per thread = one 16-byte half of a chunk's h row and of its l row
+            const float sc = a3d_pow2_scale(m);
+            unsigned char *hrow = a.out_h2 + (size_t)row * a.P * a.P * a.C * 4;
+            const int n8 = (a.P * a.P * a.C) >> 3;
+            for (int i = threadIdx.x; i < n8; i += 64 * NW) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pooled_lds + (size_t)i * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pooled_lds + (size_t)i * 8 + 4);
+                const f32x4 x0 = v0 * sc, x1 = v1 * sc;
+                const ra_h16x4 h0 = __builtin_convertvector(x0, ra_h16x4), h1 = __builtin_convertvector(x1, ra_h16x4);
+                const ra_h16x4 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x4), ra_h16x4);
+                const ra_h16x4 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x4), ra_h16x4);
+                unsigned char *dst = hrow + (size_t)(i >> 1) * 64 + (i & 1) * 16;
+                *reinterpret_cast<ra_h16x8 *>(dst) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<ra_h16x8 *>(dst + 32) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
     }
 }
 
 extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
-    if (!d || !d->boxes || !d->out || d->L < 1 || d->L > 4 || (d->C & 3) || d->B <= 0 || d->R <= 0 || d->P <= 0)
+    if (!d || !d->boxes || (!d->out && !d->out_h2) || d->L < 1 || d->L > 4 || (d->C & 3) || d->B <= 0 || d->R <= 0 || d->P <= 0)
         return A3D_ERR_ARG;
     RoiArgs a;
     for (int l = 0; l < 4; ++l) {
@@ -337,6 +368,7 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     a.order = nullptr;
     a.nblk = d->B * d->R;
     a.out_amax = d->out_amax;
+    a.out_h2 = (unsigned char *)d->out_h2;
     a.window_count = d->window_count;
     for (int l = 0; l < 4; ++l) a.level_amax[l] = l < d->L ? d->level_amax[l] : nullptr;
     a3d_begin();
@@ -344,7 +376,27 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
         hipLaunchKernelGGL(roi_order_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, d->boxes, d->count, d->order_ws, d->R, d->L);
         a.order = d->order_ws;
     }
-    hipLaunchKernelGGL(roi_align_fpn_kernel, dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    if (d->out_h2) {  // pre-split output: the pooled row is staged in LDS (P*P*C floats), C = 256 (one float4 per lane and bin)
+        const size_t lds = (size_t)d->P * d->P * d->C * 4;
+        if (d->C != 256 || (d->C & 15) || lds > 120 * 1024) return A3D_ERR_UNSUPPORTED;
+        if (d->P == 7) {
+            static a3d_attr_once attr7;
+            if (attr7.needed()) {
+                if (hipFuncSetAttribute((const void *)roi_align_fpn_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return A3D_ERR_LAUNCH;
+                attr7.mark();
+            }
+            hipLaunchKernelGGL((roi_align_fpn_kernel<7, true>), dim3(d->B * d->R), dim3(448), lds, (hipStream_t)stream, a);
+        } else {
+            static a3d_attr_once attr4;
+            if (attr4.needed()) {
+                if (hipFuncSetAttribute((const void *)roi_align_fpn_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) return A3D_ERR_LAUNCH;
+                attr4.mark();
+            }
+            hipLaunchKernelGGL((roi_align_fpn_kernel<4, true>), dim3(d->B * d->R), dim3(256), lds, (hipStream_t)stream, a);
+        }
+        return a3d_check_launch();
+    }
+    hipLaunchKernelGGL((roi_align_fpn_kernel<4, false>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
 

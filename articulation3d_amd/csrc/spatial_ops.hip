@@ -360,3 +360,42 @@ extern "C" int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void
     hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)bx, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, (hipStream_t)stream, x, out, B, n);
     return a3d_check_launch();
 }
+
+// ---- activation pre-split for a3d_conv_desc.x_h2 (include/a3d.h) ---------------------------------------------------------------
+// x [B][n] fp32 -> dst [B][n/16][h | l][16] fp16 of x * s(b): the split the fp16x2 loaders perform on the fly (conv_bf16x3_wide.hip
+// wx_split2h), done once per tensor so that the consuming kernel takes both operands by LDS-DMA.  A thread owns 8 consecutive values
+// = one 16-byte half of a chunk's h row and of its l row (two 16-byte loads, two 16-byte stores); same bytes in and out.
+#include "conv_common.h"
+typedef _Float16 ps_h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ps_h16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void presplit_f16x2_kernel(const float *__restrict__ x, unsigned char *__restrict__ dst, const float *__restrict__ amax,
+                                                             const float *__restrict__ amax2, int B, size_t n8) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        float am = amax[b];
+        if (amax2) am = fmaxf(am, amax2[b]);
+        const float sc = a3d_pow2_scale(am);
+        const float *row = x + (size_t)b * n8 * 8;
+        unsigned char *drow = dst + (size_t)b * n8 * 32;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(row + i * 8) * sc, x1 = *reinterpret_cast<const f32x4 *>(row + i * 8 + 4) * sc;
+            const ps_h16x4 h0 = __builtin_convertvector(x0, ps_h16x4), h1 = __builtin_convertvector(x1, ps_h16x4);
+            const ps_h16x4 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x4), ps_h16x4);
+            const ps_h16x4 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x4), ps_h16x4);
+            unsigned char *d = drow + (i >> 1) * 64 + (i & 1) * 16;
+            *reinterpret_cast<ps_h16x8 *>(d) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<ps_h16x8 *>(d + 32) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+}
+
+extern "C" int a3d_presplit_f16x2(const float *x, void *dst, const float *amax, const float *amax2, int B, size_t n, void *stream) {
+    if (!x || !dst || !amax || B <= 0 || n == 0 || (n & 15) || ((size_t)x & 15) || ((size_t)dst & 15)) return A3D_ERR_ARG;
+    a3d_begin();
+    size_t bx = (n / 8 + 255) / 256;
+    const size_t cap = B >= 64 ? 64 : 2048 / (size_t)B;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(presplit_f16x2_kernel, dim3((unsigned)bx, (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned char *)dst, amax, amax2, B, n / 8);
+    return a3d_check_launch();
+}

@@ -39,7 +39,8 @@ class FastRCNNConvFCHead(nn.Module):
 
     def forward(self, x):
         """x: [rows, P, P, C] NHWC bins (or [rows, K]) -> [rows, FC_DIM]."""
-        x = ops.keep_amax(x.reshape(x.shape[0], -1), x)  # (a view: the recorded per-ROI maxima stay valid)
+        if x.dtype != torch.float16:  # (pre-split rows from the pooler go to fc1 as they are: ops.linear)
+            x = ops.keep_amax(x.reshape(x.shape[0], -1), x)  # (a view: the recorded per-ROI maxima stay valid)
         for fc in self.fcs:
             x = fc(x)
         return x

@@ -32,6 +32,11 @@ from .plane_head import build_plane_head
 # threshold 0.5 (276 rows) runs 44.36 ms per step with the heads one after the other and 44.43 ms with them side by side, and one after
 # the other the plane and axis heads share one Winograd input transform.
 HEADS_CONCURRENT_ROWS = int(os.environ.get("A3D_HEADS_CONCURRENT_ROWS", "0"))
+# True: the box pooler writes its rows pre-split (a3d_roialign_desc.out_h2) and fc1 takes both operands by LDS-DMA ("conv_h2w_kernel xd").
+# Same bits either way (tests/test_gpu_presplit.py).  Measured on the 64-frame clip (tools/fc1_bench.py, profiles/r04_fc1_dual_dma.txt):
+# pooler 2.50 -> 3.31 ms (the row waits in LDS for its maximum: three 7-wave workgroups per CU, each with a serial split-and-store tail),
+# fc1 4.05 -> 4.12-4.21 ms -- so the default stays the fp32 rows.  Why fc1 does not gain: DESIGN.md section 5 (round 4).
+POOLER_PRESPLIT = os.environ.get("A3D_POOLER_PRESPLIT", "0") != "0"
 
 
 class BatchedDetections:
@@ -92,7 +97,8 @@ class PlaneRCNNROIHeads(nn.Module):
     def box_batched(self, feats: Dict[str, torch.Tensor], prop_boxes, prop_count, img_hw) -> BatchedDetections:
         """_forward_box on fixed-size proposals [B,R,4] + count [B]."""
         lv = [feats[f] for f in self.box_in_features]
-        pooled = self.box_pooler.forward_batched(lv, prop_boxes, prop_count)  # [B*R,7,7,C]
+        # [B*R,7,7,C]; in the default arithmetic the pooler writes the rows pre-split for fc1 (both GEMM operands by LDS-DMA)
+        pooled = self.box_pooler.forward_batched(lv, prop_boxes, prop_count, presplit=POOLER_PRESPLIT and len(self.box_head.fcs) > 0)
         pred = self.box_predictor(self.box_head(pooled))
         boxes, scores, classes, _pos, count = self.box_predictor.inference_batched(pred, prop_boxes, prop_count, img_hw)
         return BatchedDetections(boxes, scores, classes, count, img_hw)

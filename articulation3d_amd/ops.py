@@ -381,6 +381,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     Winograd tiles, split-K partial sums) reaches 4 GiB -- ~86 frames x 1000 proposals at the box head's fc1, ~218 frames at a
     256-channel 120x160 layer -- run as consecutive launches over blocks of images.  Every image's result is a function of that
     image alone (per-image scales, fixed layer algorithm), so the blocks reproduce the single launch bit for bit."""
+    if x.dtype == torch.float16:
+        return _conv2d_presplit(x, p, x2=x2, res=res, res_ups=res_ups, act=act, out=out)
     if out_dtype is not None or x.dtype == torch.bfloat16 or (res is not None and res.dtype == torch.bfloat16) or (gate is not None and gate.dtype == torch.bfloat16):
         return _conv2d_bf16_storage(x, p, res=res, res_ups=res_ups, act=act, out=out, gate=gate, precision=precision, out_dtype=out_dtype)
     _req(x)
@@ -452,6 +454,95 @@ def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, prec
     b16 = lambda t: t is not None and t.dtype == torch.bfloat16
     d.io_bf16 = (1 if b16(x) else 0) | (2 if b16(out) else 0) | (4 if b16(res) else 0) | (8 if b16(gate) else 0)
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    return out
+
+
+def presplit_f16x2(x: torch.Tensor, x2: Optional[torch.Tensor] = None):
+    """x [B, H, W, C] fp32 (C % 16 == 0) -> torch.float16 [B, H, W, C/16, 2, 16]: the two fp16 planes of x * s(b), s(b) from the tensor's
+    recorded per-image maxima -- a3d_conv_desc.x_h2 (a3d_presplit_f16x2).  With x2 (second source of a channel concat) both tensors are
+    split under the scale of max(amax(x)[b], amax(x2)[b]), as the consuming kernel scales them; returns the pair."""
+    _req(x)
+    B, n = x.shape[0], x.numel() // x.shape[0]
+    ax, ax2 = amax_of(x), (None if x2 is None else amax_of(_req(x2)))
+    outs = []
+    for t in ((x,) if x2 is None else (x, x2)):
+        nt = t.numel() // B
+        o = torch.empty(tuple(t.shape[:-1]) + (t.shape[-1] // 16, 2, 16), device=t.device, dtype=torch.float16)
+        _lib.check(_lib.lib().a3d_presplit_f16x2(t.data_ptr(), o.data_ptr(), ax.data_ptr(), _p(ax2), B, nt, _stream()), "a3d_presplit_f16x2")
+        o._a3d_amax = ax if x2 is None else torch.maximum(ax, ax2)
+        outs.append(o)
+    return outs[0] if x2 is None else tuple(outs)
+
+
+def _conv2d_presplit(x, p: PackedConv, *, x2=None, res=None, res_ups=False, act=None, out=None) -> torch.Tensor:
+    """A direct fp16x2 layer on PRE-SPLIT activations (x, x2: torch.float16 [B, H, W, C/16, 2, 16] with recorded maxima): the wide kernel
+    with both operands by LDS-DMA ("conv_h2w_kernel xd").  Bit-identical to conv2d on the fp32 tensor the planes were split from."""
+    if DEFAULT_PRECISION != 3 and not os.environ.get("A3D_ALLOW_PRESPLIT"):
+        raise RuntimeError("pre-split activations belong to the fp16x2 arithmetic (A3D_PRECISION=3)")
+    ok = lambda t: t.is_cuda and t.is_contiguous() and t.dtype == torch.float16 and t.dim() == 6 and t.shape[4:] == (2, 16)
+    if not ok(x) or (x2 is not None and not ok(x2)):
+        raise RuntimeError("expected contiguous pre-split fp16 tensors [B, H, W, C/16, 2, 16]")
+    B, H, W = x.shape[:3]
+    Cin = x.shape[3] * 16
+    Cin2 = 0 if x2 is None else x2.shape[3] * 16
+    assert Cin + Cin2 == p.Cin and not (p.stem or p.pixshuf or p.phase) and p.presplit and p.Kpad == p.KH * p.KW * p.Cin, "plain direct layers only"
+    Ho = (H + 2 * p.pad - p.KH) // p.stride + 1
+    Wo = (W + 2 * p.pad - p.KW) // p.stride + 1
+    if B * max(H * W * max(Cin, Cin2), Ho * Wo * p.cols) * 4 > _ADDR_LIMIT:
+        # (blocks of images, as conv2d does for fp32 tensors: every image's result is a function of that image alone)
+        nb = max(1, _ADDR_LIMIT // (max(H * W * max(Cin, Cin2), Ho * Wo * p.cols) * 4))
+        if out is None:
+            out = torch.empty((B, Ho, Wo, p.cols), device=x.device, dtype=torch.float32)
+        ya = amax_slot(B, x.device)
+        cut = lambda t, s0, e0: None if t is None else keep_amax(t[s0:e0], _amax_rows(t, s0, e0))
+        for s0 in range(0, B, nb):
+            e0 = min(s0 + nb, B)
+            o = out[s0:e0]
+            o._a3d_amax = ya[s0:e0]
+            _conv2d_presplit(cut(x, s0, e0), p, x2=cut(x2, s0, e0), res=cut(res, s0, e0), res_ups=res_ups, act=act, out=o)
+        out._a3d_amax = ya
+        return out
+    if out is None:
+        out = torch.empty((B, Ho, Wo, p.cols), device=x.device, dtype=torch.float32)
+    d = _lib.ConvDesc()
+    d.x_h2, d.x2_h2 = x.data_ptr(), _p(x2)
+    d.w, d.scale, d.shift, d.res, d.y = _p(p.w), _p(p.scale), _p(p.shift), _p(res), _p(out)
+    d.B, d.H, d.W, d.Cin, d.Cin2 = B, H, W, Cin, Cin2
+    d.Ho, d.Wo, d.Cout = Ho, Wo, p.cols
+    d.KH, d.KW, d.stride, d.pad = p.KH, p.KW, p.stride, p.pad
+    d.Kpad, d.ups, d.act = p.Kpad, 0, p.act if act is None else act
+    d.res_ups, d.pixshuf, d.stem, d.splitk = int(res_ups), 0, 0, 1
+    d.precision = 3
+    d.tune = int(os.environ.get("A3D_XD_TUNE", "0"))  # (developer builds with -DA3D_ABLATIONS only: timing-only variants of the ring)
+    a = getattr(x, "_a3d_amax", None)
+    if a is None or a.numel() != B:
+        raise RuntimeError("a pre-split tensor carries the per-image maxima it was scaled by (_a3d_amax)")
+    d.in_amax = a.data_ptr()  # (two sources: both were split under the shared maximum, recorded on each)
+    if getattr(p, "_w_scale", None) is None:
+        p._w_scale = _pow2_scale_host(float(p.w.abs().max()))
+    d.w_scale = p._w_scale
+    if p.w_h2 is None or p.w_h2.device != p.w.device:
+        p.w_h2 = torch.empty((p.Kpad // 16, 2, p.w.shape[0], 16), device=p.w.device, dtype=torch.float16)
+        _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w.data_ptr(), p.w_h2.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, d.w_scale, _stream()), "a3d_split_f16x2_chunk")
+        if not os.environ.get("A3D_NO_PUBLISH"):
+            torch.cuda.current_stream().synchronize()
+    d.w_x3 = p.w_h2.data_ptr()
+    if not os.environ.get("A3D_NO_YAMAX"):
+        ya = getattr(out, "_a3d_amax", None)
+        if ya is None or ya.numel() != out.shape[0]:
+            ya = out._a3d_amax = amax_slot(out.shape[0], out.device)
+        d.y_amax = ya.data_ptr()
+    timing = CONV_TIMING is not None
+    if timing and CONV_TIMING_ONLY is not None:
+        timing = "conv_h2w_kernel xd" in CONV_TIMING_ONLY
+    if timing:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    if timing:
+        e1.record()
+        fl = 2.0 * B * Ho * Wo * p.cols * p.KH * p.KW * p.Cin
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, f"{B}x{H}x{W}x{Cin + Cin2}->{p.cols} k{p.KH} s{p.stride} presplit", fl, "f16x3", _stream()))
     return out
 
 
@@ -727,6 +818,10 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
 def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
     """x [M, K] -> [M, cols]."""
+    if x.dtype == torch.float16:  # pre-split rows [M, 1, 1, K/16, 2, 16] (roi_align_fpn(presplit=True), presplit_f16x2)
+        M = x.shape[0]
+        y = conv2d(x, p, act=act, splitk=splitk, m_dev=m_dev, precision=precision)
+        return keep_amax(y.view(M, p.cols), y)
     M, K = x.shape
     y = conv2d(keep_amax(x.view(M, 1, 1, K), x), p, act=act, splitk=splitk, m_dev=m_dev, precision=precision)
     return keep_amax(y.view(M, p.cols), y)
@@ -929,8 +1024,12 @@ ROI_SPATIAL_ORDER = True  # walk every image's boxes in (level, y, x) order (sch
 def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor,
                   count: Optional[torch.Tensor], P: int, sampling_ratio: int, aligned: bool, *,
                   row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, want_level: bool = False,
-                  zero: bool = False):
-    """feats[l] NHWC [B,Hf,Wf,C]; boxes [B,R,4]; -> [rows, P, P, C] (rows = B*R unless compacted)."""
+                  zero: bool = False, presplit: bool = False):
+    """feats[l] NHWC [B,Hf,Wf,C]; boxes [B,R,4]; -> [rows, P, P, C] (rows = B*R unless compacted).
+
+    presplit (default arithmetic only; a3d_roialign_desc.out_h2): the pooled rows leave the kernel as the two scaled fp16 planes the
+    fp16x2 GEMM multiplies -- a torch.float16 tensor [rows, 1, 1, P*P*C/16, 2, 16] (a3d_conv_desc.x_h2) carrying the per-row maxima;
+    `conv2d` / `linear` take it in place of the fp32 rows and move both operands by LDS-DMA."""
     _req(boxes)
     B, R, _ = boxes.shape
     Cc = feats[0].shape[3]
@@ -938,7 +1037,11 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     nrows = B * R if rows is None else rows
     # rows of slots past count[b] are never written NOR read downstream (GEMM rows are independent and the selection
     # kernels only look at live rows), so the buffer is not cleared (a 3 GB memset per 64-frame step otherwise)
-    out = (torch.zeros if zero else torch.empty)((nrows, P, P, Cc), device=dev, dtype=torch.float32)
+    presplit = bool(presplit) and DEFAULT_PRECISION == 3 and Cc == 256 and P * P * Cc * 4 <= 120 * 1024
+    if presplit:
+        out = (torch.zeros if zero else torch.empty)((nrows, 1, 1, P * P * Cc // 16, 2, 16), device=dev, dtype=torch.float16)
+    else:
+        out = (torch.zeros if zero else torch.empty)((nrows, P, P, Cc), device=dev, dtype=torch.float32)
     lvl = torch.full((nrows,), -1, device=dev, dtype=torch.int32) if want_level else None
     d = _lib.RoiAlignDesc()
     for l, f in enumerate(feats):
@@ -949,7 +1052,9 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     d.L, d.C = len(feats), Cc
     d.boxes, d.count, d.row_offset = boxes.data_ptr(), _p(count), _p(row_offset)
     d.B, d.R, d.P, d.sampling_ratio, d.aligned = B, R, int(P), int(sampling_ratio), int(bool(aligned))
-    d.out, d.out_level = out.data_ptr(), _p(lvl)
+    d.out, d.out_level = (None if presplit else out.data_ptr()), _p(lvl)
+    if presplit:
+        d.out_h2 = out.data_ptr()
     # (measured, tools/roi_bench.py: -7 % on the 1000-proposal box pooler; the 100-detection poolers lose 3-5 % to the sort launch)
     order = torch.empty((B * R,), device=dev, dtype=torch.int32) if (512 <= R <= 1024 and ROI_SPATIAL_ORDER) else None
     d.order_ws = _p(order)

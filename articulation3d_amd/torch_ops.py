@@ -73,19 +73,38 @@ def _conv2d_fused(x: Tensor, w: Tensor, scale: Optional[Tensor], shift: Optional
     return ops.conv2d(x, _packed_for(w, scale, shift, w_wino, KH, KW, stride, pad, act), res=res)
 
 
-_PACKED: "dict" = {}  # (storage identity and version of the filter tensors, geometry) -> PackedConv with its cached splits / scales
+_PACKED: "dict" = {}  # opt-in cache: (identity of the filter tensors, geometry) -> PackedConv with its cached splits / scales
+_CACHE_FILTERS = False
+
+
+def enable_filter_cache(flag: bool = True) -> None:
+    """OPT-IN cache of the derived filter forms of `conv2d_fused` (power-of-two scale, fp16 / bf16 planes).  Off by default: the op
+    takes RAW tensors, and nothing the op can see cheaply tells it that a filter's bytes changed -- `Tensor._version` is not bumped by
+    writes through `.data`, by raw-pointer kernels (this package's own `a3d_sgd_momentum` on flat-buffer views) or by other libraries,
+    so a cached split could silently go stale.  A caller that enables it owns the contract: call `invalidate_filter_cache()` after
+    every update of a filter that does not go through an in-place torch op on that very tensor."""
+    global _CACHE_FILTERS
+    _CACHE_FILTERS = bool(flag)
+    if not flag:
+        _PACKED.clear()
+
+
+def invalidate_filter_cache() -> None:
+    _PACKED.clear()
 
 
 def _packed_for(w, scale, shift, w_wino, KH, KW, stride, pad, act):
-    """The op takes raw tensors, the kernels want the filter's derived forms (its power-of-two scale, the fp16 planes of the default
-    arithmetic, published to every stream): building them per call cost 2-3 host synchronisations and redundant split kernels per
-    op call.  They are cached per filter identity -- data_ptr + `_version` (bumped by every in-place update) of each tensor -- in a
-    small LRU, like the modules' own packed weights (modeling/layers.py)."""
+    """The op takes raw tensors, the kernels want the filter's derived forms.  By default they are built PER CALL from the bytes the
+    tensors hold now (`presplit=False`: the direct kernels split the filter in their loaders, the Winograd layers split U on the launch
+    stream, the power-of-two scale is read back once per call) -- correct for any way the caller updates its weights.  The detector's
+    own modules do not come through here: they keep packed weights keyed on their parameters (modeling/layers.py)."""
+    cols, Kpad = w.shape
+    if not _CACHE_FILTERS:
+        return ops.PackedConv(w, scale, shift, KH, KW, stride, pad, Kpad // (KH * KW), cols, Kpad, act, w_wino=w_wino, presplit=False)
     ident = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.device)
     key = (ident(w), ident(scale), ident(shift), ident(w_wino), KH, KW, stride, pad, act)
     p = _PACKED.pop(key, None)
     if p is None:
-        cols, Kpad = w.shape
         p = ops.PackedConv(w, scale, shift, KH, KW, stride, pad, Kpad // (KH * KW), cols, Kpad, act, w_wino=w_wino, presplit=True)
         while len(_PACKED) >= 256:
             _PACKED.pop(next(iter(_PACKED)))

@@ -151,6 +151,15 @@ typedef struct a3d_conv_desc {
                               instead of fp32 -- bit 0: x, bit 1: y, bit 2: res, bit 3: gate (x / y / res / gate then point at bf16
                               data).  The kernel rounds its operands to bf16 anyway, so a bf16 x gives the same products; y is
                               rounded to nearest even on the way out.  BASELINE configs[4]: bf16 activations and gradients.       */
+    /* ---- precision 3 with the ACTIVATIONS pre-split by their producer (round 4): x_h2 replaces x (x may then be NULL).  Layout
+     * [B,H,W][Cin/16][h | l][16] fp16 -- per pixel (or per row of a linear layer) and 16-channel chunk the two fp16 planes of
+     * x * s(b), s(b) = the power of two that puts in_amax[b] in [2^14, 2^15): exactly the bits the loaders of the split-operand
+     * kernels compute from the fp32 tensor, and the same bytes (2 + 2 per element).  Producers: a3d_roi_align_fpn with out_h2 (the
+     * workgroup that pools a ROI knows the ROI's maximum before it stores) and a3d_presplit_f16x2 (one pass over a finished tensor).
+     * The wide direct kernel then moves BOTH operands global -> LDS by LDS-DMA through a 4-stage ring: no activation registers, no
+     * split arithmetic and no VGPR -> LDS stores in its loop; results are bit-identical to the launch on the fp32 tensor. */
+    const void *x_h2;      /* source 0 pre-split, or NULL                                                                            */
+    const void *x2_h2;     /* source 1 pre-split (required with x_h2 when Cin2 > 0), or NULL                                        */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -165,6 +174,10 @@ int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols,
 int a3d_split_bf16x3_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, void *stream);
 /* The fp16x2 counterpart (precision 3): src * scale == hi + lo (fp16, to 2^-22 relative); dst [outer][cols/chunk][2][rows][chunk]. */
 int a3d_split_f16x2_chunk(const float *src, void *dst, int outer, int rows, int cols, int chunk, float scale, void *stream);
+/* Activation pre-split for a3d_conv_desc.x_h2: x [B][n] fp32 (n % 16 == 0: pixels x channels of image b, channels % 16 == 0) ->
+ * dst [B][n/16][h | l][16] fp16 of x * s(b), s(b) from amax[b] as the kernels derive it (a3d_conv_desc.in_amax); amax2 optional
+ * (second source of a channel concat: both share max(amax[b], amax2[b])).  One HBM-bound pass, same byte count in and out. */
+int a3d_presplit_f16x2(const float *x, void *dst, const float *amax, const float *amax2, int B, size_t n, void *stream);
 /* out[b] = max(out[b], max |x[b, 0..n)|) for b < B (out zero-initialised by the caller): the in_amax of a tensor that no kernel of
  * this library produced. */
 int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream);
@@ -282,6 +295,11 @@ typedef struct a3d_roialign_desc {
                           block exponents leave every feature with an absolute error of ~2^-40 of its level's maximum; relative to
                           such a ROI that exceeds fp32's own rounding.  The default arithmetic counts these ROIs instead of passing
                           them silently (0 on every frame of the test and bench clips; A3D_PRECISION=2 is the remedy). */
+    void *out_h2;      /* optional, INSTEAD of out (round 4; C == 256, P*P*C*4 <= 120 KiB: the 7x7 box pooler): the pooled rows pre-split
+                          for the fp16x2 GEMM that consumes them, [rows][P*P*C/16][h | l][16] fp16 of pooled * s(row), s(row) = the
+                          power of two that puts out_amax[row] in [2^14, 2^15) -- a3d_conv_desc.x_h2 of the box head's fc1
+                          (roi_heads.py:185-187).  The workgroup keeps the row in LDS until its maximum is known.  Same pooled
+                          values as `out` (the split is exact to 2^-22 of the row's maximum). */
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);

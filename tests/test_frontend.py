@@ -116,3 +116,32 @@ def test_device_rle_encode_equals_the_host_codec():
     got_bool = rle.encode_device(torch.from_numpy(masks[:4].astype(bool)).cuda())
     assert got_bool == got[:4]
     assert rle.encode_device(torch.zeros((0, H, W), dtype=torch.uint8, device="cuda")) == []
+
+
+def test_every_rank_of_an_image_directory_reads_its_block_even_an_empty_one(tmp_path):
+    """tools/inference.py's reader under torchrun: shard_range uses ceil blocks, so with 9 frames on 8 ranks the blocks are
+    2,2,2,2,1,0,0,0 -- the trailing ranks' EMPTY blocks come back as (0, H, W, 3) arrays at the clip's size (a rank that raised
+    there died before the gather and took the job down)."""
+    import importlib.util
+    import os
+
+    from PIL import Image
+
+    from articulation3d_amd.parallel import shard_range
+
+    spec = importlib.util.spec_from_file_location("a3d_inference_tool", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "inference.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    for i in range(9):
+        Image.fromarray(_img(24, 32, seed=i)).save(tmp_path / f"f{i:03d}.png")
+    assert tool.count_frames(str(tmp_path)) == 9
+    whole = tool.read_frames(str(tmp_path))
+    assert whole.shape == (9, 24, 32, 3)
+    got = []
+    for rank in range(8):
+        lo, hi = shard_range(9, rank, 8)
+        blk = tool.read_frames(str(tmp_path), lo, hi)
+        assert blk.dtype == np.uint8 and blk.shape == (hi - lo, 24, 32, 3), (rank, blk.shape)
+        got.append(blk)
+    assert sum(len(b) == 0 for b in got) == 3
+    assert np.array_equal(np.concatenate(got), whole)

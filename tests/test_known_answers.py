@@ -181,3 +181,26 @@ def test_torch_ops_give_the_same_bits_as_the_ctypes_wrappers():
     y3 = torch.ops.a3d.conv2d_fused(x, pk3.w, None, None, None, pk3.w_wino, 3, 3, 1, 1, ops.ACT_NONE)  # Winograd-domain weights -> Winograd path
     # (64 -> 64: the Winograd form in the bf16x3 / fp32 arithmetic, the direct form in the default fp16x2 one)
     assert torch.equal(y3, ops.conv2d(x, pk3)) and ops.last_conv_variant().startswith(("wino_gemm", "conv_h2_kernel"))
+    # the op sees RAW tensors: a filter updated behind torch's version counter (`.data`, a raw-pointer optimiser kernel) must be used
+    # as it is NOW -- derived forms (power-of-two scale, fp16 planes) are built per call unless the caller opted into the cache
+    from articulation3d_amd import torch_ops
+
+    wq = pk.w.clone()
+    y_a = torch.ops.a3d.conv2d_fused(x, wq, pk.scale, pk.shift, None, None, 1, 1, 1, 0, ops.ACT_RELU)
+    v0 = wq._version
+    wq.data.mul_(-3.0)  # (does not bump wq._version)
+    assert wq._version == v0
+    y_b = torch.ops.a3d.conv2d_fused(x, wq, pk.scale, pk.shift, None, None, 1, 1, 1, 0, ops.ACT_RELU)
+    pk_b = ops.pack_conv(w * -3.0, torch.zeros(256), None, 1, 0, ops.ACT_RELU)
+    pk_b.scale, pk_b.shift = pk.scale, pk.shift
+    assert torch.equal(y_b, ops.conv2d(x, pk_b)) and not torch.equal(y_a, y_b)
+    torch_ops.enable_filter_cache(True)  # opt-in: the caller owns invalidation
+    try:
+        y_c = torch.ops.a3d.conv2d_fused(x, wq, pk.scale, pk.shift, None, None, 1, 1, 1, 0, ops.ACT_RELU)
+        assert torch.equal(y_c, y_b)
+        wq.data.mul_(0.5)
+        torch_ops.invalidate_filter_cache()
+        y_d = torch.ops.a3d.conv2d_fused(x, wq, pk.scale, pk.shift, None, None, 1, 1, 1, 0, ops.ACT_RELU)
+        assert not torch.equal(y_d, y_c)
+    finally:
+        torch_ops.enable_filter_cache(False)

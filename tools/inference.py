@@ -68,8 +68,15 @@ def read_frames(path: str, lo: int = 0, hi: int = None) -> np.ndarray:
         z = np.load(path)
         frames = z[list(z.keys())[0]][sl]
     elif os.path.isdir(path):
-        names = sorted(n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg")))[sl]
-        frames = np.stack([np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names])
+        every = sorted(n for n in os.listdir(path) if n.lower().endswith((".png", ".jpg", ".jpeg")))
+        names = every[sl]
+        if names:
+            frames = np.stack([np.asarray(Image.open(os.path.join(path, n)).convert("RGB")) for n in names])
+        else:  # an empty block (trailing ranks when F <= ceil(F / world) * (world - 1)): zero frames at the clip's size
+            if not every:
+                raise SystemExit(f"{path}: no .png / .jpg frames")
+            w, h = Image.open(os.path.join(path, every[0])).size
+            frames = np.zeros((0, h, w, 3), np.uint8)
     else:
         frames = np.asarray(Image.open(path).convert("RGB"))[None]
     assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8, "frames must be uint8 [F,H,W,3]"
@@ -133,10 +140,9 @@ def main():
     lo, hi = shard_range(n_frames, rank, world)
     frames_rgb = read_frames(args.input, lo, hi)  # this rank's block only (rank 0 reads the rest later, for the optimiser)
     if args.calibrate_bn:
-        if lo > 0:  # the statistics come from the FIRST two frames of the clip on every rank
-            frames_rgb_head = read_frames(args.input, 0, 2)
-        else:
-            frames_rgb_head = frames_rgb[:2]
+        # the statistics come from the FIRST two frames of the clip on EVERY rank (rank 0's own block may hold only one of them)
+        n_head = min(2, n_frames)
+        frames_rgb_head = frames_rgb[:n_head] if lo == 0 and hi - lo >= n_head else read_frames(args.input, 0, n_head)
         from articulation3d_amd import ops
         from articulation3d_amd.utils.synthetic import calibrate_batchnorm
 
