@@ -353,8 +353,10 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     const int mtiles = (d->Cout + 127) / 128, ntiles = (d->Cin + 127) / 128;
     int chunk = (P + d->splitk - 1) / d->splitk;
     chunk = (chunk + 31) / 32 * 32;  // a multiple of both kernels' k-chunk (16 / 32 pixels)
-    a3d_begin();
     if (d->io_bf16 && (d->precision != 1 || (d->io_bf16 & ~3))) return A3D_ERR_ARG;  // bf16-stored operands: the bf16 arithmetic only
+    // (the bf16-stored forms load channel PAIRS as dwords: an odd channel count would drop the last channel's gradient and misalign the loads)
+    if (((d->io_bf16 & 1) && (d->Cin & 1)) || ((d->io_bf16 & 2) && (d->Cout & 1))) return A3D_ERR_ARG;
+    a3d_begin();
     if (d->precision == 1 || d->precision == 2) {
         if ((size_t)P * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
         const dim3 grid(mtiles * ntiles * d->KH * d->KW, d->splitk);

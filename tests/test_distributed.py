@@ -185,3 +185,101 @@ def test_gradient_allreduce_single_process():
 
     g = torch.ones(8)
     assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.ones(8))
+
+
+# ---- BASELINE configs[3] at its real shapes on 8 gloo ranks (no 8-GPU node exists here; the path is covered on CPU) ---
+def _clip1024_worker(rank, world, port, q):
+    import sys
+
+    import psutil
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from articulation3d_amd.parallel import gather_records, gather_records_async, shard_range
+    from articulation3d_amd.pipeline import instances_from_compact
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F_, R, REC, BATCH = 1024, 100, 798, 32
+    per = (F_ + world - 1) // world
+    lo, hi = shard_range(F_, rank, world)
+    ok = (lo, hi) == (rank * 128, rank * 128 + 128) and per == 128
+    proc = psutil.Process()
+
+    def block(det_of_frame):
+        """This rank's [128, 100, 798] slot block, filled batch by batch as pipeline.detect_clip fills it (4 batches of 32 frames);
+        detection r of clip frame f carries score f + r / 1000 in field 4 and class r % 3 in field 5."""
+        rec = torch.zeros(per, R, REC)
+        cnt = torch.zeros(per, dtype=torch.int32)
+        for s in range(lo, hi, BATCH):
+            for f in range(s, min(s + BATCH, hi)):
+                n = det_of_frame(f)
+                cnt[f - lo] = n
+                rec[f - lo, :n, 4] = f + torch.arange(n, dtype=torch.float32) / 1000.0
+                rec[f - lo, :n, 5] = (torch.arange(n) % 3).float()
+        return rec, cnt
+
+    slots = [r * per + i for r in range(world) for i in range(128)]
+    # (a) the realistic operating point, D ~ 4 per frame: ONE gather of the live records for the rank's whole block
+    d4 = lambda f: (f * 7) % 9  # 0..8 detections, mean 4
+    rec, cnt = block(d4)
+    rss0 = proc.memory_info().rss
+    rows, all_cnt = gather_records_async(rec, cnt, rows=per).wait_compact()
+    grew = proc.memory_info().rss - rss0
+    live = sum(d4(f) for f in range(F_))
+    ok = ok and rows.shape == (live, REC) and all_cnt.tolist() == [d4(f) for f in range(F_)]
+    # what arrived is the live records (13 MB), not the 327 MB slot layout of the clip: the receiving side never builds the dense form
+    ok = ok and rows.numel() * 4 == live * REC * 4 and grew < 150 * 2 ** 20
+    preds = instances_from_compact(rows, all_cnt, slots, (480, 640), conf_threshold=-1.0, with_masks=False)
+    ok = ok and len(preds) == F_
+    for f in (0, 1, 127, 128, 129, 511, 512, 1023):  # temporal order across rank boundaries, frame by frame
+        want = [f + r / 1000.0 for r in range(d4(f))]
+        ok = ok and len(preds[f].scores) == len(want) and all(abs(float(a) - b) < 1e-3 for a, b in zip(preds[f].scores, want))
+    ok = ok and [len(p.scores) for p in preds] == [d4(f) for f in range(F_)]
+    # (b) per-batch gathers as bench.py issues them: 4 batches of 32 frames, the gather of batch i in flight while batch i + 1 is built
+    pending, got = [], []
+    for b in range(4):
+        sl = slice(b * BATCH, (b + 1) * BATCH)
+        pending.append(gather_records_async(rec[sl].contiguous(), cnt[sl].contiguous(), rows=BATCH))
+        if len(pending) > 1:
+            got.append(pending.pop(0).wait_compact())
+    got.append(pending.pop(0).wait_compact())
+    for b, (rws, cc) in enumerate(got):  # batch b of every rank, rank-major: clip frames r * 128 + b * 32 + i
+        frames = [r * 128 + b * BATCH + i for r in range(world) for i in range(BATCH)]
+        ok = ok and cc.tolist() == [d4(f) for f in frames] and rws.shape[0] == sum(d4(f) for f in frames)
+        first = [f for f in frames if d4(f)][:1]
+        ok = ok and (not first or abs(float(rws[0, 4]) - first[0]) < 1e-3)
+    # (c) the stress point D = 100 (SCORE_THRESH_TEST 0: every slot live): the compact form degenerates to the dense one and must still
+    # arrive whole and in order -- one 32-frame batch per rank (82 MB gathered on every rank)
+    rec100, cnt100 = block(lambda f: 100)
+    rws, cc = gather_records_async(rec100[:BATCH].contiguous(), cnt100[:BATCH].contiguous(), rows=BATCH).wait_compact()
+    ok = ok and rws.shape == (world * BATCH * 100, REC) and cc.tolist() == [100] * (world * BATCH)
+    ok = ok and abs(float(rws[(3 * BATCH + 5) * 100 + 42, 4]) - (3 * 128 + 5 + 0.042)) < 1e-3
+    # (d) a block that does not fit `rows` on ONE rank: all eight raise (nobody is left inside the collective)
+    try:
+        n_mine = BATCH + 1 if rank == 5 else BATCH
+        gather_records(rec[:n_mine].contiguous(), cnt[:n_mine].contiguous(), rows=BATCH)
+        ok = False
+    except ValueError as e:
+        ok = ok and "rows=" in str(e)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_clip_of_1024_frames_on_8_ranks_gloo():
+    """BASELINE configs[3] at its real shapes: 1024 frames -> 8 contiguous blocks of 128, filled in 4 batches of 32; records of
+    100 slots x 798 floats; D ~ 4 and D = 100.  Checks the temporal order of the reassembled clip, that the receiving side holds
+    the live records only, bench.py's one-gather-per-batch pipelining, and the all-ranks-raise path at world size 8
+    (reference analogue: tools/train_net.py:110-117 launch, evaluation/arti_evaluation.py:195-199 gather)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clip1024_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert res == [(r, True) for r in range(world)]
