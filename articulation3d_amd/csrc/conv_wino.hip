@@ -181,6 +181,7 @@ struct WinoArgs {
     const float *in_amax, *in_amax2;  // precision 3: per-image maxima of the conv input(s)
     float w_scale;                    // precision 3: scale of the pre-split filter planes in U3
     float *M;                         // plane-split form: [16][T][Cout] per-plane products (a3d_conv_desc.wino_m)
+    int abl;                          // developer builds (-DA3D_ABLATIONS, env A3D_WINO_ABL): timing-only variants of the ring loop; 0 otherwise
 };
 
 typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
@@ -954,7 +955,50 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             rdB(F0, 0, 0, p);
         }
         int cf = 0, ckc = 0;
+        // (Round 4, measured and not taken: the six fragment reads of a step pinned behind the first three MFMAs of the step before it
+        // with sched_group_barriers -- hipcc sinks them to the end of each half, in front of the `lgkmcnt(0)` waits -- 2.16 | 2.26 ms on
+        // the p2 layer across two boxes: no gain.  Timing-only decomposition of this loop, p2 256 -> 256, 2.30 ms (tools/wino_abl.sh,
+        // profiles/r04_wino_ablation.txt): without the V DMA 1.96, without the filter DMA 1.94, without both 1.85, + without the
+        // barrier 1.79, without DMA and fragment reads 1.53, without DMA and fold 1.71, MFMAs + epilogue alone 1.375.)
         for (int it = 0; it < nit; ++it) {
+#ifdef A3D_ABLATIONS  // timing-only (results wrong): bit 0 no V DMA, 1 no filter DMA, 2 no barrier, 3 no fragment reads, 4 no fold
+            const bool rd = !(a.abl & 8);
+            X3W_FENCE
+            X3W_TERM(F0, 0, 0)
+            if (rd) {
+                rdA(F1, st, 1, 0);
+                rdB(F1, st, 1, 0);
+                rdB(F1, st, 1, 1);
+            }
+            X3W_TERM(F0, 0, 1)
+            if (rd) rdA(F1, st, 1, 1);
+            X3W_TERM(F0, 1, 0)
+            X3W_FENCE
+            __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPS) : "memory");
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(a.abl & 4)) __builtin_amdgcn_s_barrier();
+            if (!(a.abl & 1)) dma_v(st, dma_c);
+            if (!(a.abl & 2)) dma_w(st);
+            st = st == NST - 1 ? 0 : st + 1;
+            X3W_FENCE
+            X3W_TERM(F1, 0, 0)
+            if (rd) {
+                rdA(F0, st, 0, 0);
+                rdB(F0, st, 0, 0);
+                rdB(F0, st, 0, 1);
+            }
+            X3W_TERM(F1, 0, 1)
+            if (rd) rdA(F0, st, 0, 1);
+            X3W_TERM(F1, 1, 0)
+            X3W_FENCE
+            if constexpr (!PS) {
+                if (++ckc == KC) {
+                    ckc = 0;
+                    if (!(a.abl & 16)) fold(mf, cf++);
+                }
+            }
+#else
+            X3W_FENCE
             X3W_TERM(F0, 0, 0)
             rdA(F1, st, 1, 0);
             rdB(F1, st, 1, 0);
@@ -962,12 +1006,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             X3W_TERM(F0, 0, 1)
             rdA(F1, st, 1, 1);
             X3W_TERM(F0, 1, 0)
+            X3W_FENCE
             __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPS) : "memory");  // chunk it + 1 has landed (younger: NST - 2 chunks)
             __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             dma_v(st, dma_c);  // chunk it + NST into the stage of chunk it
             dma_w(st);
             st = st == NST - 1 ? 0 : st + 1;
+            X3W_FENCE
             X3W_TERM(F1, 0, 0)
             rdA(F0, st, 0, 0);
             rdB(F0, st, 0, 0);
@@ -975,12 +1021,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             X3W_TERM(F1, 0, 1)
             rdA(F0, st, 0, 1);
             X3W_TERM(F1, 1, 0)
+            X3W_FENCE
             if constexpr (!PS) {
                 if (++ckc == KC) {
                     ckc = 0;
                     fold(mf, cf++);
                 }
             }
+#endif
         }
         // the DMAs past the last chunk land anywhere in the ring, the epilogue's tiles use the V areas of stages 0 and 1
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1332,6 +1380,10 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.in_amax2 = d->in_amax2;
     a.w_scale = d->w_scale;
     a.M = nullptr;
+    a.abl = 0;
+#ifdef A3D_ABLATIONS
+    a.abl = getenv("A3D_WINO_ABL") ? atoi(getenv("A3D_WINO_ABL")) : 0;
+#endif
     if (d->precision == 3) {  // fp16x2: the wide kernels only (w_wino_x3 = the filter pre-split by a3d_split_f16x2_chunk(.., 32, w_scale))
         if (!d->w_wino_x3 || (a.C & 31) || !d->in_amax || !(d->w_scale > 0.f) || ((d->Cout + 63) / 64) % 2 != 0 ||
             (size_t)16 * d->Cout * a.C * 4 >= ((size_t)1 << 32))
