@@ -1321,6 +1321,11 @@ size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
 // of the 256 CUs idle for 16 x C/32 iterations, and 32 x as many 64-tile single-plane workgroups still fit in a few rounds.  Measured
 // (frames/s, bound 0 | 16 | 32 | 48 | 96): 1 frame 113 | 145 | 143 | 145 | 143, 4 frames 386 | 426 | 447 | 451 | 453, 64 frames
 // 1288 | . | 1278 (= its 0) | . | 1285 (-0.3 %).  A3D_WINO_PS_BLOCKS overrides the bound (0 = never; A/B runs).
+// (Round 4, built, bit-identical, measured and removed: the partial LAST round of a multi-round 64-tile launch run plane-split + folded
+// while the full rounds keep the one-launch form.  64 frames of a 30x40 level are 600 blocks = one full round of 512 and one that is
+// 17 % full -- 0.214 ms where 54 frames, one round, take 0.134.  With the 88 trailing blocks as 1408 plane workgroups + the fold over
+// their tiles: 0.218 | 0.216 ms (hybrid | plain), 60x80 256 -> 128 0.475 | 0.416: ring fill, raw-tile epilogue, the M round trip and two
+// more launches cost what the short round costs.)
 extern "C" size_t a3d_wino_m_bytes(const a3d_conv_desc *d) {
     static int ps_max = -1;
     if (ps_max < 0) ps_max = getenv("A3D_WINO_PS_BLOCKS") ? atoi(getenv("A3D_WINO_PS_BLOCKS")) : 48;

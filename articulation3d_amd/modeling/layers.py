@@ -66,6 +66,9 @@ def _publish():
 class _Packable(nn.Module):
     """Caches the packed weights; re-packs when a parameter/buffer was modified or moved."""
 
+    pin_precision = None  # 2: the precision audit (PlaneRCNN.audit_precision) pinned this layer to bf16x3; applied to every (re)pack
+    _a3d_name = ""        # qualified module name, filled in by the audit for its report
+
     def __init__(self):
         super().__init__()
         self._pack_cache = None
@@ -81,6 +84,7 @@ class _Packable(nn.Module):
             self._pack_cache = self._pack()
             self._pack_key = key
             _publish()
+        self._pack_cache.pin_precision, self._pack_cache.name = self.pin_precision, self._a3d_name
         return self._pack_cache
 
     def _pack(self):
@@ -163,6 +167,8 @@ class BNConv2d(_Packable):
             self._phase_cache = ops.pack_conv_ups_phases(self.conv.weight, self.conv.bias, bn, self.act, device=self.conv.weight.device)
             self._phase_key = key
             _publish()
+        for q in self._phase_cache:
+            q.pin_precision, q.name = self.pin_precision, self._a3d_name
         return self._phase_cache
 
 

@@ -116,6 +116,50 @@ class PlaneRCNN(nn.Module):
         with ops.share_wino_input(share):
             return self._detect_on_features(feats, frames, B, hw, want_masks, given_boxes)
 
+    # ------------------------------------------------------------------ load-time precision audit (round 4)
+    def _packables(self):
+        """(qualified name, layer holder) of every conv / linear / deconv holder of the detection path, incl. the depth head's
+        packers (plain attributes there, so that its state_dict keeps the reference's names only)."""
+        from .layers import _Packable
+
+        seen = {}
+        for name, m in self.named_modules():
+            if isinstance(m, _Packable):
+                seen[id(m)] = (name, m)
+        dh = getattr(self, "depth_head", None)
+        if dh is not None:
+            for kind in ("conv", "deconv"):
+                for i, m in enumerate(getattr(dh, "_pk_" + kind, []), 1):
+                    seen.setdefault(id(m), (f"depth_head.{kind}{i}", m))
+        return list(seen.values())
+
+    @torch.no_grad()
+    def audit_precision(self, frames: torch.Tensor, pin: bool = True, source_rgb: bool = False, resize_to=(480, 640)):
+        """Run `frames` (uint8, a few calibration frames of the deployment's kind) through the detector with every fp16x2 layer
+        shadowed by its bf16x3 evaluation (ops.PrecisionAudit): each output element is held to the fp32-style one-term error law at its
+        layer's own scale, and a layer that violates it anywhere is pinned to bf16x3 for the lifetime of the model -- per LAYER,
+        statically, so results stay independent of batching.  Call once after loading a checkpoint (tools/inference.py does).
+        Returns the audit (`.rows`: one record per layer launch; `.pinned()`).  Reference: the arithmetic this guards replaces the
+        fp32 tensors of planercnn.py:125-184 on weights of the `exps/model_final.pth` kind (config.yaml:312)."""
+        assert not self.training
+        for name, m in self._packables():
+            m._a3d_name = name
+        audit = ops.PrecisionAudit(pin=pin)
+        if ops.DEFAULT_PRECISION != 3:
+            return audit  # (nothing to audit: bf16x3 and the fp32-input MFMA have no block exponents)
+        with audit:
+            self.inference_batched(frames, source_rgb=source_rgb, resize_to=resize_to)
+            torch.cuda.synchronize()
+        if pin:
+            names = {r["layer"] for r in audit.pinned()}
+            for name, m in self._packables():
+                if name in names:
+                    m.pin_precision = 2
+        return audit
+
+    def pinned_layers(self):
+        return sorted(name for name, m in self._packables() if m.pin_precision == 2)
+
     def _detect_on_features(self, feats, frames, B, hw, want_masks, given_boxes) -> BatchedOutput:
         proposals = None
         if given_boxes is None:

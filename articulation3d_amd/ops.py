@@ -104,6 +104,8 @@ class PackedConv:
     w_x3: Optional[torch.Tensor] = None  # [Kpad/16, 3, cols, 16] bf16 planes of w (a3d_conv_desc.w_x3), made at the first such use
     w_wino_h2: Optional[torch.Tensor] = None  # [16, Cin/32, 2, cols, 32] fp16 planes of w_wino * its scale (precision 3)
     w_h2: Optional[torch.Tensor] = None  # [Kpad/16, 2, cols, 16] fp16 planes of w * w_scale (a3d_conv_desc.w_x3 at precision 3)
+    pin_precision: Optional[int] = None  # 2: this layer runs bf16x3 (exact splits, no window) whatever the mode -- set by the precision audit
+    name: str = ""  # owner module's qualified name, when known (audit reports)
 
     @property
     def out_channels(self) -> int:
@@ -381,6 +383,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     Winograd tiles, split-K partial sums) reaches 4 GiB -- ~86 frames x 1000 proposals at the box head's fc1, ~218 frames at a
     256-channel 120x160 layer -- run as consecutive launches over blocks of images.  Every image's result is a function of that
     image alone (per-image scales, fixed layer algorithm), so the blocks reproduce the single launch bit for bit."""
+    if AUDIT is not None and not AUDIT.busy and precision is None and x.dtype == torch.float32 and out_dtype is None and not p.phase:
+        return AUDIT.conv2d(x, p, x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk, m_dev=m_dev, out=out, tune=tune, wino=wino, gate=gate)
     if x.dtype == torch.float16:
         return _conv2d_presplit(x, p, x2=x2, res=res, res_ups=res_ups, act=act, out=out)
     if out_dtype is not None or x.dtype == torch.bfloat16 or (res is not None and res.dtype == torch.bfloat16) or (gate is not None and gate.dtype == torch.bfloat16):
@@ -595,6 +599,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
         mode = DEFAULT_PRECISION if precision is None else 2
+        if mode == 3 and p.pin_precision == 2:  # pinned by the precision audit (a function of the LAYER: batch invariance survives)
+            mode = 2
         plain = not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or splitk != 1 or m_dev is not None) and p.Kpad == p.KH * p.KW * p.Cin
         if mode == 1:
             precision = 1 if plain and p.Cin % 32 == 0 else 0
@@ -617,6 +623,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         else:
             precision = 0
     d.precision = int(precision)
+    global _LAST_PRECISION
+    _LAST_PRECISION = int(precision)
     d.phase = int(p.phase)
     if d.precision == 3:  # fp16x2: per-image scales of the activations (recorded by their producers), one static scale of the filter
         d.in_amax = amax_of(x).data_ptr()
@@ -800,9 +808,12 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
     (A3D_UPS_FUSED_MIN_BLOCKS).  Measured at 64 frames (tools/ups_bench.py, four launches | one): 8x10 0.122 | 0.083 ms, 15x20 0.230 |
     0.144, 30x40 0.401 | 0.400, 60x80 1.328 | 1.364, 120x160 -> 64 channels 3.26 | 2.76; the step 1305 -> 1324 frames/s."""
     B, H, W, _ = x.shape
+    if AUDIT is not None and not AUDIT.busy and fused is None:
+        return AUDIT.conv2d_ups(x, phases, x2)
     out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
+    pinned = phases[0].pin_precision == 2  # (the audit pins the LAYER: its four phase launches then run bf16x3)
     if fused is None:
-        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and (-(-(B * H * W) // 256)) * (-(-4 * phases[0].cols // 256)) >= UPS_FUSED_MIN_BLOCKS
+        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned and (-(-(B * H * W) // 256)) * (-(-4 * phases[0].cols // 256)) >= UPS_FUSED_MIN_BLOCKS
     if fused:
         pf = getattr(phases[0], "_fused", None)
         if pf is None:
@@ -813,6 +824,115 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out
+
+
+_LAST_PRECISION = -1  # a3d_conv_desc.precision of the calling thread's last conv launch (what the mode rules resolved to)
+AUDIT = None  # a PrecisionAudit while model.audit_precision() runs (offline, once per loaded checkpoint); None on the detection path
+
+
+class PrecisionAudit:
+    """Load-time check of the default arithmetic on the weights actually loaded.
+
+    fp16x2 carries 22 significand bits under ONE power-of-two exponent per image: an output whose whole receptive field lies more than
+    2^18 below its image's maximum loses bits ("what the format guarantees").  Random-init weights with calibrated
+    batch norm never get there; a checkpoint nobody here has seen might.  While this object is installed (`with PrecisionAudit() as a:`)
+    every conv / linear / deconv layer that the mode rules send to fp16x2 is ALSO evaluated in bf16x3 (exact 3-way splits: no block
+    exponent, no window) on the same input, together with S = sum_k |x_k| |w_k| (the same layer on |x|, |w|), and every output element
+    is held to the fp32-style ONE-term law at the layer's own scale:
+
+        | y_fp16x2 - y_bf16x3 |  <=  1.25 c 2^-22 |scale_n| S,      c = 8 + sqrt(K) / 4      (tests/test_gpu_precision.py; Winograd layers:
+                                                                     S max-pooled 3x3, the 4x4 input patch of a 2x2 output tile)
+
+    (the epilogue -- folded BN scale, shift, residual, ReLU / LeakyReLU -- is 1-Lipschitz in the accumulator up to |scale_n|; 1.25 leaves
+    room for the reference's own rounding).  A layer with any violating element is PINNED to bf16x3 (`PackedConv.pin_precision`, kept on
+    its module): a static property of the layer, so a frame's result still does not depend on its batch.  The pass costs three launches
+    per layer and a few torch reductions; it is not part of the detection path."""
+
+    def __init__(self, pin: bool = True, slack: float = 1.25):
+        self.pin, self.slack, self.busy = pin, slack, False
+        self.rows = []  # dicts: layer, kernel, shape, K, max_ratio, violations, elements, pinned
+
+    def __enter__(self):
+        global AUDIT
+        self._prev, AUDIT = AUDIT, self
+        return self
+
+    def __exit__(self, *exc):
+        global AUDIT
+        AUDIT = self._prev
+        return False
+
+    @staticmethod
+    def _abs_pack(p: PackedConv) -> PackedConv:
+        q = getattr(p, "_audit_abs", None)
+        if q is None or q.w.data_ptr() == 0 or getattr(p, "_audit_abs_src", None) != (p.w.data_ptr(), p.w._version):
+            q = PackedConv(p.w.abs(), None, None, p.KH, p.KW, p.stride, p.pad, p.Cin, p.cols, p.Kpad, ACT_NONE, p.pixshuf, p.stem, phase=p.phase)
+            p._audit_abs, p._audit_abs_src = q, (p.w.data_ptr(), p.w._version)
+        return q
+
+    def _judge(self, p: PackedConv, variant: str, shape, y3, y2, S, K: int, wino: bool):
+        c = 8.0 + math.sqrt(K) / 4.0
+        if wino:  # a 2x2 output tile is computed from its whole 4x4 input patch
+            S = torch.nn.functional.max_pool2d(S.permute(0, 3, 1, 2), 3, 1, 1).permute(0, 2, 3, 1)
+        n = y3.shape[-1]
+        sc = torch.ones(n, device=y3.device) if p.scale is None else p.scale[:n].abs()  # (per GEMM column = per output channel; deconvs carry none)
+        bound = self.slack * c * 2.0 ** -22 * sc * S[..., :n] + 1e-37
+        err = (y3 - y2).abs()
+        finite = torch.isfinite(err) & torch.isfinite(bound)
+        ratio = torch.where(finite, err / bound, torch.zeros_like(err))
+        viol = int((ratio > 1.0).sum())
+        row = dict(layer=p.name or f"<packed {id(p):x}>", kernel=variant, shape=shape, K=K, max_ratio=float(ratio.max()) if ratio.numel() else 0.0,
+                   violations=viol, elements=int(ratio.numel()), pinned=False)
+        if viol and self.pin:
+            p.pin_precision = 2
+            row["pinned"] = True
+        self.rows.append(row)
+        return row
+
+    def conv2d(self, x, p: PackedConv, **kw):
+        self.busy = True
+        try:
+            y = conv2d(x, p, **kw)
+            variant, prec = last_conv_variant(), _LAST_PRECISION
+            if prec != 3:
+                return y
+            kw2 = dict(kw)
+            kw2["out"] = None
+            y2 = conv2d(x, p, precision="bf16x3", **kw2)
+            x2 = kw.get("x2")
+            S = conv2d(x.abs(), self._abs_pack(p), x2=None if x2 is None else x2.abs(), ups=kw.get("ups", False), splitk=kw.get("splitk", 1),
+                       m_dev=kw.get("m_dev"), precision="bf16x3", wino=False)
+            live = None
+            if kw.get("m_dev") is not None:  # ragged per-ROI batches: rows past the live count are not computed
+                live = int(kw["m_dev"].reshape(-1)[0])
+            yy, y2, S = (t if live is None else t[:live] for t in (y, y2, S))
+            self._judge(p, variant, tuple(x.shape), yy, y2, S, 147 if p.stem else p.KH * p.KW * p.Cin, variant.startswith("wino"))
+            return y
+        finally:
+            self.busy = False
+
+    def conv2d_ups(self, x, phases, x2):
+        self.busy = True
+        try:
+            y = conv2d_ups(x, phases, x2=x2)
+            variant = last_conv_variant()
+            if DEFAULT_PRECISION != 3 or phases[0].pin_precision == 2:
+                return y
+            out2 = torch.empty_like(y)
+            S = torch.empty_like(y)
+            for p in phases:  # the four phase launches: bf16x3 reference, and sum |x||w| per phase
+                conv2d(x, p, x2=x2, out=out2, precision="bf16x3")
+                conv2d(x.abs(), self._abs_pack(p), x2=None if x2 is None else x2.abs(), out=S, precision="bf16x3")
+            row = self._judge(phases[0], variant, tuple(x.shape) + ("ups",), y, out2, S, 4 * phases[0].Cin, False)
+            if row["pinned"]:
+                for p in phases:
+                    p.pin_precision = 2
+            return y
+        finally:
+            self.busy = False
+
+    def pinned(self):
+        return [r for r in self.rows if r["pinned"]]
 
 
 def linear(x: torch.Tensor, p: PackedConv, *, act: Optional[int] = None, splitk: int = 1,

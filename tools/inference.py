@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--random-init", action="store_true",
                     help="do NOT load cfg.MODEL.WEIGHTS: explicit random initialisation (plumbing runs; a missing checkpoint is otherwise an error)")
     ap.add_argument("--dist-backend", default="nccl", help="torchrun only: nccl (= RCCL over xGMI) or gloo")
+    ap.add_argument("--no-precision-audit", action="store_true",
+                    help="skip the load-time audit of the default arithmetic (PlaneRCNN.audit_precision: every fp16x2 layer checked against its "
+                         "bf16x3 evaluation on the clip's first frames; layers that leave the format's window are pinned to bf16x3)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[], help="KEY VALUE config overrides, e.g. MODEL.DEVICE cuda:0")
     args = ap.parse_args()
 
@@ -148,6 +151,16 @@ def main():
 
         _x4, head = ops.preprocess_resize_u8(torch.from_numpy(np.ascontiguousarray(frames_rgb_head)).to(model.device), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), want_u8=True)
         calibrate_batchnorm(model, head.flip(-1).contiguous())  # resized RGB -> BGR uint8
+    if not args.no_precision_audit:
+        # once per loaded checkpoint, on the FIRST two frames of the clip on every rank (every rank must pin the same layers: a frame's
+        # result may not depend on the rank that detects it)
+        n_head = min(2, n_frames)
+        head_rgb = frames_rgb[:n_head] if lo == 0 and hi - lo >= n_head else read_frames(args.input, 0, n_head)
+        audit = model.audit_precision(torch.from_numpy(np.ascontiguousarray(head_rgb)).to(model.device), source_rgb=True)
+        if rank == 0:
+            worst = max((r["max_ratio"] for r in audit.rows), default=0.0)
+            print(f"precision audit: {len(audit.rows)} fp16x2 layer launches checked against bf16x3 on {n_head} frame(s), worst err / bound {worst:.3f}; "
+                  f"pinned to bf16x3: {model.pinned_layers() or 'none'}")
     preds = detect_clip(model, frames_rgb, batch=args.batch, conf_threshold=args.conf_threshold, source_rgb=True, num_frames=n_frames)
     if world > 1:
         import torch.distributed as dist
