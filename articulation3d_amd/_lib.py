@@ -116,8 +116,13 @@ class WgradDesc(C.Structure):
         ("x", fptr), ("dy", fptr), ("scale", fptr), ("dw", fptr), ("workspace", fptr),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
         ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-        ("splitk", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("io_bf16", C.c_int),
+        ("splitk", C.c_int), ("accumulate", C.c_int), ("precision", C.c_int), ("io_bf16", C.c_int), ("defer_reduce", C.c_int),
     ]
+
+
+class TransposeItem(C.Structure):
+    _fields_ = [("w", fptr), ("scale", fptr), ("wt", fptr), ("Cout", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("Cin", C.c_int),
+                ("block0", C.c_int), ("pad_", C.c_int)]
 
 
 class RoiAlignBwdDesc(C.Structure):
@@ -226,6 +231,8 @@ SIGNATURES = {
     "a3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "a3d_conv_wgrad_nhwc_f32": (C.c_int, [C.POINTER(WgradDesc), fptr]),
     "a3d_weight_transpose": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_weight_transpose_batch": (C.c_int, [fptr, C.c_int, C.c_int, fptr]),
+    "a3d_wgrad_reduce_batch": (C.c_int, [fptr, C.c_int, fptr]),
     "a3d_wino_weight_transform": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr]),
     "a3d_zero_insert2_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_sumpool2_add_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
@@ -249,7 +256,7 @@ SIGNATURES = {
 }
 
 STRUCT_IDS = {0: ConvDesc, 1: RpnDesc, 2: BoxDetDesc, 3: RoiAlignDesc, 4: PasteDesc, 5: PackDesc, 6: WgradDesc,
-              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc, 11: RoiSampleDesc, 12: SweepDesc}
+              7: RoiAlignBwdDesc, 8: MatchDesc, 9: RpnLossDesc, 10: BoxLossDesc, 11: RoiSampleDesc, 12: SweepDesc, 13: TransposeItem}
 
 _lib = None
 

@@ -127,6 +127,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const a3d_wgrad_
     }
 }
 
+// n layers in one launch: blockIdx.y = layer (a3d_wgrad_reduce_batch).  Per element the same operations as above.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_batch_kernel(const a3d_wgrad_desc *__restrict__ table) {
+    const a3d_wgrad_desc d = table[blockIdx.y];
+    const size_t row = (size_t)d.KH * d.KW * d.Cin;
+    const size_t total4 = (size_t)d.Cout * row / 4;
+    const size_t plane = (size_t)d.Cout * row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < d.splitk; ++k) s += *reinterpret_cast<const f32x4 *>(d.workspace + (size_t)k * plane + i * 4);
+        if (d.scale) s *= d.scale[(i * 4) / row];
+        f32x4 *o = reinterpret_cast<f32x4 *>(d.dw + i * 4);
+        *o = d.accumulate ? *o + s : s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16-MFMA variant (a3d_wgrad_desc.precision == 1; see conv_bf16.hip for the why).  The fragments of
 // v_mfma_f32_32x32x16_bf16 want 8 CONSECUTIVE k (= pixels) per lane, but NHWC makes channels contiguous, so the transpose
@@ -353,6 +368,7 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     const int mtiles = (d->Cout + 127) / 128, ntiles = (d->Cin + 127) / 128;
     int chunk = (P + d->splitk - 1) / d->splitk;
     chunk = (chunk + 31) / 32 * 32;  // a multiple of both kernels' k-chunk (16 / 32 pixels)
+    if (d->defer_reduce && d->accumulate) return A3D_ERR_ARG;  // (a chain into one dw is ordered by its per-launch reduces)
     if (d->io_bf16 && (d->precision != 1 || (d->io_bf16 & ~3))) return A3D_ERR_ARG;  // bf16-stored operands: the bf16 arithmetic only
     // (the bf16-stored forms load channel PAIRS as dwords: an odd channel count would drop the last channel's gradient and misalign the loads)
     if (((d->io_bf16 & 1) && (d->Cin & 1)) || ((d->io_bf16 & 2) && (d->Cout & 1))) return A3D_ERR_ARG;
@@ -371,9 +387,18 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
         else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
     } else
         hipLaunchKernelGGL(conv_wgrad_kernel, dim3(mtiles * ntiles * d->KH * d->KW, d->splitk), dim3(256), 0, s, *d, P, mtiles, ntiles, chunk);
+    if (d->defer_reduce) return a3d_check_launch();  // the caller folds the slices later (a3d_wgrad_reduce_batch)
     const size_t total4 = (size_t)d->Cout * d->KH * d->KW * d->Cin / 4;
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, *d, d->splitk);
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_wgrad_reduce_batch(const a3d_wgrad_desc *table, int n, void *stream) {
+    if (!table || n <= 0 || n > 65535) return A3D_ERR_ARG;
+    a3d_begin();
+    // 64 blocks of 256 threads per layer walk its float4s with a grid stride: 1-12 M floats per layer, slices summed per element
+    hipLaunchKernelGGL(conv_wgrad_reduce_batch_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, table);
     return a3d_check_launch();
 }

@@ -186,6 +186,7 @@ extern "C" size_t a3d_struct_size(int id) {
         case 10: return sizeof(a3d_box_loss_desc);
         case 11: return sizeof(a3d_roi_sample_desc);
         case 12: return sizeof(a3d_sweep_desc);
+        case 13: return sizeof(a3d_transpose_item);
         default: return 0;
     }
 }

@@ -45,6 +45,49 @@ extern "C" int a3d_weight_transpose(const float *w, const float *scale, float *w
     return a3d_check_launch();
 }
 
+// n filters in one launch (a3d_weight_transpose_batch): a block finds its filter by binary search over the items' first-block prefix.
+__global__ void weight_transpose_batch_kernel(const a3d_transpose_item *__restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= bid) lo = mid;
+        else hi = mid - 1;
+    }
+    const a3d_transpose_item it = table[lo];
+    const int T = it.KH * it.KW, nx = (it.Cin + 31) / 32, ny = (it.Cout + 31) / 32;
+    int r_ = bid - it.block0;
+    const int tap = r_ / (nx * ny);
+    r_ -= tap * nx * ny;
+    const int by = r_ / nx, bx = r_ - by * nx;
+    const int ci0 = bx * 32, co0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < it.Cout && ci < it.Cin) {
+            v = it.w[((size_t)co * T + tap) * it.Cin + ci];
+            if (it.scale) v *= it.scale[co];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    const int kh = tap / it.KW, kw = tap - kh * it.KW;
+    const int ftap = (it.KH - 1 - kh) * it.KW + (it.KW - 1 - kw);
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < it.Cin && co < it.Cout) it.wt[((size_t)ci * T + ftap) * it.Cout + co] = tile[tx][r];
+    }
+}
+
+extern "C" int a3d_weight_transpose_batch(const a3d_transpose_item *table, int n, int total_blocks, void *stream) {
+    if (!table || n <= 0 || total_blocks <= 0) return A3D_ERR_ARG;
+    a3d_begin();
+    hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    return a3d_check_launch();
+}
+
 // Winograd-domain weights U = G g G^T of a packed 3x3 filter [Cout][3][3][Cin] -> [16][Cout][Cin] (see conv_wino.hip).
 // Needed every step in training because the filter changes; at inference this is done once at load time.
 __global__ void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int Cout, int Cin) {

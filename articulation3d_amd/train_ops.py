@@ -18,9 +18,49 @@ def choose_wgrad_slices(P: int, tiles: int) -> int:
     return int(max(1, min(want, P // 64 if P >= 64 else 1, 256)))
 
 
+class DeferredReduces:
+    """The slice reductions of a step's weight-gradient launches, folded in ONE launch (a3d_wgrad_reduce_batch).  conv_wgrad(...,
+    defer=this) launches the partial-sum kernel only and parks its descriptor here; `flush()` uploads the table (pinned, asynchronous)
+    and reduces every parked layer.  Workspaces are persistent per layer (keyed by the dw pointer), so nothing is freed under a pending
+    reduce.  Same sums in the same order as the per-launch reduce: bit-identical gradients."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ws = {}      # dw.data_ptr() -> persistent workspace tensor
+        self.items = []   # WgradDesc copies of this step
+        self._host = None
+        self._dev = None
+
+    def workspace(self, dw: torch.Tensor, nbytes: int) -> torch.Tensor:
+        t = self.ws.get(dw.data_ptr())
+        if t is None or t.numel() * 4 < nbytes:
+            t = self.ws[dw.data_ptr()] = torch.empty(nbytes // 4, device=self.device, dtype=torch.float32)
+        return t
+
+    def flush(self):
+        n = len(self.items)
+        if not n:
+            return
+        sz = C.sizeof(_lib.WgradDesc)
+        arr = (_lib.WgradDesc * n)(*self.items)
+        for i in range(n):  # (the reduce reads neither operand: keep the table identical from step to step)
+            arr[i].x = arr[i].dy = None
+        raw = C.string_at(C.addressof(arr), n * sz)
+        if raw != self._host:
+            # workspaces, gradients and shapes are the same every step (same batch size), so the table is uploaded once; a change
+            # (first step, another batch size) drains the stream first -- a pending reduce may still be reading the old table
+            torch.cuda.current_stream().synchronize()
+            self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._host = raw
+        _lib.check(_lib.lib().a3d_wgrad_reduce_batch(self._dev.data_ptr(), n, _stream()), "a3d_wgrad_reduce_batch")
+        self.items = []
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int, pad: int,
-               scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None, precision: int = 0) -> torch.Tensor:
-    """dw [Cout, KH*KW*Cin] (=/+=) weight gradient of y = conv(x) given dy (NHWC tensors)."""
+               scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None, precision: int = 0,
+               defer: Optional[DeferredReduces] = None) -> torch.Tensor:
+    """dw [Cout, KH*KW*Cin] (=/+=) weight gradient of y = conv(x) given dy (NHWC tensors).
+    defer: park the slice reduction in a DeferredReduces (one launch for all layers at its flush()); not with accumulate."""
     # (precision 1 only: x / dy may be STORED as bf16 -- a3d_wgrad_desc.io_bf16; the kernel rounds them to bf16 anyway)
     _req(x, x.dtype if (precision == 1 and x.dtype == torch.bfloat16) else torch.float32)
     _req(dy, dy.dtype if (precision == 1 and dy.dtype == torch.bfloat16) else torch.float32)
@@ -37,10 +77,56 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     d.accumulate = int(accumulate)
     d.precision = int(precision)
     d.io_bf16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if dy.dtype == torch.bfloat16 else 0)
-    ws = torch.empty(_lib.lib().a3d_wgrad_workspace_bytes(C.byref(d)) // 4, device=x.device, dtype=torch.float32)
+    nbytes = _lib.lib().a3d_wgrad_workspace_bytes(C.byref(d))
+    if defer is not None and not accumulate:
+        ws = defer.workspace(dw, nbytes)
+        d.defer_reduce = 1
+    else:
+        defer = None
+        ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     d.workspace = ws.data_ptr()
+    if defer is not None:
+        keep = _lib.WgradDesc()
+        C.memmove(C.addressof(keep), C.addressof(d), C.sizeof(_lib.WgradDesc))
+        defer.items.append(keep)
+    from . import ops as _ops
+
+    if _ops.CONV_TIMING is not None:  # tools/train_bench.py's roofline leg: HIP events around the launch, same record as ops.conv2d's
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().a3d_conv_wgrad_nhwc_f32(C.byref(d), _stream()), "a3d_conv_wgrad_nhwc_f32")
+        e1.record()
+        fl = 2.0 * B * Ho * Wo * Cout * KH * KW * Cin  # the pixel-reduction GEMM dY^T . X per tap = the layer's forward FLOPs
+        label = {0: "conv_wgrad_kernel", 1: f"conv_wgrad_bf16_kernel<false, {d.io_bf16}>", 2: "conv_wgrad_bf16_kernel<true, 0>"}[int(precision)]
+        _ops.CONV_TIMING.append((label, fl, e0, e1, f"{B}x{H}x{W}x{Cin}->{Cout} k{KH} s{stride} wgrad sk{d.splitk}", fl,
+                                 {0: "f32", 1: "bf16", 2: "bf16x6"}[int(precision)], _stream()))
+        return dw
     _lib.check(_lib.lib().a3d_conv_wgrad_nhwc_f32(C.byref(d), _stream()), "a3d_conv_wgrad_nhwc_f32")
     return dw
+
+
+class TransposeBatch:
+    """The data-gradient filters of every trainable layer in ONE launch (a3d_weight_transpose_batch).  The table is built once:
+    parameters, scales and scratch filters are views of the trainer's flat buffers, whose addresses do not change."""
+
+    def __init__(self, entries, device):
+        # entries: (w, scale or None, wt, Cout, KH, KW, Cin)
+        n = len(entries)
+        arr = (_lib.TransposeItem * n)()
+        blk = 0
+        for i, (w, sc, wt, Cout, KH, KW, Cin) in enumerate(entries):
+            assert _req(w).numel() == Cout * KH * KW * Cin == _req(wt).numel()
+            arr[i].w, arr[i].scale, arr[i].wt = w.data_ptr(), _p(sc), wt.data_ptr()
+            arr[i].Cout, arr[i].KH, arr[i].KW, arr[i].Cin, arr[i].block0 = Cout, KH, KW, Cin, blk
+            blk += ((Cin + 31) // 32) * ((Cout + 31) // 32) * KH * KW
+        self.n, self.blocks = n, blk
+        self.keep = [t for e in entries for t in e[:3] if t is not None]
+        host = torch.empty(n * C.sizeof(_lib.TransposeItem), dtype=torch.uint8)
+        C.memmove(host.data_ptr(), C.addressof(arr), host.numel())
+        self.table = host.to(device)
+
+    def run(self):
+        _lib.check(_lib.lib().a3d_weight_transpose_batch(self.table.data_ptr(), self.n, self.blocks, _stream()), "a3d_weight_transpose_batch")
 
 
 def weight_transpose(w: torch.Tensor, out: torch.Tensor, Cout: int, KH: int, KW: int, Cin: int,

@@ -26,6 +26,7 @@ a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16; `storage="fp32"` keeps them fp32
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -36,6 +37,9 @@ from .parallel import allreduce_gradients
 from .ops import ACT_NONE, ACT_RELU, PackedConv
 
 FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
+# One launch for all data-gradient filters and one for all weight-gradient slice reductions of a step instead of one per layer (round 4;
+# "0": the per-layer launches -- the same bits either way, tests/test_gpu_training.py).
+BATCHED_LAUNCHES = os.environ.get("A3D_TRAIN_BATCHED", "1") != "0"
 RES_STAGES = (("res3", 4, 128, 512), ("res4", 6, 256, 1024), ("res5", 3, 512, 2048))  # name, blocks, mid, out
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
 
@@ -295,8 +299,13 @@ class DetectorTrainer:
 
     def _prepare_filters(self):
         """Per step: data-gradient filters (and the Winograd images of the 3x3 filters) of the CURRENT weights."""
+        if BATCHED_LAUNCHES:  # every layer's data-gradient filter in one launch (50 launches of ~6 us each otherwise)
+            if getattr(self, "_tbatch", None) is None:
+                self._tbatch = T.TransposeBatch([(ly.w, ly.scale, ly.wt, ly.rows, ly.k, ly.k, ly.cin) for ly in self.layers.values()], self.dev)
+            self._tbatch.run()
         for ly in self.layers.values():
-            T.weight_transpose(ly.w, ly.wt, ly.rows, ly.k, ly.k, ly.cin, scale=ly.scale)
+            if not BATCHED_LAUNCHES:
+                T.weight_transpose(ly.w, ly.wt, ly.rows, ly.k, ly.k, ly.cin, scale=ly.scale)
             if ly.k == 3 and self.prec != 1:  # (the bf16 step runs its 3x3 layers as direct convolutions)
                 T.wino_weight_transform(ly.w, ly.U, ly.rows, ly.cin)
                 T.wino_weight_transform(ly.wt, ly.Ut, ly.cin, ly.rows)
@@ -317,7 +326,14 @@ class DetectorTrainer:
         return ops.conv2d(x, pk, precision=self.prec, **kw)
 
     def _wgrad(self, ly: _Layer, x, dy, accumulate=False):
-        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate, precision=self.wgrad_prec)
+        # The slice reductions of the step's weight gradients are folded in ONE launch at the end of the backward pass (self._defer.flush()
+        # in forward_backward): 63 reduce launches of ~17 us each were 11 % of the step at the reference's 2 images per GPU.  Layers whose
+        # gradient accumulates over several launches (the RPN head over its five levels) keep the per-launch reduce, which orders them.
+        shared = ly.name.startswith("proposal_generator.")
+        if BATCHED_LAUNCHES and getattr(self, "_defer", None) is None:
+            self._defer = T.DeferredReduces(self.dev)
+        T.conv_wgrad(x, dy, ly.dw, KH=ly.k, KW=ly.k, stride=ly.stride, pad=ly.pad, scale=ly.scale, accumulate=accumulate, precision=self.wgrad_prec,
+                     defer=self._defer if (BATCHED_LAUNCHES and not shared and not accumulate) else None)
         if ly.db is not None:
             T.colsum(dy, ly.db, accumulate=accumulate)
 
@@ -477,6 +493,8 @@ class DetectorTrainer:
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
                     g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
+        if getattr(self, "_defer", None) is not None:
+            self._defer.flush()  # every parked weight gradient: one reduce launch
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))

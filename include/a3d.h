@@ -34,7 +34,8 @@ extern "C" {
 int a3d_version(void);
 /* sizeof() of a descriptor struct, for bindings to verify their mirror of the layout.  id: 0 a3d_conv_desc, 1 a3d_rpn_desc,
  * 2 a3d_boxdet_desc, 3 a3d_roialign_desc, 4 a3d_paste_desc, 5 a3d_pack_desc, 6 a3d_wgrad_desc, 7 a3d_roialign_bwd_desc,
- * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc, 11 a3d_roi_sample_desc, 12 a3d_sweep_desc; 0 for an unknown id. */
+ * 8 a3d_match_desc, 9 a3d_rpn_loss_desc, 10 a3d_box_loss_desc, 11 a3d_roi_sample_desc, 12 a3d_sweep_desc, 13 a3d_transpose_item; 0 for an
+ * unknown id. */
 size_t a3d_struct_size(int id);
 
 /* ------------------------------------------------------------------------------------------------
@@ -86,7 +87,7 @@ typedef struct a3d_conv_desc {
     int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch            */
     const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
                          so ragged per-ROI batches need no host synchronisation                      */
-    int tune;         /* 0 = library picks the kernel variant; 1 = force the general (v1) kernel;
+    int tune;         /* 0 = library picks the kernel variant; 1 = (the round-1 general kernel: removed in round 4, A3D_ERR_UNSUPPORTED);
                          2 = direct implicit GEMM even when w_wino is given; 5 / 6 = never / always use the persistent
                          pointwise kernel on eligible 1x1 layers; 7 = two-launch Winograd where the one-launch kernel would
                          run; precision 2: 8 = the narrow split-operand kernels (64-wide Winograd GEMM, 128 x 128 direct),
@@ -408,12 +409,30 @@ typedef struct a3d_wgrad_desc {
     int accumulate;     /* 1: dw += (weights shared by several call sites, e.g. the RPN head over 5 levels) */
     int precision;      /* 0: fp32 MFMA; 1: bf16 MFMA, fp32 accumulation; 2: fp32-grade 3-way bf16 split (see a3d_conv_desc.precision) */
     int io_bf16;        /* precision 1 only: bit 0: x is stored as bf16, bit 1: dy is stored as bf16 (dw stays fp32)              */
+    int defer_reduce;   /* 1: launch the partial-sum kernel only; the caller keeps `workspace` alive and folds the slices of MANY layers
+                           in one launch later (a3d_wgrad_reduce_batch).  Same sums in the same order: bit-identical dw.  Not with
+                           accumulate (a chain of launches into one dw is ordered by its reduces).                                  */
 } a3d_wgrad_desc;
 size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
 int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);
+/* The slice reduction of n deferred weight-gradient launches in ONE launch (round 4: at the reference's 2 images per GPU the 63 per-layer
+ * reduce launches of a training step were 17 us of latency each, 11 % of the step).  table: DEVICE array of n a3d_wgrad_desc whose
+ * workspace / scale / dw / Cout / KH / KW / Cin / splitk fields are read (x, dy are not).  Every layer: dw = scale * sum over slices
+ * in slice order -- the arithmetic of the per-launch reduce.  tools/train_net.py:84-104 (the backward of DDP's step). */
+int a3d_wgrad_reduce_batch(const a3d_wgrad_desc *table, int n, void *stream);
 
 /* wt[ci][KH-1-kh][KW-1-kw][co] = scale[co] * w[co][kh][kw][ci]: the filter of the data gradient. */
 int a3d_weight_transpose(const float *w, const float *scale, float *wt, int Cout, int KH, int KW, int Cin, void *stream);
+/* The same for n filters in ONE launch: table = DEVICE array of n items.  The data-gradient filters of every trainable layer are
+ * re-derived each step: 50 launches of ~6 us each at 2 images per GPU. */
+typedef struct a3d_transpose_item {
+    const float *w, *scale;
+    float *wt;
+    int Cout, KH, KW, Cin;
+    int block0; /* first 32 x 32 x tap block of this filter in the launch's flat block index (exclusive prefix sum, filled by the caller) */
+    int pad_;
+} a3d_transpose_item;
+int a3d_weight_transpose_batch(const a3d_transpose_item *table, int n, int total_blocks, void *stream);
 /* U = G g G^T of a packed 3x3 filter [Cout][3][3][Cin] -> [16][Cout][Cin] (a3d_conv_desc.w_wino), on the device. */
 int a3d_wino_weight_transform(const float *w, float *U, int Cout, int Cin, void *stream);
 

@@ -1207,3 +1207,22 @@ def test_detect_clip_matches_reference_style_loop(hip_model, oracle):
         assert torch.equal(p.pred_masks, ref.pred_masks)  # re-pasted on the receiving side == pasted by the sender
     planes = track_planes(preds)  # runs on the rebuilt records (5 frames: every track is filtered as too short)
     assert planes == {"rot": [], "trans": []}
+
+
+def test_seeded_fuzz_of_every_fp32_grade_kernel(ops):
+    """tools/fuzz_kernels.py with a fixed seed and a 45 s budget: random layers of every kind the detector uses, in all three fp32-grade
+    arithmetics, each against a float64 convolution, and every kernel form that claims the dispatcher's bits held to them.  The
+    dispatcher's own log must show the kernel families of all three modes (the coverage statement of the run)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("a3d_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_kernels.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    out = fuzz.run(seed=20260104, budget_s=45.0, verbose=False)
+    assert out["cases"] >= 20, out["cases"]
+    assert not out["failures"], out["failures"][:5]
+    fam = {v.split("<")[0].split(" ")[0] for v in out["variants"]}
+    want = {"conv_h2_kernel", "conv_h2w_kernel", "conv_h2xs_kernel", "wino_gemm_h2w_kernel",  # fp16x2
+            "conv_x3_kernel", "wino_gemm_x3w_kernel",                                          # bf16x3
+            "conv_gemm_v2_kernel", "conv_pw_kernel", "wino_fused_kernel", "wino_gemm_kernel"}  # fp32-input MFMA
+    assert want <= fam, (want - fam, sorted(fam))

@@ -733,3 +733,45 @@ def test_bf16_step_stores_its_resnet_activations_and_gradients_as_bf16(hip_model
     assert all(bool(torch.isfinite(v).all()) for v in gbf.values())
     for k in gf:
         assert 0.5 < float(gbf[k].norm() / (gf[k].norm() + 1e-30)) < 2.0, k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_batched_launches_give_the_per_layer_launches_bits(hip_model, oracle, precision):
+    """Round 4: ONE launch for the data-gradient filters of all layers (a3d_weight_transpose_batch) and ONE for the slice reductions of
+    the step's weight gradients (a3d_wgrad_reduce_batch) instead of one per layer.  Same sums in the same order: on the same batch and
+    sampled sets the box-head gradients -- downstream of nothing non-deterministic -- agree BIT FOR BIT, every other gradient within the
+    per-layer form's OWN run-to-run spread (the ROIAlign backward's float atomics), and the transposed filters are identical."""
+    from articulation3d_amd import training
+    from articulation3d_amd.training import DetectorTrainer
+    from oracle import train_oracle as TO
+
+    frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
+    tg = TO.synthetic_targets(2)
+    gb, gc = [t[0] for t in tg], [t[1] for t in tg]
+    saved = training.BATCHED_LAUNCHES
+    try:
+        training.BATCHED_LAUNCHES = False
+        t0 = DetectorTrainer(hip_model, seed=5, precision=precision)
+        l0, aux = t0.forward_backward(frames, gb, gc)
+        rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
+        samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=[ri[i, : int(rc[i])].long() for i in range(2)])
+        g0 = {k: v.clone() for k, v in t0.export_grads().items()}
+        wt0 = t0._wt.clone()
+        t0.forward_backward(frames, gb, gc, samples=samples)  # the per-layer form once more: its own run-to-run spread (float atomics)
+        spread = {k: l2rel(v, g0[k]) for k, v in t0.export_grads().items()}
+        training.BATCHED_LAUNCHES = True
+        t1 = DetectorTrainer(hip_model, seed=5, precision=precision)
+        for _ in range(2):  # (twice: the second step reuses the cached device tables and the persistent workspaces)
+            l1, _ = t1.forward_backward(frames, gb, gc, samples=samples)
+        g1 = t1.export_grads()
+        assert t1._defer is not None and t1._tbatch is not None and not t1._defer.items
+    finally:
+        training.BATCHED_LAUNCHES = saved
+    assert torch.equal(t1._wt, wt0)
+    for k in l0:
+        assert float(l0[k]) == float(l1[k]), k
+    for k in g0:
+        if k.startswith("roi_heads."):
+            assert torch.equal(g0[k], g1[k]), k
+        else:  # (bf16 rounds activations and gradients: an atomics-order difference of 1e-7 upstream flips roundings downstream)
+            assert l2rel(g1[k], g0[k]) <= 4.0 * max(spread.values()) + 1e-6, (k, l2rel(g1[k], g0[k]), spread[k], max(spread.values()))

@@ -1,11 +1,21 @@
-"""Random-shape fuzz of the round-3 kernels (seeded; a developer tool, the fixed cases live in tests/):
-  * conv_h2xs_kernel (tune 13) against the tiled kernels (tune 14): outputs and recorded maxima bit for bit;
-  * the fp16x2 Winograd pair (pre-split transform + DMA-ring GEMM) against a float64 convolution: error at the level of the
-    direct fp16x2 kernel on the same layer.
-    python tools/fuzz_kernels.py [cases] [seed]"""
+"""Seeded random-shape fuzz of EVERY conv / linear kernel the three fp32-grade arithmetics dispatch.
+
+For each random layer (1x1 / 3x3 / strided / linear / transposed 2x2 / upsampled 3x3 with and without a second source / stem), in each
+of the modes fp16x2 (3), bf16x3 (2) and fp32-input MFMA (0):
+  * the dispatcher's choice against a float64 convolution of the same operands (first and last image), relative to the image's
+    output scale -- the fp32-grade bar of tests/test_gpu_parity.py;
+  * every FORM that claims the dispatcher's bits must deliver them: narrow 128 x 64 / 128 x 128 tiles (tune 10 / 11), the wide 256 x 256
+    kernel (tune 9), per-lane instead of row-major epilogue (tune 12), the activation-stationary pointwise kernel on / off (tune 13 / 14),
+    pre-split activations through the dual-DMA kernel, Winograd one-launch / plane-split, the bf16x3 narrow Winograd GEMM (tune 8), the
+    fp32 one-launch against the two-launch Winograd (tune 7), the persistent pointwise kernel on / off (tune 6 / 5), fused against
+    four-launch upsampled convs.  A form the launcher refuses for the shape (A3D_ERR_UNSUPPORTED) is skipped, not failed.
+The set of kernel variants the dispatcher reported is returned (and printed): the coverage statement of the run.
+
+    python tools/fuzz_kernels.py [budget_seconds] [seed]        (tests/test_gpu_parity.py runs it with a fixed seed and a 45 s budget)"""
 import os
 import random
 import sys
+import time
 
 import torch
 import torch.nn.functional as F
@@ -13,42 +23,189 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd import ops  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # larger maps / batches: the non-plane-split GEMMs, the N-split tail of conv_h2xs
-bad = 0
-for case in range(n):
-    torch.manual_seed(case)
-    B, H, W = (rng.randint(8, 48), rng.randint(40, 130), rng.randint(40, 170)) if BIG else (rng.randint(1, 9), rng.randint(1, 70), rng.randint(1, 90))
-    Cin, Cout = rng.choice([64, 128, 256]), rng.choice([128, 256, 384, 512, 1024])
-    with_res, act = rng.random() < 0.6, rng.choice([ops.ACT_RELU, ops.ACT_NONE])
-    x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-2, 2, B, device="cuda")[:, None, None, None]
-    res = torch.randn(B, H, W, Cout, device="cuda") if with_res else None
-    pk = ops.pack_conv(torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5, torch.randn(Cout) * 0.1, None, 1, 0, act)
-    a = ops.conv2d(x, pk, res=res, precision=3, tune=13)
-    va = ops.last_conv_variant()
-    b = ops.conv2d(x, pk, res=res, precision=3, tune=14)
-    ok = va.startswith("conv_h2xs") and torch.equal(a, b) and torch.equal(ops.amax_of(a), ops.amax_of(b))
-    bad += not ok
-    print(f"xs   {B}x{H}x{W}x{Cin}->{Cout} res={int(with_res)} act={act}: [{va}] {'ok' if ok else 'MISMATCH'}", flush=True)
-for case in range(n):
-    torch.manual_seed(1000 + case)
-    B, H, W = (rng.randint(4, 24), rng.randint(20, 90), rng.randint(20, 120)) if BIG else (rng.randint(1, 6), rng.randint(2, 50), rng.randint(2, 60))
-    Cin, Cout = rng.choice([32, 64, 128, 256]), rng.choice([128, 256, 512])
-    x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
-    w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
-    bias = torch.randn(Cout) * 0.1
-    pk = ops.pack_conv(w, bias, None, 1, 1, ops.ACT_RELU)
-    yw = ops.conv2d(x, pk, precision=3, wino=True)
-    vw = ops.last_conv_variant()
-    yd = ops.conv2d(x, pk, precision=3, wino=False)
-    bs = sorted({0, B - 1})  # (float64 reference on the first and last image: the CPU side of the check)
-    ref = torch.relu(F.conv2d(x[bs].double().permute(0, 3, 1, 2).cpu(), w.double(), bias.double(), padding=1)).permute(0, 2, 3, 1)
-    scale = ref.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
-    ew = float(((yw[bs].double().cpu() - ref).abs() / scale).max())
-    ed = float(((yd[bs].double().cpu() - ref).abs() / scale).max())
-    ok = "wino" in vw and ew < max(4 * ed, 3e-6) and bool(torch.isfinite(yw).all())
-    bad += not ok
-    print(f"wino {B}x{H}x{W}x{Cin}->{Cout}: [{vw}] err {ew:.1e} (direct {ed:.1e}) {'ok' if ok else 'BAD'}", flush=True)
-print("FAILURES:", bad)
-sys.exit(1 if bad else 0)
+MODES = {3: "fp16x2", 2: "bf16x3", 0: "fp32"}
+TOL = 5e-6  # max |y - y64| over an image / max |y64| of that image (tests/test_gpu_parity.py's bar for one fp32-grade layer)
+
+
+def _try(fn):
+    try:
+        return fn(), None
+    except RuntimeError as e:  # a form the launcher does not offer for this shape
+        if "UNSUPPORTED" in str(e) or "A3D_ERR_ARG" in str(e):
+            return None, str(e)
+        raise
+
+
+def _ref_check(y, ref, imgs):
+    got = y[imgs].double().cpu()
+    scale = ref.abs().flatten(1).amax(1).clamp_min(1e-30).view(-1, *([1] * (ref.dim() - 1)))
+    return float(((got - ref).abs() / scale).max())
+
+
+def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: int = 10 ** 6):
+    rng = random.Random(seed)
+    t_end = time.time() + budget_s
+    seen, fails, cases = set(), [], 0
+    saved_mode, saved_ps = ops.DEFAULT_PRECISION, ops.WINO_PLANE_SPLIT
+
+    def note():
+        v = ops.last_conv_variant()
+        seen.add(v)
+        return v
+
+    def launch(mode, x, pk, **kw):
+        ops.DEFAULT_PRECISION = mode
+        y = ops.conv2d(x, pk, **kw)
+        return y, note()
+
+    try:
+        while time.time() < t_end and cases < max_cases:
+            cases += 1
+            torch.manual_seed(seed * 100003 + cases)
+            kind = rng.choice(["1x1", "1x1", "3x3", "3x3", "3x3s2", "linear", "deconv", "ups", "ups2", "stem"])
+            B = rng.randint(1, 5)
+            H, W = rng.randint(3, 44), rng.randint(3, 52)
+            act = rng.choice([ops.ACT_RELU, ops.ACT_NONE, ops.ACT_LEAKY])
+            spread = torch.logspace(-2, 2, B, device="cuda").view(B, 1, 1, 1)
+            x2 = None
+            kw = {}
+            desc = kind
+            if kind in ("1x1", "3x3", "3x3s2"):
+                k = 1 if kind == "1x1" else 3
+                st = 2 if kind == "3x3s2" or (kind == "1x1" and rng.random() < 0.25) else 1
+                Cin = rng.choice([32, 64, 128, 256, 512] if k == 3 else [32, 64, 128, 256, 512, 1024, 2048])
+                Cout = rng.choice([16, 36, 64, 128, 256, 512] if k == 3 else [12, 16, 64, 128, 256, 512, 1024])
+                w = torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5)
+                bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5, 1e-5) if rng.random() < 0.5 else None
+                bias = None if bn is not None else torch.randn(Cout) * 0.1
+                pk = ops.pack_conv(w, bias, bn, st, k // 2, act)
+                x = torch.randn(B, H, W, Cin, device="cuda") * spread
+                Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+                with_res = rng.random() < 0.4
+                if with_res:
+                    kw["res"] = torch.randn(B, Ho, Wo, pk.cols, device="cuda")
+
+                def ref_fn(imgs, w=w, bias=bias, bn=bn, st=st, k=k, kw=kw, act=act):
+                    r = F.conv2d(x[imgs].double().permute(0, 3, 1, 2).cpu(), w.double(), None if bias is None else bias.double(), stride=st, padding=k // 2)
+                    if bn is not None:
+                        sc = bn[0].double() / torch.sqrt(bn[3].double() + bn[4])
+                        r = r * sc.view(1, -1, 1, 1) + (bn[1].double() - bn[2].double() * sc).view(1, -1, 1, 1)
+                    r = r.permute(0, 2, 3, 1)
+                    if "res" in kw:
+                        r = r + kw["res"][imgs][..., : r.shape[-1]].double().cpu()
+                    return r
+                desc = f"{kind} {B}x{H}x{W}x{Cin}->{Cout} s{st} res={int(with_res)} bn={int(bn is not None)}"
+            elif kind == "linear":
+                M, K, N = rng.randint(1, 700), rng.choice([256, 1024, 4096]), rng.choice([12, 256, 1024])
+                w = torch.randn(N, K) / K ** 0.5
+                bias = torch.randn(N) * 0.1
+                pk = ops.pack_linear(w, bias, act=act)
+                x = (torch.randn(M, K, device="cuda") * torch.logspace(-2, 2, M, device="cuda").view(M, 1)).view(M, 1, 1, K)
+                B = M
+                ref_fn = lambda imgs, w=w, bias=bias: (x[imgs].double().cpu().view(len(imgs), -1) @ w.double().t() + bias.double()).view(len(imgs), 1, 1, -1)
+                desc = f"linear {M}x{K}->{N}"
+            elif kind == "deconv":
+                Cin, Cout = rng.choice([64, 256]), rng.choice([64, 256])
+                w = torch.randn(Cin, Cout, 2, 2) / Cin ** 0.5
+                bias = torch.randn(Cout) * 0.1
+                pk = ops.pack_deconv2x2(w, bias, act)
+                x = torch.randn(B, H, W, Cin, device="cuda") * spread
+                ref_fn = lambda imgs, w=w, bias=bias: F.conv_transpose2d(x[imgs].double().permute(0, 3, 1, 2).cpu(), w.double(), bias.double(), stride=2).permute(0, 2, 3, 1)
+                desc = f"deconv2x2 {B}x{H}x{W}x{Cin}->{Cout}"
+            elif kind in ("ups", "ups2"):
+                C1, Cout = rng.choice([64, 128]), rng.choice([64, 128])
+                C2 = C1 if kind == "ups2" else 0
+                w = torch.randn(Cout, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5)
+                bias = torch.randn(Cout) * 0.1
+                phases = ops.pack_conv_ups_phases(w, bias, None, act)
+                x = torch.randn(B, H, W, C1, device="cuda") * spread
+                x2 = torch.randn(B, H, W, C2, device="cuda") * spread if C2 else None
+
+                def ref_fn(imgs, w=w, bias=bias, x2=x2):
+                    xi = x[imgs] if x2 is None else torch.cat([x[imgs], x2[imgs]], -1)
+                    up = F.interpolate(xi.double().permute(0, 3, 1, 2).cpu(), scale_factor=2, mode="nearest")
+                    return F.conv2d(up, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+                desc = f"ups3x3 {B}x{H}x{W}x({C1}+{C2})->{Cout}"
+            else:  # stem: 7x7 s2 p3 on the NHWC4 frame tensor
+                Hs, Ws = 2 * rng.randint(8, 40), 2 * rng.randint(8, 40)
+                w = torch.randn(64, 3, 7, 7) / 12.0
+                bn = (torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(64) * 0.1, torch.rand(64) + 0.5, 1e-5)
+                pk = ops.pack_stem(w, bn)
+                x = torch.zeros(B, Hs, Ws, 4, device="cuda")
+                x[..., :3] = torch.randn(B, Hs, Ws, 3, device="cuda") * 60
+                act = ops.ACT_RELU
+
+                def ref_fn(imgs, w=w, bn=bn):
+                    r = F.conv2d(x[imgs][..., :3].double().permute(0, 3, 1, 2).cpu(), w.double(), None, stride=2, padding=3)
+                    sc = bn[0].double() / torch.sqrt(bn[3].double() + bn[4])
+                    return (r * sc.view(1, -1, 1, 1) + (bn[1].double() - bn[2].double() * sc).view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+                desc = f"stem {B}x{Hs}x{Ws}"
+            imgs = sorted({0, B - 1})
+            ref = ref_fn(imgs)
+            if act == ops.ACT_RELU:
+                ref = torch.relu(ref)
+            elif act == ops.ACT_LEAKY:
+                ref = F.leaky_relu(ref, 0.01)
+            n = ref.shape[-1]
+            for mode in (3, 2, 0):
+                problems = []
+                if kind in ("ups", "ups2"):
+                    ops.DEFAULT_PRECISION = mode
+                    y = ops.conv2d_ups(x, phases, x2=x2)
+                    v0 = note()
+                    forms = [("four launches", lambda: ops.conv2d_ups(x, phases, x2=x2, fused=False))]
+                else:
+                    y, v0 = launch(mode, x, pk, **kw)
+                    forms = []
+                    plain = kind in ("1x1", "3x3", "3x3s2", "linear")
+                    # (an explicit tile variant goes with an explicit arithmetic: the mode rules only pick 2 / 3 for tune 0)
+                    own = (mode == 3 and v0.startswith("conv_h2")) or (mode == 2 and v0.startswith("conv_x3"))
+                    if own and plain:
+                        forms += [(f"tune {t}", lambda t=t: launch(mode, x, pk, tune=t, precision=mode, **kw)[0]) for t in (9, 10, 11, 12)]
+                    if own and mode == 3 and kind == "1x1":
+                        forms += [(f"tune {t}", lambda t=t: launch(3, x, pk, tune=t, precision=3, **kw)[0]) for t in (13, 14)]
+                    if own and mode == 3 and plain and x.shape[-1] % 16 == 0:
+                        forms.append(("pre-split activations", lambda: launch(3, ops.presplit_f16x2(x), pk, **kw)[0]))
+                    if mode == 3 and v0.startswith("wino"):
+                        def other_ps():
+                            ops.WINO_PLANE_SPLIT = not saved_ps
+                            try:
+                                return launch(3, x, pk, **kw)[0]
+                            finally:
+                                ops.WINO_PLANE_SPLIT = saved_ps
+                        forms.append(("plane-split toggled", other_ps))
+                    if mode == 2 and v0.startswith("wino"):
+                        forms.append(("tune 8", lambda: launch(2, x, pk, tune=8, **kw)[0]))
+                    if mode == 0 and v0.startswith("wino"):
+                        forms.append(("tune 7", lambda: launch(0, x, pk, tune=7, **kw)[0]))
+                    if mode == 0 and kind in ("1x1", "linear"):
+                        forms += [(f"tune {t}", lambda t=t: launch(0, x, pk, tune=t, **kw)[0]) for t in (5, 6)]
+                torch.cuda.synchronize()
+                err = _ref_check(y[..., :n], ref, imgs)
+                if not (err < TOL) or not bool(torch.isfinite(y).all()):
+                    problems.append(f"error {err:.2e} vs float64")
+                for name, fn in forms:
+                    alt, why = _try(fn)
+                    note()
+                    if alt is None:
+                        continue
+                    if not torch.equal(alt, y):
+                        problems.append(f"{name}: bits differ from the dispatcher's ({float((alt - y).abs().max()):.2e})")
+                if verbose:
+                    print(f"[{MODES[mode]:6s}] {desc}: {v0}  err {err:.1e}  {'ok' if not problems else 'FAIL ' + '; '.join(problems)}", flush=True)
+                if problems:
+                    fails.append((MODES[mode], desc, v0, problems))
+    finally:
+        ops.DEFAULT_PRECISION, ops.WINO_PLANE_SPLIT = saved_mode, saved_ps
+    return dict(cases=cases, failures=fails, variants=sorted(seen))
+
+
+if __name__ == "__main__":
+    out = run(seed=int(sys.argv[2]) if len(sys.argv) > 2 else 7, budget_s=float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    print(f"\n{out['cases']} random layers x 3 arithmetics; kernel variants the dispatcher reported ({len(out['variants'])}):")
+    for v in out["variants"]:
+        print("  ", v)
+    print("FAILURES:", len(out["failures"]))
+    for f in out["failures"]:
+        print("  ", f)
+    sys.exit(1 if out["failures"] else 0)

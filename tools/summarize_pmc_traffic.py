@@ -56,9 +56,10 @@ def main():
     timed = {k: v for k, v in timed.items() if v}
     grand = sum(sum(x[1] for x in v) for v in timed.values())
     fetch, write = per_kernel_counter(fetch_dir, "FETCH_SIZE"), per_kernel_counter(write_dir, "WRITE_SIZE")
-    B = bench["config"]["frames_per_step_per_gpu"]
-    R = bench["config"]["proposals_per_frame"]
-    D = bench["config"]["raw_detections_per_frame"]
+    cfg = bench["config"]  # (bench.py's line, or tools/train_bench.py's: images_per_gpu instead of frames_per_step_per_gpu)
+    B = cfg.get("frames_per_step_per_gpu", cfg.get("images_per_gpu", 1))
+    R = cfg.get("proposals_per_frame", 1000)
+    D = cfg.get("raw_detections_per_frame", 0)
     # closed-form algorithmic bytes per launch where the bench configuration fixes them
     algo = {
         "roi_align_fpn_kernel": {"note": "largest launch = the 7x7 box pooler: every live proposal writes 49 bins x 256 channels x 4 B and reads its "
@@ -85,15 +86,15 @@ def main():
         if algo_of(k):
             e["algorithmic"] = algo_of(k)
         res[k] = e
-    ra = res.get("roi_align_fpn_kernel")
-    if ra:
+    ra = next((v for k, v in res.items() if k == "roi_align_fpn_kernel" or k.startswith("roi_align_fpn_kernel<")), None)
+    if ra and "algorithmic" in ra:
         # the box pooler is the first and by far largest of the step's three launches: weigh the per-launch averages back to it
         tot_f = ra["fetch_bytes_per_launch"] * ra["launches_per_step"]
         tot_w = ra["write_bytes_per_launch"] * ra["launches_per_step"]
         a = ra["algorithmic"]
         ra["per_step_fetch_bytes"], ra["per_step_write_bytes"] = round(tot_f), round(tot_w)
         ra["over_fetch_vs_distinct_cells"] = round(tot_f / a["read_bytes_upper_bound_box_pooler"], 2)
-    doc = {"command": "python3 bench.py --steps %d --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points" % steps,
+    doc = {"command": sys.argv[7] if len(sys.argv) > 7 else "python3 bench.py --steps %d --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points" % steps,
            "source": "rocprofv3 --kernel-trace (durations), --pmc FETCH_SIZE, --pmc WRITE_SIZE: three separate passes; FETCH_SIZE x2 "
                      "(gfx950 wide-read correction), KiB -> bytes; Infinity-Cache hits are counted as traffic",
            "bench_value": bench["value"], "ms_per_step": bench["ms_per_step"], "kernels": res}

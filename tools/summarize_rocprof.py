@@ -19,6 +19,7 @@ from collections import defaultdict
 
 def main():
     d, bench_json, steps, warmup, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    command = sys.argv[6] if len(sys.argv) > 6 else (f"python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes --no-operating-points")
     stats = max(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     trace = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
@@ -29,7 +30,7 @@ def main():
     marks = sorted(t for t, _ in per[[k for k in per if k.startswith("preprocess_u8_kernel")][0]])
     t_begin = marks[-steps]
     lines = ["# rocprofv3 kernel summary", "",
-             f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes --no-operating-points`", "",
+             f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- {command}`", "",
              f"bench line of the profiled run: value={bench['value']} {bench['unit']}, ms_per_step={bench['ms_per_step']}, "
              f"roofline={json.dumps({k: bench['roofline'][k] for k in ('kernel', 'achieved', 'peak', 'frac', 'launches', 'avg_launch_ms')})}", "",
              "## timed region only (last %d steps), per kernel" % steps, "",
