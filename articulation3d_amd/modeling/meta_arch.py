@@ -116,6 +116,48 @@ class PlaneRCNN(nn.Module):
         with ops.share_wino_input(share):
             return self._detect_on_features(feats, frames, B, hw, want_masks, given_boxes)
 
+    # ------------------------------------------------------------------ the small-batch pass as a HIP graph (round 4)
+    @torch.no_grad()
+    def inference_graphed(self, frames: torch.Tensor, want_masks: bool = False) -> BatchedOutput:
+        """`inference_batched(frames)` replayed from a captured HIP graph: for the per-frame loop of the reference
+        (tools/inference.py:215-228 -> arti_vis.py:54-61), whose ~210 launches per frame the host issues one by one.  The first call per
+        (shape, dtype, want_masks) warms up eagerly and captures ONE pass -- side-stream branches included -- into a graph with its own
+        memory pool and its own zero-filled maxima slots; later calls copy the frame into the static input and replay.  Needs a pass
+        without host reads: the ROI heads run in `fixed_rows` mode (roi_heads.py: head tensors sized for every detection slot).  The returned BatchedOutput's tensors live in the graph's pool: they are overwritten by the next call.  Same kernels, same
+        bits as the eager pass (tests/test_gpu_bench.py).
+        MEASURED AND NOT THE DEFAULT (round 4, tools/loop_bench.py): one frame 4.42 ms eager | 5.37 ms replayed, two frames 5.01 | 6.82 --
+        the replay issues nothing from the host, but it pays the fixed-size head rows (5.43 ms eager in that mode) and gains nothing on
+        top: the pass is bound by the latency of ~210 dependent small kernels on the GPU, not by their launches."""
+        assert not self.training and frames.is_cuda
+        rh = self.roi_heads
+        B = frames.shape[0]
+        R = rh.box_predictor.test_topk_per_image
+        if B * R > rh.FIXED_ROWS_CAP:
+            return self.inference_batched(frames, want_masks=want_masks)
+        key = (tuple(frames.shape), frames.dtype, bool(want_masks), ops.DEFAULT_PRECISION, tuple(self.pinned_layers()))
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            saved = rh.fixed_rows
+            rh.fixed_rows = True
+            try:
+                static_in = frames.clone()
+                for _ in range(2):  # warm-up: weight packs and their splits, LDS opt-ins, side streams, allocator
+                    self.inference_batched(static_in, want_masks=want_masks)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                ops._amax_arena.pop(static_in.device, None)  # the pass gets maxima slots of its own, zero-filled INSIDE the graph
+                with torch.cuda.graph(g):
+                    out = self.inference_batched(static_in, want_masks=want_masks)
+                ops._amax_arena.pop(static_in.device, None)  # (eager passes must not hand out slots of the graph's pool)
+            finally:
+                rh.fixed_rows = saved
+            ent = cache[key] = (g, static_in, out)
+        g, static_in, out = ent
+        static_in.copy_(frames)
+        g.replay()
+        return out
+
     # ------------------------------------------------------------------ load-time precision audit (round 4)
     def _packables(self):
         """(qualified name, layer holder) of every conv / linear / deconv holder of the detection path, incl. the depth head's

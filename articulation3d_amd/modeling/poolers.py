@@ -32,11 +32,11 @@ class ROIPooler(nn.Module):
         assert math.isclose(min_level, int(min_level)) and int(min_level) == 2, "pyramid must start at stride 4 (p2)"
 
     def forward_batched(self, feats_nhwc: List[torch.Tensor], boxes: torch.Tensor, count: Optional[torch.Tensor], *,
-                        row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, presplit: bool = False):
+                        row_offset: Optional[torch.Tensor] = None, rows: Optional[int] = None, presplit: bool = False, zero: bool = False):
         """boxes [B,R,4] fixed-size slots, count [B] live slots -> [rows, P, P, C] NHWC bins (presplit: the rows as the fp16 planes
         of the default arithmetic, for a Linear consumer -- ops.roi_align_fpn)."""
         return ops.roi_align_fpn(feats_nhwc, self.scales, boxes, count, self.output_size, self.sampling_ratio,
-                                 self.aligned, row_offset=row_offset, rows=rows, presplit=presplit)
+                                 self.aligned, row_offset=row_offset, rows=rows, presplit=presplit, zero=zero)
 
     def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]):
         """Reference signature: list of NCHW level features + per-image Boxes -> [sum(K_i), C, P, P]."""

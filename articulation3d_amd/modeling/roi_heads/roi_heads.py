@@ -109,6 +109,8 @@ class PlaneRCNNROIHeads(nn.Module):
         host read of the batch does not drain the GPU queue."""
         R = det.boxes.shape[1]
         det.row_offset = ops.count_offsets(det.count, R)
+        if self.fixed_rows and det.boxes.shape[0] * R <= self.FIXED_ROWS_CAP:
+            return det  # (no host read in this mode: given_boxes_batched sizes the head tensors for every slot)
         if getattr(self, "_total_pin", None) is None:
             self._total_pin = torch.zeros(1, dtype=torch.int32, pin_memory=True)
         self._total_pin.copy_(det.row_offset[-1:], non_blocking=True)
@@ -116,19 +118,36 @@ class PlaneRCNNROIHeads(nn.Module):
         det._total_event.record()
         return det
 
+    # Batches of at most this many detection SLOTS (frames x DETECTIONS_PER_IMAGE) can run their per-ROI heads without the step's one
+    # host read (`fixed_rows`, off by default): the head tensors are sized for every slot, rows past the live total are zero-pooled and
+    # never read (GEMM rows are independent; paste / pack go by the device-side counts); live rows keep their compact positions, so
+    # the bits are those of the sized form.  It exists so that a pass can be captured as a HIP graph (PlaneRCNN.inference_graphed) --
+    # and it is what that experiment costs: at one frame the sized heads see ~4 ROIs (a handful of plane-split workgroups per layer),
+    # the fixed form 100, and the single-frame pass goes from 4.42 to 5.43 ms eager, 5.37 ms replayed from the graph
+    # (tools/loop_bench.py, profiles/r04_loop_bench.txt): the host read is cheaper than the rows it saves.
+    FIXED_ROWS_CAP = 256
+    fixed_rows = False
+
     def given_boxes_batched(self, feats: Dict[str, torch.Tensor], det: BatchedDetections) -> BatchedDetections:
-        """forward_with_given_boxes on fixed-size detections; one host read of the live-ROI total."""
+        """forward_with_given_boxes on fixed-size detections; one host read of the live-ROI total (none with `fixed_rows`)."""
         lv = [feats[f] for f in self.in_features]
-        if getattr(det, "_total_event", None) is None:
-            self.start_row_count(det)
-        det._total_event.synchronize()  # waits for the count only, not for the work enqueued after it
-        det.total = int(self._total_pin[0])
-        det._total_event = None
+        fixed = self.fixed_rows and det.boxes.shape[0] * det.boxes.shape[1] <= self.FIXED_ROWS_CAP
+        if fixed:
+            if det.row_offset is None:
+                det.row_offset = ops.count_offsets(det.count, det.boxes.shape[1])
+            det._total_event = None
+            det.total = det.boxes.shape[0] * det.boxes.shape[1]
+        else:
+            if getattr(det, "_total_event", None) is None:
+                self.start_row_count(det)
+            det._total_event.synchronize()  # waits for the count only, not for the work enqueued after it
+            det.total = int(self._total_pin[0])
+            det._total_event = None
         rows = det.total
         if rows == 0:
             return det
         same_pool = self.plane_on and self.axis_on and self._same_pooler(self.plane_pooler, self.axis_pooler)
-        pool = lambda p: p.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows)
+        pool = lambda p: p.forward_batched(lv, det.boxes, det.count, row_offset=det.row_offset, rows=rows, zero=fixed)
         shared = pool(self.plane_pooler) if self.plane_on else None
         # the three heads are independent: concurrent branches for 1-2 frame batches (streams.py), and for any batch whose
         # heads are single-round launches (few ROIs: each conv fills a fraction of the chip; measured +0.6% on the 64-frame clip)

@@ -182,6 +182,13 @@ def pack_conv_ups_phases(weight: torch.Tensor, bias=None, bn=None, act=ACT_NONE,
                             wp[:, :, a, b] += w[:, :, kh, kw]
             wk = _pad_rows(wp.float().permute(0, 2, 3, 1).reshape(Cout, 4 * Cin))
             out.append(PackedConv(dev(wk), scale_d, shift_d, 2, 2, 1, 0, Cin, wk.shape[0], 4 * Cin, act, phase=1 + dy * 2 + dx, presplit=True))
+    # ONE power-of-two filter scale for the layer, not one per phase: the fused four-phase launch splits all four filters under the scale
+    # of their common maximum, and a phase launched alone must split ITS filter under the same scale to produce the same bits (the
+    # pre-summed taps of the phases differ in magnitude; under another scale a weight below 2^-18 of the maximum lands in fp16's
+    # subnormal range in one form only -- found by tools/fuzz_kernels.py as a 1-ulp difference on one layer in 640)
+    common = _pow2_scale_host(max(float(q.w.abs().max()) for q in out))
+    for q in out:
+        q._w_scale = common
     return out
 
 

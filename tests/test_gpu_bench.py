@@ -175,3 +175,36 @@ def test_first_small_batch_of_a_process_equals_the_steady_state():
             out, _ = pr.communicate(timeout=600)
             assert pr.returncode == 0, out[-2000:]
             assert "0 runs differ from the first" in out, out[-2000:]
+
+
+def test_single_frame_pass_without_its_host_read_and_as_a_hip_graph():
+    """Round 4: `roi_heads.fixed_rows` sizes the per-ROI head tensors for every detection slot instead of reading
+    the live total back, and `PlaneRCNN.inference_graphed` captures that pass -- side-stream branches included -- as ONE HIP graph.
+    Both must give the bits of the eager, sized pass (records, depth, pasted masks), on the frame they were captured with and on another
+    one.  (Timing: tools/loop_bench.py -- the graph is not the default.)"""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from bench import build_detector
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
+    model, _ = build_detector(0.5, "cuda:0")
+    fr = torch.from_numpy(synthetic_frames(3, 2020)).cuda()
+    ref = [model.inference_batched(fr[i:i + 1], want_masks=True) for i in range(3)]
+    ref = [(o.records.clone(), o.rec_count.clone(), o.depth.clone(), o.masks.clone()) for o in ref]
+    assert sum(int(r[1].sum()) for r in ref) > 0
+    model.roi_heads.fixed_rows = True
+    try:
+        for i in range(3):
+            o = model.inference_batched(fr[i:i + 1], want_masks=True)
+            assert torch.equal(o.records, ref[i][0]) and torch.equal(o.rec_count, ref[i][1]) and torch.equal(o.depth, ref[i][2]) and torch.equal(o.masks, ref[i][3])
+    finally:
+        model.roi_heads.fixed_rows = False
+    for i in (0, 1, 2, 0):
+        o = model.inference_graphed(fr[i:i + 1], want_masks=True)
+        torch.cuda.synchronize()
+        assert torch.equal(o.records, ref[i][0]) and torch.equal(o.rec_count, ref[i][1]) and torch.equal(o.depth, ref[i][2]) and torch.equal(o.masks, ref[i][3]), i
+    assert len(model._graphs) == 1
+    # an eager pass after the captures is untouched by them (its maxima slots are its own)
+    o = model.inference_batched(fr[1:2], want_masks=True)
+    assert torch.equal(o.records, ref[1][0]) and torch.equal(o.depth, ref[1][2])

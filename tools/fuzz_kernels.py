@@ -175,7 +175,7 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                                 ops.WINO_PLANE_SPLIT = saved_ps
                         forms.append(("plane-split toggled", other_ps))
                     if mode == 2 and v0.startswith("wino"):
-                        forms.append(("tune 8", lambda: launch(2, x, pk, tune=8, **kw)[0]))
+                        forms.append(("tune 8", lambda: launch(2, x, pk, tune=8, precision=2, **kw)[0]))
                     if mode == 0 and v0.startswith("wino"):
                         forms.append(("tune 7", lambda: launch(0, x, pk, tune=7, **kw)[0]))
                     if mode == 0 and kind in ("1x1", "linear"):

@@ -46,3 +46,35 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): model.inference_batched(x)
 torch.cuda.synchronize(); print("inference_batched(B=1) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
 
+# the same single-frame pass replayed from a captured HIP graph (PlaneRCNN.inference_graphed): bits and time
+e = model.inference_batched(x, want_masks=True)
+er, ed, ec = e.records.clone(), e.depth.clone(), e.rec_count.clone()
+g = model.inference_graphed(x, want_masks=True)
+torch.cuda.synchronize()
+same = bool(torch.equal(g.records, er) and torch.equal(g.depth, ed) and torch.equal(g.rec_count, ec))
+x2 = torch.from_numpy(frames[9:10]).cuda()
+e2 = model.inference_batched(x2, want_masks=True)
+er2, em2 = e2.records.clone(), e2.masks.clone()
+g2 = model.inference_graphed(x2, want_masks=True)
+torch.cuda.synchronize()
+same = same and bool(torch.equal(g2.records, er2) and torch.equal(g2.masks, em2))
+for _ in range(3): model.inference_graphed(x)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): model.inference_graphed(x)
+torch.cuda.synchronize(); print("inference_graphed(B=1) ms: %.2f  (bits equal to the eager pass: %s)" % ((time.perf_counter() - t0) / 20 * 1e3, same))
+for nb in (2,):
+    xb = torch.from_numpy(frames[4:4 + nb]).cuda()
+    for _ in range(3): model.inference_batched(xb); model.inference_graphed(xb)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): model.inference_batched(xb)
+    torch.cuda.synchronize(); te = (time.perf_counter() - t0) / 20 * 1e3; t0 = time.perf_counter()
+    for _ in range(20): model.inference_graphed(xb)
+    torch.cuda.synchronize(); print("B=%d: eager %.2f ms, graph %.2f ms" % (nb, te, (time.perf_counter() - t0) / 20 * 1e3))
+model.roi_heads.fixed_rows = True  # the eager pass without its one host read (head tensors sized for every detection slot)
+for _ in range(3): model.inference_batched(x)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20): model.inference_batched(x)
+torch.cuda.synchronize(); print("inference_batched(B=1, fixed_rows) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
+f = model.inference_batched(x, want_masks=True)
+print("fixed_rows bits equal:", bool(torch.equal(f.records, er) and torch.equal(f.depth, ed)))
+model.roi_heads.fixed_rows = False
