@@ -97,6 +97,20 @@ def test_bench_spawns_its_ranks(tmp_path):
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
 
 
+def test_bench_with_eight_ranks_reports_eight(tmp_path):
+    """BASELINE configs[3]'s launch shape on the one GPU of this box: `bench.py --gpus 8` spawns eight ranks (gloo, all on device 0: the
+    driver's 8-GPU run uses RCCL with one device per rank -- LOCAL_RANK is the device ordinal there), each detects its own frames, every
+    step's records are all-gathered, rank 0 runs the CPU leg and the matched-detections check while the others wait at the barrier,
+    and the line says n_gpus = 8 with whole-job frames per step."""
+    r = _run(["bench.py", "--gpus", "8", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "2",
+              "--cpu-frames", "2", "--no-alt-modes", "--no-operating-points"], timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["global_frames_per_step"] == 16 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0 and d["matched_detections"]["matched"] is True
+    assert "RCCL all-gather" in d["config"]["sharding"] and d["roofline"]["frac"] > 0
+
+
 def _two_gpus():
     import torch
 
