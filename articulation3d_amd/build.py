@@ -29,6 +29,7 @@ SOURCES = {
     "conv_bf16x3.hip": [],
     "conv_bf16x3_wide.hip": [],
     "conv_xs_h2.hip": [],
+    "conv_ph4p.hip": [],
     "spatial_ops.hip": [],
     "roi_align.hip": ["-ffp-contract=off"],  # sample coordinates ~1e2 px: an FMA-rounded coordinate moves the bilinear weights by 1e-5
     "proposals.hip": ["-ffp-contract=off"],

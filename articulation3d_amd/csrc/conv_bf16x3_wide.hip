@@ -647,6 +647,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 // The fused four-phase form (a3d_conv_desc.phase == 5): see conv_x3w_kernel's PH4.
 static int launch_ph4(const a3d_conv_desc *d, hipStream_t s) {
     if (d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
+    {
+        const int rp = a3d_conv_launch_ph4p(d, s);  // maps that fit its 8 x 32 tiles: the patch-resident form (conv_ph4p.hip)
+        if (rp != A3D_ERR_UNSUPPORTED) return rp;
+    }
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return A3D_ERR_ARG;
     if (d->stem || d->ups || d->m_dev || d->splitk != 1 || d->res || d->gate || d->pixshuf) return A3D_ERR_ARG;
     if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_ARG;

@@ -145,6 +145,8 @@ int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s);
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
 // its wide form (conv_bf16x3_wide.hip: 256 x 256 tiles, pre-split weights by LDS-DMA); A3D_ERR_UNSUPPORTED -> the kernel above
 int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s);
+// the fused four-phase form with the input patch resident in LDS (conv_ph4p.hip); A3D_ERR_UNSUPPORTED -> the tap-outer form
+int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s);
 // second launch of a split-K layer (conv_gemm_v2.hip): workspace [splitk][M][Cout] -> y with the fused epilogue
 void a3d_launch_splitk_reduce(const a3d_conv_desc *d, int M, hipStream_t s);
 

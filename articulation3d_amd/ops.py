@@ -805,29 +805,32 @@ def _conv2d_timed(d, p, out, shared, have_v, use_wino, fused_wino, B, H, W, Ho, 
 
 WINO_MAX_HW = int(os.environ.get("A3D_WINO_MAX_HW", "0"))
 UPS_FUSED = os.environ.get("A3D_UPS_FUSED", "1") != "0"  # (False: always the four-launch form; same bits)
-UPS_FUSED_MIN_BLOCKS = int(os.environ.get("A3D_UPS_FUSED_MIN_BLOCKS", "0"))
 
 
-def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None, fused: Optional[bool] = None) -> torch.Tensor:
+def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[torch.Tensor] = None, fused: Optional[bool] = None, tune: int = 0) -> torch.Tensor:
     """3x3 pad-1 conv over the nearest-x2 upsampling of (x || x2), as four source-grid 2x2 convs (pack_conv_ups_phases) -- in the
-    default arithmetic as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5, conv_x3w_kernel's PH4).  The two forms agree
-    bit for bit (test_fused_upsampled_conv_equals_the_four_phase_launches), so the choice may depend on the batch
-    (A3D_UPS_FUSED_MIN_BLOCKS).  Measured at 64 frames (tools/ups_bench.py, four launches | one): 8x10 0.122 | 0.083 ms, 15x20 0.230 |
-    0.144, 30x40 0.401 | 0.400, 60x80 1.328 | 1.364, 120x160 -> 64 channels 3.26 | 2.76; the step 1305 -> 1324 frames/s."""
+    default arithmetic as ONE launch over the 9 distinct taps (a3d_conv_desc.phase == 5).  Two kernels run that launch: the
+    patch-resident one (csrc/conv_ph4p.hip, round 4, the default: the input patch of an 8 x 32 tile split once per chunk and held in
+    LDS while the nine taps multiply it) and the tap-outer one (conv_x3w_kernel's PH4, tune 15), which agrees BIT FOR BIT with the
+    four-launch form (test_fused_upsampled_conv_equals_the_four_phase_launches).  The patch-resident kernel reduces over (chunk, tap)
+    instead of (tap, chunk): it agrees with the other two to fp32 rounding, so which form runs is a function of the layer and the
+    arithmetic only, never of the batch.  Measured at 64 frames (tools/ups_bench.py; four launches | tap-outer | patch-resident, ms):
+    8x10 0.107 | 0.078 | 0.060, 15x20 0.200 | 0.142 | 0.115, 30x40 0.382 | 0.403 | 0.400, 60x80 1.230 | 1.351 | 1.168, 120x160 -> 64
+    channels 3.044 | 2.825 | 1.931."""
     B, H, W, _ = x.shape
     if AUDIT is not None and not AUDIT.busy and fused is None:
         return AUDIT.conv2d_ups(x, phases, x2)
     out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
     pinned = phases[0].pin_precision == 2  # (the audit pins the LAYER: its four phase launches then run bf16x3)
     if fused is None:
-        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned and (-(-(B * H * W) // 256)) * (-(-4 * phases[0].cols // 256)) >= UPS_FUSED_MIN_BLOCKS
+        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned  # (a function of the layer and the arithmetic: never of the batch)
     if fused:
         pf = getattr(phases[0], "_fused", None)
         if pf is None:
             pf = pack_conv_ups_fused(phases)
             phases[0]._fused = pf if pf is not None else False
-        if pf:
-            return conv2d(x, pf, x2=x2, out=out, precision=3)
+        if pf:  # (tune 15 / 16: never / always the patch-resident kernel of csrc/conv_ph4p.hip; 0: by the map's size)
+            return conv2d(x, pf, x2=x2, out=out, precision=3, tune=tune)
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out

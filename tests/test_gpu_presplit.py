@@ -167,3 +167,44 @@ def test_box_head_on_presplit_rows_equals_the_fp32_rows(ops):
     live[:R] = True
     live[R:R + 640] = True
     assert torch.equal(y0[live], y1[live])
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=16, W=64, C1=128, C2=128, Cout=64, tune=16),   # whole tiles, two sources (the decoder's last stage in miniature)
+    dict(B=3, H=24, W=96, C1=128, C2=0, Cout=128, tune=16),    # one source, two column tiles
+    dict(B=2, H=13, W=42, C1=64, C2=64, Cout=64, tune=16),     # partial tiles in both directions, map borders inside a tile
+    dict(B=1, H=8, W=32, C1=32, C2=0, Cout=32, tune=16),       # a single tile, a single pair of chunks, 128 GEMM columns of 256
+    dict(B=2, H=120, W=160, C1=128, C2=128, Cout=64, tune=0),  # the dispatcher's own choice on the decoder's 120 x 160 stage
+], ids=lambda c: f"{c['B']}x{c['H']}x{c['W']}x({c['C1']}+{c['C2']})to{c['Cout']}")
+def test_patch_resident_upsampled_conv_matches_the_tap_outer_form(ops, case):
+    """csrc/conv_ph4p.hip (round 4): the fused four-phase upsampled conv with the input patch resident in LDS.  Same products, same term
+    order per k, but the reduction runs (chunk, tap) instead of (tap, chunk): it must agree with the tap-outer form to fp32 rounding
+    (2e-6 of the image's output scale; both are held to float64 at 5e-6), record the same per-image maxima to that precision, and the
+    dispatcher's choice must not depend on the batch (one frame alone == the same frame inside a batch, bit for bit)."""
+    import torch.nn.functional as F
+
+    c = case
+    torch.manual_seed(41)
+    spread = torch.logspace(-2, 2, c["B"], device="cuda").view(-1, 1, 1, 1)
+    x = torch.randn(c["B"], c["H"], c["W"], c["C1"], device="cuda") * spread
+    x2 = torch.randn(c["B"], c["H"], c["W"], c["C2"], device="cuda") * spread if c["C2"] else None
+    w = torch.randn(c["Cout"], c["C1"] + c["C2"], 3, 3) / (3 * (c["C1"] + c["C2"]) ** 0.5)
+    bn = (torch.rand(c["Cout"]) + 0.5, torch.randn(c["Cout"]) * 0.1, torch.randn(c["Cout"]) * 0.1, torch.rand(c["Cout"]) + 0.5, 1e-3)
+    phases = ops.pack_conv_ups_phases(w, None, bn, ops.ACT_RELU)
+    y_old = ops.conv2d_ups(x, phases, x2=x2, tune=15)
+    assert ops.last_conv_variant() == "conv_h2w_kernel ph4", ops.last_conv_variant()
+    y_new = ops.conv2d_ups(x, phases, x2=x2, tune=c["tune"])
+    assert ops.last_conv_variant() == "conv_ph4p_kernel", ops.last_conv_variant()
+    scale = y_old.abs().flatten(1).amax(1).clamp_min(1e-30).view(-1, 1, 1, 1)
+    assert float(((y_new - y_old).abs() / scale).max()) < 2e-6
+    assert torch.allclose(ops.amax_of(y_new), ops.amax_of(y_old), rtol=2e-6, atol=0)
+    xi = x if x2 is None else torch.cat([x, x2], -1)
+    up = F.interpolate(xi[:1].double().permute(0, 3, 1, 2).cpu(), scale_factor=2, mode="nearest")
+    ref = F.conv2d(up, w.double(), None, padding=1)
+    sc = bn[0].double() / torch.sqrt(bn[3].double() + bn[4])
+    ref = torch.relu(ref * sc.view(1, -1, 1, 1) + (bn[1].double() - bn[2].double() * sc).view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert float((y_new[:1, ..., : c["Cout"]].double().cpu() - ref).abs().max() / ref.abs().max()) < 5e-6
+    # batch invariance of whatever the dispatcher picks (tune 0): the last frame alone
+    alone = ops.conv2d_ups(x[-1:].contiguous(), phases, x2=None if x2 is None else x2[-1:].contiguous())
+    batch = ops.conv2d_ups(x, phases, x2=x2)
+    assert torch.equal(alone[0], batch[-1])

@@ -16,18 +16,23 @@ for B, H, W, C1, C2, Cout in SHAPES:
     a = torch.randn(B, H, W, C1, device="cuda")
     c2 = torch.randn(B, H, W, C2, device="cuda") if C2 else None
     phases = ops.pack_conv_ups_phases(torch.randn(Cout, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5), torch.randn(Cout) * 0.1, None, ops.ACT_LEAKY)
-    outs, ts = [], [[], []]
-    for f in (False, True):
-        outs.append(ops.conv2d_ups(a, phases, x2=c2, fused=f))
+    forms = [("four launches", dict(fused=False)), ("one launch, tap-outer", dict(fused=True, tune=15)), ("one launch, patch-resident", dict(fused=True, tune=16))]
+    outs, ts, names = [], [[] for _ in forms], []
+    for _n, kw in forms:
+        outs.append(ops.conv2d_ups(a, phases, x2=c2, **kw))
+        names.append(ops.last_conv_variant())
     for _ in range(9):
-        for i, f in enumerate((False, True)):
+        for i, (_n, kw) in enumerate(forms):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.conv2d_ups(a, phases, x2=c2, fused=f)
+            ops.conv2d_ups(a, phases, x2=c2, **kw)
             e1.record()
             torch.cuda.synchronize()
             ts[i].append(e0.elapsed_time(e1))
-    t4, t1 = sorted(ts[0])[4], sorted(ts[1])[4]
+    t4, t1, tp = (sorted(t)[4] for t in ts)
     gf = 2.0 * B * H * W * 4 * Cout * 4 * (C1 + C2) / 1e9
-    print(f"{B}x{H}x{W}x({C1}+{C2})->{Cout}: four launches {t4:.3f} ms | one launch {t1:.3f} ms ({gf / t1:.0f} fp32-eq GFLOP/ms) | "
-          f"bits equal: {bool(torch.equal(outs[0], outs[1]))}", flush=True)
+    dflt = ops.conv2d_ups(a, phases, x2=c2)
+    vd = ops.last_conv_variant()
+    err = float((outs[2] - outs[1]).abs().max() / outs[1].abs().max())
+    print(f"{B}x{H}x{W}x({C1}+{C2})->{Cout}: four launches {t4:.3f} ms | tap-outer {t1:.3f} ms | patch-resident {tp:.3f} ms ({gf / tp:.0f} fp32-eq GFLOP/ms) | "
+          f"four == tap-outer bits: {bool(torch.equal(outs[0], outs[1]))}; patch-resident vs tap-outer max rel {err:.1e}; default: {vd}", flush=True)
