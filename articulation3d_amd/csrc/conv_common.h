@@ -147,6 +147,8 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
 int a3d_conv_launch_bf16x3_wide(const a3d_conv_desc *d, hipStream_t s);
 // the fused four-phase form with the input patch resident in LDS (conv_ph4p.hip); A3D_ERR_UNSUPPORTED -> the tap-outer form
 int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s);
+// the same loop on a plain 3x3 stride-1 pad-1 fp16x2 layer (conv_ph4p.hip); A3D_ERR_UNSUPPORTED -> the tap-outer kernels
+int a3d_conv_launch_c3p(const a3d_conv_desc *d, hipStream_t s);
 // second launch of a split-K layer (conv_gemm_v2.hip): workspace [splitk][M][Cout] -> y with the fused epilogue
 void a3d_launch_splitk_reduce(const a3d_conv_desc *d, int M, hipStream_t s);
 

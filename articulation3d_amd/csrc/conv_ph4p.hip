@@ -44,9 +44,11 @@ constexpr int PP_TW = 32, PP_TH = 8, PP_PC = PP_TW + 2, PP_PR = PP_TH + 2, PP_NP
 constexpr int PP_ITEMS = PP_NPOS * 4;                       // loader items: (position, channel quad)
 constexpr int PP_LI = (PP_ITEMS + 511) / 512;               // items per thread (3)
 constexpr int PP_XPL = PP_NPOS * 16, PP_XBUF = 2 * PP_XPL;  // 16-bit elements: one plane / one buffer (h | l) of the patch
-constexpr int PP_WPL = 256 * 16, PP_WST = 2 * PP_WPL;       // one plane / one stage of the filter ring (256 columns x 16 k)
 constexpr int PP_NWS = 6;                                   // ring stages = two groups of three taps
-constexpr int pp_lds_bytes() { return (2 * PP_XBUF + PP_NWS * PP_WST) * 2 + 2 * 256 * 4; }
+// one plane / one stage of the filter ring: BN = 64 NB columns x 16 k (16 KiB per stage at 256 columns, 4 KiB at 64: the 64-column
+// form then fits two workgroups per CU)
+constexpr int pp_wpl(int NB) { return 64 * NB * 16; }
+constexpr int pp_lds_bytes(int NB) { return (2 * PP_XBUF + PP_NWS * 2 * pp_wpl(NB)) * 2 + 2 * 256 * 4; }
 
 // the phases (bit 2 dy + dx) whose 2x2 window inside the 3x3 neighbourhood holds tap kh = tap / 3, kw = tap % 3
 constexpr unsigned pp_tap_phases(const int tap) {
@@ -56,7 +58,28 @@ constexpr unsigned pp_tap_phases(const int tap) {
     return rows & cols;
 }
 
-__global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d, const int tiles_x, const int tiles_y, const int ntiles, const int nblk) {
+// live 32-column blocks of a wave at a tap: the phases whose window holds the tap (PH), or all NB blocks (a plain 3x3 convolution)
+template <bool PH, int NB>
+constexpr unsigned pp_act(const int tap) {
+    return PH ? pp_tap_phases(tap) : ((1u << NB) - 1u);
+}
+// filter-fragment register set a tap starts from: A[0] holds the first block of a group's first tap and the sets alternate block by block
+template <bool PH, int NB>
+constexpr int pp_start(const int tap) {
+    int s = 0;
+    for (int t = (tap / 3) * 3; t < tap; ++t) s += __builtin_popcount(pp_act<PH, NB>(t));
+    return s & 1;
+}
+
+// PH = true, NB = 4: the fused four-phase upsampled convolution (a3d_conv_desc.phase == 5).  PH = false: a plain 3x3 stride-1 pad-1
+// convolution of the fp16x2 arithmetic with NB x 64 output channels per workgroup (the layers the Winograd form does not take: fewer than
+// 256 input channels -- res2 / res3 conv2, pkg/modeling/meta_arch/planercnn.py:150 -> detectron2 BottleneckBlock), same loop, every block
+// live at every tap.
+template <bool PH, int NB>
+__global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a3d_conv_desc d, const int tiles_x, const int tiles_y, const int ntiles, const int nblk) {
+    static_assert(!PH || NB == 4, "the four phases are the four blocks of a wave");
+    constexpr int WCOLS = NB * 32, BN = 2 * WCOLS;  // columns per wave / per workgroup
+    constexpr int PP_WPL = pp_wpl(NB), PP_WST = 2 * PP_WPL;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 *const Xs = lds;                                   // [2 buffers][h | l][340 positions][16 k]
     __bf16 *const Ws = lds + 2 * PP_XBUF;                     // [6 stages][h | l][256 columns][16 k]
@@ -70,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
     const int tpi = tiles_x * tiles_y;
     const int b = mt / tpi, tr = mt - b * tpi;
     const int ty0 = (tr / tiles_x) * PP_TH, tx0 = (tr % tiles_x) * PP_TW;
-    const int n0 = nt * 256;
+    const int n0 = nt * BN;
     const int CinT = d.Cin + d.Cin2, cs4 = d.Cin * 4, nchunks = CinT >> 4;
     const __amdgpu_buffer_rsrc_t rx = pp_rsrc(d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
     const __amdgpu_buffer_rsrc_t rx2 = pp_rsrc(d.x2 ? d.x2 : d.x, (unsigned)((size_t)d.B * d.H * d.W * (size_t)cs4));
@@ -124,26 +147,27 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
             __bf16 *Wt = Ws + (half * 3 + t) * PP_WST;
             const int base = __builtin_amdgcn_readfirstlane(((3 * g + t) * nchunks + cc) * (int)w3chunk + n0 * 32);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int j = wave * 2 + i;
-                const int p = j >> 3, gg = j & 7;
-                pp_dma16(rw, Wt + p * PP_WPL + gg * 32 * 16, wvoff, base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + gg * 1024));
+            for (int i = 0; i < 2; ++i) {  // 2 BN / 32 pieces of 32 rows: piece j = plane j / (BN / 32), row group j % (BN / 32)
+                const int j = wave + 8 * i;
+                const int p = j / (BN / 32), gg = j % (BN / 32);
+                if (j < 2 * (BN / 32))  // (narrow tiles: fewer pieces than waves; a wave without one waits conservatively)
+                    pp_dma16(rw, Wt + p * PP_WPL + gg * 32 * 16, wvoff, base + __builtin_amdgcn_readfirstlane(p * d.Cout * 32 + gg * 1024));
             }
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[NB][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][m][r] = 0.f;
-    a3d_stage_scale_shift(ss, d, n0, 256, tid);
+    a3d_stage_scale_shift(ss, d, n0, BN, tid);
 
     // ---- fragments
     const int frow = lane & 31, khalf = lane >> 5;
-    const __bf16 *const fW = Ws + (wn * 128 + frow) * 16 + (((khalf ^ (frow >> 3)) & 1) << 3);
+    const __bf16 *const fW = Ws + (wn * WCOLS + frow) * 16 + (((khalf ^ (frow >> 3)) & 1) << 3);
     const int posb0 = (2 * wm) * PP_PC + frow, posb1 = posb0 + PP_PC;
     struct FragA {
         pp_bf16x8 p[2];
@@ -179,13 +203,14 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
     // NEXT tap's activation fragments are read (the patch of the chunk -- or, behind the last tap, of the next chunk -- is complete in
     // LDS), under the last block the next tap's first filter block, unless that tap belongs to the next group (its stage may not have
     // landed: the group's barrier comes first).  Returns the register set the next tap starts from.
-    auto tap = [&](auto tap_c, auto s_c, auto last_c, auto bi_c, const int stage, const int buf_next, const int stage_next) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tap_c)::value, S = decltype(s_c)::value, BI = decltype(bi_c)::value;
+    auto tap = [&](auto tap_c, auto last_c, auto bi_c, const int stage, const int buf_next, const int stage_next) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tap_c)::value, BI = decltype(bi_c)::value;
+        constexpr int S = pp_start<PH, NB>(TAP);
         constexpr bool LAST = decltype(last_c)::value;  // last tap of its group
-        constexpr unsigned ACT = pp_tap_phases(TAP);
+        constexpr unsigned ACT = pp_act<PH, NB>(TAP);
         constexpr int NTAP = (TAP + 1) % 9;
         constexpr int ntoff = (NTAP / 3) * PP_PC + (NTAP % 3);
-        constexpr int nfirst = __builtin_ctz(pp_tap_phases(NTAP));
+        constexpr int nfirst = __builtin_ctz(pp_act<PH, NB>(NTAP));
         constexpr int b0 = __builtin_ctz(ACT);
         constexpr unsigned R1 = ACT & (ACT - 1), R2 = R1 & (R1 - 1), R3 = R2 & (R2 - 1);
         // block 0 of the tap (+ the next tap's activation fragments)
@@ -233,32 +258,32 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
         constexpr int buf = PAR, h0 = PAR, h1 = PAR ^ 1;  // ring halves of groups 0 / 1 / 2: h0, h1, h0  ((3 c + g) & 1)
         using E = std::integral_constant<int, PAR>;       // fragment set of the even taps
         using O = std::integral_constant<int, PAR ^ 1>;   // ... of the odd taps
-        // ---- group 0: taps 0 (one block), 1 (two), 2 (one)
+        // ---- group 0: taps 0, 1, 2 (four-phase form: one, two, one live blocks)
         dma_group(c, 1);
         load_patch(c + 1);
-        rdA(A[0], h0 * 3 + 0, 0);
-        tap(PP_T(0), I0{}, TF{}, E{}, h0 * 3 + 0, buf, h0 * 3 + 1);  // -> the next tap starts from A[1]
-        tap(PP_T(1), I1{}, TF{}, O{}, h0 * 3 + 1, buf, h0 * 3 + 2);  // A[1], A[0] -> next from A[1]
-        tap(PP_T(2), I1{}, TT{}, E{}, h0 * 3 + 2, buf, 0);
+        rdA(A[0], h0 * 3 + 0, __builtin_ctz(pp_act<PH, NB>(0)));
+        tap(PP_T(0), TF{}, E{}, h0 * 3 + 0, buf, h0 * 3 + 1);
+        tap(PP_T(1), TF{}, O{}, h0 * 3 + 1, buf, h0 * 3 + 2);
+        tap(PP_T(2), TT{}, E{}, h0 * 3 + 2, buf, 0);
         __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"(PP_LI) : "memory");  // filter group 1 has landed (younger: the patch loads)
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // ---- group 1: taps 3 (two blocks), 4 (four), 5 (two)
+        // ---- group 1: taps 3, 4, 5 (two, four, two)
         dma_group(c, 2);
-        rdA(A[0], h1 * 3 + 0, 0);
-        tap(PP_T(3), I0{}, TF{}, O{}, h1 * 3 + 0, buf, h1 * 3 + 1);
-        tap(PP_T(4), I0{}, TF{}, E{}, h1 * 3 + 1, buf, h1 * 3 + 2);
-        tap(PP_T(5), I0{}, TT{}, O{}, h1 * 3 + 2, buf, 0);
+        rdA(A[0], h1 * 3 + 0, __builtin_ctz(pp_act<PH, NB>(3)));
+        tap(PP_T(3), TF{}, O{}, h1 * 3 + 0, buf, h1 * 3 + 1);
+        tap(PP_T(4), TF{}, E{}, h1 * 3 + 1, buf, h1 * 3 + 2);
+        tap(PP_T(5), TT{}, O{}, h1 * 3 + 2, buf, 0);
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");  // filter group 2 and the next chunk's patch loads have landed
         store_patch(buf ^ 1);
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        // ---- group 2: taps 6 (one block), 7 (two), 8 (one)
+        // ---- group 2: taps 6, 7, 8 (one, two, one)
         dma_group(c + 1, 0);
-        rdA(A[0], h0 * 3 + 0, 2);
-        tap(PP_T(6), I0{}, TF{}, E{}, h0 * 3 + 0, buf, h0 * 3 + 1);
-        tap(PP_T(7), I1{}, TF{}, O{}, h0 * 3 + 1, buf, h0 * 3 + 2);
-        tap(PP_T(8), I1{}, TT{}, E{}, h0 * 3 + 2, buf ^ 1, 0);  // (its activation prefetch = tap 0 of the next chunk, from the next patch)
+        rdA(A[0], h0 * 3 + 0, __builtin_ctz(pp_act<PH, NB>(6)));
+        tap(PP_T(6), TF{}, E{}, h0 * 3 + 0, buf, h0 * 3 + 1);
+        tap(PP_T(7), TF{}, O{}, h0 * 3 + 1, buf, h0 * 3 + 2);
+        tap(PP_T(8), TT{}, E{}, h0 * 3 + 2, buf ^ 1, 0);  // (its activation prefetch = tap 0 of the next chunk, from the next patch)
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -271,7 +296,8 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
 #undef PP_BLOCK
 #undef PP_MFMA
 
-    // ---- epilogue (conv_bf16x3_wide.hip's PH4 stores): column 128 g + 32 phase + c -> pixel (2 oh + dy, 2 ow + dx), channel 32 g + c
+    // ---- epilogue.  Four-phase form (conv_bf16x3_wide.hip's PH4 stores): column 128 g + 32 phase + c -> pixel (2 oh + dy, 2 ow + dx),
+    // channel 32 g + c.  Plain form: pixel (oh, ow), channel = column.
     const float unx = 1.f / sx, unw = 1.f / sw;
     float vmax = 0.f;
     const int co_n = d.Cout >> 2;
@@ -280,20 +306,25 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
         const int oh = ty0 + 2 * wm + mi, ow = tx0 + frow;
         if (oh >= d.H || ow >= d.W) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NB; ++ni) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int nl = (wn * 4 + ni) * 32 + rg * 8 + khalf * 4;
+                const int nl = (wn * NB + ni) * 32 + rg * 8 + khalf * 4;
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
                 v = (v * unx) * unw;  // exact: powers of two
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + 256 + nl), false, zero);
+                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), false, zero);
                 vmax = fmaxf(vmax, a3d_absmax4(v));
-                const int co = (n >> 7) * 32 + (n & 31);
-                const size_t row = ((size_t)b * (2 * d.H) + (2 * oh + (ni >> 1))) * (size_t)(2 * d.W) + (2 * ow + (ni & 1));
-                *reinterpret_cast<f32x4 *>(d.y + row * co_n + co) = v;
+                if constexpr (PH) {
+                    const int co = (n >> 7) * 32 + (n & 31);
+                    const size_t row = ((size_t)b * (2 * d.H) + (2 * oh + (ni >> 1))) * (size_t)(2 * d.W) + (2 * ow + (ni & 1));
+                    *reinterpret_cast<f32x4 *>(d.y + row * co_n + co) = v;
+                } else {
+                    const size_t row = ((size_t)b * d.H + oh) * (size_t)d.W + ow;
+                    *reinterpret_cast<f32x4 *>(d.y + row * d.Cout + n) = v;
+                }
             }
         }
     }
@@ -303,6 +334,21 @@ __global__ __launch_bounds__(512, 1) void conv_ph4p_kernel(const a3d_conv_desc d
 
 // A3D_ERR_UNSUPPORTED: tune 15 (the tap-outer form of conv_bf16x3_wide.hip: A/B runs and the bit-equality test against the four-launch
 // form) or a tensor past the 32-bit offsets.  tune 16 = this kernel (the default anyway).
+template <bool PH, int NB>
+static int pp_launch(const a3d_conv_desc *d, hipStream_t s, const char *label) {
+    const int tiles_x = (d->W + PP_TW - 1) / PP_TW, tiles_y = (d->H + PP_TH - 1) / PP_TH;
+    const int ntiles = (d->Cout + 64 * NB - 1) / (64 * NB);
+    const int nblk = d->B * tiles_x * tiles_y * ntiles;
+    static a3d_attr_once attr;
+    if (attr.needed()) {
+        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel<PH, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(NB)) != hipSuccess) return A3D_ERR_LAUNCH;
+        attr.mark();
+    }
+    a3d_note_variant("%s", label);
+    hipLaunchKernelGGL((conv_ph4p_kernel<PH, NB>), dim3(nblk), dim3(512), pp_lds_bytes(NB), s, *d, tiles_x, tiles_y, ntiles, nblk);
+    return a3d_check_launch();
+}
+
 int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s) {
     if (d->phase != 5 || d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return A3D_ERR_ARG;
@@ -312,18 +358,27 @@ int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s) {
     if ((d->Cin & 15) || (CinT & 31) || d->Kpad != 9 * CinT || (d->Cout & 127)) return A3D_ERR_ARG;
     if (d->tune == 15) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
-    const int tiles_x = (d->W + PP_TW - 1) / PP_TW, tiles_y = (d->H + PP_TH - 1) / PP_TH;
     // (Measured at 64 frames, tap-outer | this kernel, tools/ups_bench.py: 8x10 0.078 | 0.060 ms, 15x20 0.142 | 0.115, 30x40 0.403 | 0.400, 60x80
     // 1.351 | 1.168, 120x160 2.825 | 1.931 -- ahead or level on every map of the decoder, also where its 8 x 32 tiles cover 1.3-3 x the map:
     // every phase-5 launch takes it.  The two forms differ in their reduction order, so the choice may never depend on the batch.)
-    const int ntiles = (d->Cout + 255) / 256;
-    const int nblk = d->B * tiles_x * tiles_y * ntiles;
-    static a3d_attr_once attr;
-    if (attr.needed()) {
-        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes()) != hipSuccess) return A3D_ERR_LAUNCH;
-        attr.mark();
+    return pp_launch<true, 4>(d, s, "conv_ph4p_kernel");
+}
+
+// The plain 3x3 stride-1 pad-1 layers of the fp16x2 arithmetic that stay in the direct form (fewer than 256 input channels: res2 / res3
+// conv2): A3D_ERR_UNSUPPORTED for anything else -- residual / gate / concat / other geometry, no pre-split filter, a map too small to
+// be worth an 8 x 32 tile (a function of the layer and the map size, never of the batch: the reduction order differs from the
+// tap-outer kernels'), tune != 0 (an explicit tile variant of those kernels) except 16, which forces this kernel.
+int a3d_conv_launch_c3p(const a3d_conv_desc *d, hipStream_t s) {
+    if (d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f) || (d->tune != 0 && d->tune != 16)) return A3D_ERR_UNSUPPORTED;
+    if (d->phase || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->H || d->Wo != d->W) return A3D_ERR_UNSUPPORTED;
+    if (d->stem || d->ups || d->m_dev || d->splitk != 1 || d->res || d->gate || d->pixshuf || d->Cin2 || d->x2) return A3D_ERR_UNSUPPORTED;
+    if ((d->Cin & 31) || d->Kpad != 9 * d->Cin || (d->Cout & 3)) return A3D_ERR_UNSUPPORTED;
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    if (d->tune != 16) {
+        const int tiles_x = (d->W + PP_TW - 1) / PP_TW, tiles_y = (d->H + PP_TH - 1) / PP_TH;
+        if ((long)tiles_x * PP_TW * tiles_y * PP_TH * 10 > (long)d->H * d->W * 14) return A3D_ERR_UNSUPPORTED;  // tiles cover <= 1.4 x the map
     }
-    a3d_note_variant("conv_ph4p_kernel");
-    hipLaunchKernelGGL(conv_ph4p_kernel, dim3(nblk), dim3(512), pp_lds_bytes(), s, *d, tiles_x, tiles_y, ntiles, nblk);
-    return a3d_check_launch();
+    if (d->Cout <= 64) return pp_launch<false, 1>(d, s, "conv_c3p_kernel<1>");
+    if (d->Cout <= 128) return pp_launch<false, 2>(d, s, "conv_c3p_kernel<2>");
+    return pp_launch<false, 4>(d, s, "conv_c3p_kernel<4>");
 }

@@ -192,18 +192,20 @@ H2_CASES = [  # B, H, W, Cin, Cout, k, stride, kwargs, expected kernel
     (6, 30, 40, 256, 1024, 1, 1, {}, "conv_h2_kernel"),
     (5, 30, 40, 1024, 256, 1, 1, {}, "conv_h2_kernel"),
     (4, 61, 79, 128, 128, 3, 2, {}, "conv_h2_kernel"),           # taps, stride, ragged tiles
-    (3, 61, 79, 64, 64, 3, 1, {}, "conv_h2_kernel"),             # a 3x3 s1 layer the 128-wide Winograd tiles do not fit: direct form
+    (3, 61, 79, 64, 64, 3, 1, {}, "conv_c3p_kernel<1>"),         # a 3x3 s1 layer the 128-wide Winograd tiles do not fit: direct form, patch-resident (round 4)
+    (3, 61, 79, 64, 64, 3, 1, dict(tune=10), "conv_h2_kernel"),   # ... and its tap-outer form
     (700, 1, 1, 4096, 1024, 1, 1, dict(tune=9, precision=3), "conv_h2w_kernel"),
     (300, 1, 1, 16384, 1024, 1, 1, dict(splitk=32), "conv_h2w_kernel sk32"),
     (5, 30, 40, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
     (3, 61, 79, 256, 384, 3, 1, {}, "wino_gemm_h2w_kernel"),     # ragged tile / channel blocks
-    (3, 60, 80, 128, 128, 3, 1, {}, "conv_h2_kernel"),           # under 256 input channels: the direct form (ops.conv2d's rule)
+    (3, 60, 80, 128, 128, 3, 1, {}, "conv_c3p_kernel<2>"),       # under 256 input channels: the direct form (ops.conv2d's rule), patch-resident
+    (3, 30, 40, 128, 128, 3, 1, {}, "conv_h2_kernel"),           # ... on a map the 8 x 32 tiles cover badly: the tap-outer kernel
     (3, 60, 80, 128, 128, 3, 1, dict(wino=True), "wino_gemm_h2w_kernel"),
     (70, 14, 14, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
 ]
 
 
-@pytest.mark.parametrize("case", H2_CASES, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}->{c[4]}k{c[5]}s{c[6]}")
+@pytest.mark.parametrize("case", H2_CASES, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}->{c[4]}k{c[5]}s{c[6]}-{c[8].split('<')[0].split(' ')[0]}{'-' + '-'.join(map(str, c[7])) if c[7] else ''}")
 def test_fp16x2_kernels_are_fp32_grade_batch_invariant_and_record_their_maxima(ops, case):
     """The default arithmetic (a3d_conv_desc.precision == 3): x * s = h + l in fp16 with a power-of-two scale per image, three MFMAs
     per k step.  With images 10^6 apart in magnitude in ONE batch: (1) every image's error against float64 is no larger than bf16x3's

@@ -173,7 +173,7 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                     forms = []
                     plain = kind in ("1x1", "3x3", "3x3s2", "linear")
                     # (an explicit tile variant goes with an explicit arithmetic: the mode rules only pick 2 / 3 for tune 0)
-                    own = (mode == 3 and v0.startswith("conv_h2")) or (mode == 2 and v0.startswith("conv_x3"))
+                    own = (mode == 3 and v0.startswith(("conv_h2", "conv_c3p"))) or (mode == 2 and v0.startswith("conv_x3"))
                     if own and plain:
                         forms += [(f"tune {t}", lambda t=t: launch(mode, x, pk, tune=t, precision=mode, **kw)[0]) for t in (9, 10, 11, 12)]
                     if own and mode == 3 and kind == "1x1":
@@ -198,13 +198,21 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                 err = _ref_check(y[..., :n], ref, imgs)
                 if not (err < TOL) or not bool(torch.isfinite(y).all()):
                     problems.append(f"error {err:.2e} vs float64")
+                base = y
+                if v0.startswith("conv_c3p"):  # the patch-resident 3x3 kernel reduces over (chunk, tap): float64 is its yardstick; the
+                    base = None                # tap-outer forms are held to EACH OTHER's bits (the first one that runs is the base)
                 for name, fn in forms:
                     alt, why = _try(fn)
                     note()
                     if alt is None:
                         continue
-                    if not torch.equal(alt, y):
-                        problems.append(f"{name}: bits differ from the dispatcher's ({float((alt - y).abs().max()):.2e})")
+                    if base is None:
+                        base = alt
+                        if float(((alt - y).abs().flatten(1).amax(1) / y.abs().flatten(1).amax(1).clamp_min(1e-30)).max()) > TOL:  # (two fp32-grade sums)
+                            problems.append(f"{name}: more than fp32 rounding away from the patch-resident kernel")
+                        continue
+                    if not torch.equal(alt, base):
+                        problems.append(f"{name}: bits differ from the base form ({float((alt - base).abs().max()):.2e})")
                 if verbose:
                     print(f"[{MODES[mode]:6s}] {desc}: {v0}  err {err:.1e}  {'ok' if not problems else 'FAIL ' + '; '.join(problems)}", flush=True)
                 if problems:
