@@ -19,6 +19,7 @@
 // one contiguous tile row, so its fragment rows are 32 consecutive patch positions for every tap: the 32-byte-row image with the half
 // swizzle by (position >> 3) & 1 is conflict-free at any shift.
 #include "conv_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -40,7 +41,10 @@ __device__ __forceinline__ void pp_dma16(__amdgpu_buffer_rsrc_t r, __bf16 *lds_d
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds_dst, 16, voff, soff, 0, 0);
 }
 
-constexpr int PP_TW = 32, PP_TH = 8, PP_PC = PP_TW + 2, PP_PR = PP_TH + 2, PP_NPOS = PP_PC * PP_PR;  // 340 patch positions
+// Tile shapes: 8 x 32 (a 32-pixel MFMA block = one tile row: its fragment rows are 32 consecutive patch positions at every tap, the
+// conflict-free case) or 16 x 16 (a block = two tile rows: 2-way bank conflicts on some taps' activation reads, but 64 x 80 instead of
+// 64 x 96 pixels cover a 60 x 80 map).  The patch buffers are sized for the larger patch (10 x 34 = 340 positions; 18 x 18 = 324).
+constexpr int PP_NPOS = 340;
 constexpr int PP_ITEMS = PP_NPOS * 4;                       // loader items: (position, channel quad)
 constexpr int PP_LI = (PP_ITEMS + 511) / 512;               // items per thread (3)
 constexpr int PP_XPL = PP_NPOS * 16, PP_XBUF = 2 * PP_XPL;  // 16-bit elements: one plane / one buffer (h | l) of the patch
@@ -75,9 +79,12 @@ constexpr int pp_start(const int tap) {
 // convolution of the fp16x2 arithmetic with NB x 64 output channels per workgroup (the layers the Winograd form does not take: fewer than
 // 256 input channels -- res2 / res3 conv2, pkg/modeling/meta_arch/planercnn.py:150 -> detectron2 BottleneckBlock), same loop, every block
 // live at every tap.
-template <bool PH, int NB>
+template <bool PH, int NB, int TW>
 __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a3d_conv_desc d, const int tiles_x, const int tiles_y, const int ntiles, const int nblk) {
     static_assert(!PH || NB == 4, "the four phases are the four blocks of a wave");
+    constexpr int PP_TW = TW, PP_TH = 256 / TW, PP_PC = PP_TW + 2;
+    constexpr int NPOS_T = PP_PC * (PP_TH + 2), ITEMS_T = NPOS_T * 4;  // positions / loader items of this tile shape
+    static_assert(TW == 32 || TW == 16, "8 x 32 or 16 x 16 tiles");
     constexpr int WCOLS = NB * 32, BN = 2 * WCOLS;  // columns per wave / per workgroup
     constexpr int PP_WPL = pp_wpl(NB), PP_WST = 2 * PP_WPL;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -107,13 +114,13 @@ __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a
 #pragma unroll
     for (int i = 0; i < PP_LI; ++i) {
         const int j = tid + 512 * i;
-        const int pos = min(j >> 2, PP_NPOS - 1), q = j & 3;
+        const int pos = min(j >> 2, NPOS_T - 1), q = j & 3;
         const int py = pos / PP_PC, px = pos - py * PP_PC;
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
-        const bool inb = j < PP_ITEMS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+        const bool inb = j < ITEMS_T && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
         pixoff[i] = inb ? ((b * d.H + y) * d.W + x) * cs4 + q * 16 : -1;
         inmask |= inb ? (1u << i) : 0u;
-        ldsoff[i] = j < PP_ITEMS ? pos * 16 + ((((q >> 1) ^ (pos >> 3)) & 1) << 3) + (q & 1) * 4 : -1;
+        ldsoff[i] = j < ITEMS_T ? pos * 16 + ((((q >> 1) ^ (pos >> 3)) & 1) << 3) + (q & 1) * 4 : -1;
     }
     f32x4 xs[PP_LI];
     auto load_patch = [&](const int c) {  // chunk c of (source 0 || source 1); past the last chunk: zeros (the count of loads stays uniform)
@@ -168,7 +175,10 @@ __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a
     // ---- fragments
     const int frow = lane & 31, khalf = lane >> 5;
     const __bf16 *const fW = Ws + (wn * WCOLS + frow) * 16 + (((khalf ^ (frow >> 3)) & 1) << 3);
-    const int posb0 = (2 * wm) * PP_PC + frow, posb1 = posb0 + PP_PC;
+    // the wave's two 32-pixel blocks: tile rows 2 wm, 2 wm + 1 (8 x 32) or row pairs 4 wm .. 4 wm + 3 (16 x 16: lane = 16 row + column)
+    const int prow = TW == 32 ? 0 : frow >> 4, pcol = TW == 32 ? frow : frow & 15;
+    constexpr int RPB = TW == 32 ? 1 : 2;  // tile rows per block
+    const int posb0 = (2 * RPB * wm + prow) * PP_PC + pcol, posb1 = posb0 + RPB * PP_PC;
     struct FragA {
         pp_bf16x8 p[2];
     };
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a
     const int co_n = d.Cout >> 2;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const int oh = ty0 + 2 * wm + mi, ow = tx0 + frow;
+        const int oh = ty0 + RPB * (2 * wm + mi) + prow, ow = tx0 + pcol;
         if (oh >= d.H || ow >= d.W) continue;
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni) {
@@ -334,19 +344,36 @@ __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a
 
 // A3D_ERR_UNSUPPORTED: tune 15 (the tap-outer form of conv_bf16x3_wide.hip: A/B runs and the bit-equality test against the four-launch
 // form) or a tensor past the 32-bit offsets.  tune 16 = this kernel (the default anyway).
-template <bool PH, int NB>
-static int pp_launch(const a3d_conv_desc *d, hipStream_t s, const char *label) {
-    const int tiles_x = (d->W + PP_TW - 1) / PP_TW, tiles_y = (d->H + PP_TH - 1) / PP_TH;
+// tile shape by the map's size alone: the one that covers fewer pixels (ties: 8 x 32, whose fragment reads are conflict-free)
+static inline long pp_covered(int H, int W, int TW) {
+    const int TH = 256 / TW;
+    return (long)((W + TW - 1) / TW) * TW * ((H + TH - 1) / TH) * TH;
+}
+static inline int pp_tile_width(int H, int W) {
+    static int force = -1;
+    if (force < 0) force = getenv("A3D_PP_TW") ? atoi(getenv("A3D_PP_TW")) : 0;  // (A/B runs: 16 | 32)
+    if (force == 16 || force == 32) return force;
+    return pp_covered(H, W, 16) < pp_covered(H, W, 32) ? 16 : 32;
+}
+
+template <bool PH, int NB, int TW>
+static int pp_launch_t(const a3d_conv_desc *d, hipStream_t s, const char *label) {
+    constexpr int TH = 256 / TW;
+    const int tiles_x = (d->W + TW - 1) / TW, tiles_y = (d->H + TH - 1) / TH;
     const int ntiles = (d->Cout + 64 * NB - 1) / (64 * NB);
     const int nblk = d->B * tiles_x * tiles_y * ntiles;
     static a3d_attr_once attr;
     if (attr.needed()) {
-        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel<PH, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(NB)) != hipSuccess) return A3D_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel<PH, NB, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(NB)) != hipSuccess) return A3D_ERR_LAUNCH;
         attr.mark();
     }
-    a3d_note_variant("%s", label);
-    hipLaunchKernelGGL((conv_ph4p_kernel<PH, NB>), dim3(nblk), dim3(512), pp_lds_bytes(NB), s, *d, tiles_x, tiles_y, ntiles, nblk);
+    a3d_note_variant("%s%d>", label, TW);  // ("conv_ph4p_kernel<16>", "conv_c3p_kernel<2, 32>": the tile width is part of the name rocprofv3 shows)
+    hipLaunchKernelGGL((conv_ph4p_kernel<PH, NB, TW>), dim3(nblk), dim3(512), pp_lds_bytes(NB), s, *d, tiles_x, tiles_y, ntiles, nblk);
     return a3d_check_launch();
+}
+template <bool PH, int NB>
+static int pp_launch(const a3d_conv_desc *d, hipStream_t s, const char *label) {
+    return pp_tile_width(d->H, d->W) == 16 ? pp_launch_t<PH, NB, 16>(d, s, label) : pp_launch_t<PH, NB, 32>(d, s, label);
 }
 
 int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s) {
@@ -358,10 +385,11 @@ int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s) {
     if ((d->Cin & 15) || (CinT & 31) || d->Kpad != 9 * CinT || (d->Cout & 127)) return A3D_ERR_ARG;
     if (d->tune == 15) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
-    // (Measured at 64 frames, tap-outer | this kernel, tools/ups_bench.py: 8x10 0.078 | 0.060 ms, 15x20 0.142 | 0.115, 30x40 0.403 | 0.400, 60x80
-    // 1.351 | 1.168, 120x160 2.825 | 1.931 -- ahead or level on every map of the decoder, also where its 8 x 32 tiles cover 1.3-3 x the map:
-    // every phase-5 launch takes it.  The two forms differ in their reduction order, so the choice may never depend on the batch.)
-    return pp_launch<true, 4>(d, s, "conv_ph4p_kernel");
+    // (Measured at 64 frames, tap-outer | this kernel, tools/ups_bench.py: 8x10 0.078 | 0.060 ms, 15x20 0.142 | 0.115, 30x40 0.403 | 0.326, 60x80
+    // 1.351 | 1.045, 120x160 2.825 | 1.931 -- ahead on every map of the decoder, also where its tiles cover 1.3-3 x the map: every phase-5
+    // launch takes it (16 x 16 tiles where they cover fewer pixels than 8 x 32: the 30x40 and 60x80 stages).  The two forms differ in
+    // their reduction order, so the choice may never depend on the batch.)
+    return pp_launch<true, 4>(d, s, "conv_ph4p_kernel<");
 }
 
 // The plain 3x3 stride-1 pad-1 layers of the fp16x2 arithmetic that stay in the direct form (fewer than 256 input channels: res2 / res3
@@ -374,11 +402,10 @@ int a3d_conv_launch_c3p(const a3d_conv_desc *d, hipStream_t s) {
     if (d->stem || d->ups || d->m_dev || d->splitk != 1 || d->res || d->gate || d->pixshuf || d->Cin2 || d->x2) return A3D_ERR_UNSUPPORTED;
     if ((d->Cin & 31) || d->Kpad != 9 * d->Cin || (d->Cout & 3)) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
-    if (d->tune != 16) {
-        const int tiles_x = (d->W + PP_TW - 1) / PP_TW, tiles_y = (d->H + PP_TH - 1) / PP_TH;
-        if ((long)tiles_x * PP_TW * tiles_y * PP_TH * 10 > (long)d->H * d->W * 14) return A3D_ERR_UNSUPPORTED;  // tiles cover <= 1.4 x the map
-    }
-    if (d->Cout <= 64) return pp_launch<false, 1>(d, s, "conv_c3p_kernel<1>");
-    if (d->Cout <= 128) return pp_launch<false, 2>(d, s, "conv_c3p_kernel<2>");
-    return pp_launch<false, 4>(d, s, "conv_c3p_kernel<4>");
+    // (measured at 64 frames, tap-outer | this kernel: 120x160 64 -> 64 0.465 | 0.30-0.32 ms, 60x80 128 -> 128 0.340 | 0.320, 120x160 128 -> 256
+    // 2.03 | 1.81; 30x40 128 -> 128, whose tiles cover 1.28 x the map, 0.111 | 0.124-0.136: the tiles must cover at most 1.2 x the map)
+    if (d->tune != 16 && pp_covered(d->H, d->W, pp_tile_width(d->H, d->W)) * 10 > (long)d->H * d->W * 12) return A3D_ERR_UNSUPPORTED;
+    if (d->Cout <= 64) return pp_launch<false, 1>(d, s, "conv_c3p_kernel<1, ");
+    if (d->Cout <= 128) return pp_launch<false, 2>(d, s, "conv_c3p_kernel<2, ");
+    return pp_launch<false, 4>(d, s, "conv_c3p_kernel<4, ");
 }

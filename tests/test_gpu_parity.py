@@ -192,13 +192,13 @@ H2_CASES = [  # B, H, W, Cin, Cout, k, stride, kwargs, expected kernel
     (6, 30, 40, 256, 1024, 1, 1, {}, "conv_h2_kernel"),
     (5, 30, 40, 1024, 256, 1, 1, {}, "conv_h2_kernel"),
     (4, 61, 79, 128, 128, 3, 2, {}, "conv_h2_kernel"),           # taps, stride, ragged tiles
-    (3, 61, 79, 64, 64, 3, 1, {}, "conv_c3p_kernel<1>"),         # a 3x3 s1 layer the 128-wide Winograd tiles do not fit: direct form, patch-resident (round 4)
+    (3, 61, 79, 64, 64, 3, 1, {}, "conv_c3p_kernel<1, 16>"),     # a 3x3 s1 layer the 128-wide Winograd tiles do not fit: direct form, patch-resident (round 4)
     (3, 61, 79, 64, 64, 3, 1, dict(tune=10), "conv_h2_kernel"),   # ... and its tap-outer form
     (700, 1, 1, 4096, 1024, 1, 1, dict(tune=9, precision=3), "conv_h2w_kernel"),
     (300, 1, 1, 16384, 1024, 1, 1, dict(splitk=32), "conv_h2w_kernel sk32"),
     (5, 30, 40, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
     (3, 61, 79, 256, 384, 3, 1, {}, "wino_gemm_h2w_kernel"),     # ragged tile / channel blocks
-    (3, 60, 80, 128, 128, 3, 1, {}, "conv_c3p_kernel<2>"),       # under 256 input channels: the direct form (ops.conv2d's rule), patch-resident
+    (3, 60, 80, 128, 128, 3, 1, {}, "conv_c3p_kernel<2, 16>"),   # under 256 input channels: the direct form (ops.conv2d's rule), patch-resident
     (3, 30, 40, 128, 128, 3, 1, {}, "conv_h2_kernel"),           # ... on a map the 8 x 32 tiles cover badly: the tap-outer kernel
     (3, 60, 80, 128, 128, 3, 1, dict(wino=True), "wino_gemm_h2w_kernel"),
     (70, 14, 14, 256, 256, 3, 1, {}, "wino_gemm_h2w_kernel"),
@@ -630,7 +630,7 @@ def test_fused_upsampled_conv_equals_the_four_phase_launches(ops, case):
     assert one.shape == (B, 2 * H, 2 * W, Cout)
     assert torch.equal(one, four) and torch.equal(one._a3d_amax, four._a3d_amax)
     dflt = ops.conv2d_ups(a, phases, x2=c2)  # the default since round 4: the patch-resident kernel (another reduction order: fp32 rounding)
-    assert ops.last_conv_variant() == "conv_ph4p_kernel", ops.last_conv_variant()
+    assert ops.last_conv_variant().startswith("conv_ph4p_kernel<"), ops.last_conv_variant()
     for i in range(B):
         assert float((dflt[i] - one[i]).abs().max() / one[i].abs().max()) < 2e-6
     xin = a if c2 is None else torch.cat([a, c2], 3)

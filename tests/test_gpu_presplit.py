@@ -194,7 +194,7 @@ def test_patch_resident_upsampled_conv_matches_the_tap_outer_form(ops, case):
     y_old = ops.conv2d_ups(x, phases, x2=x2, tune=15)
     assert ops.last_conv_variant() == "conv_h2w_kernel ph4", ops.last_conv_variant()
     y_new = ops.conv2d_ups(x, phases, x2=x2, tune=c["tune"])
-    assert ops.last_conv_variant() == "conv_ph4p_kernel", ops.last_conv_variant()
+    assert ops.last_conv_variant().startswith("conv_ph4p_kernel<"), ops.last_conv_variant()
     scale = y_old.abs().flatten(1).amax(1).clamp_min(1e-30).view(-1, 1, 1, 1)
     assert float(((y_new - y_old).abs() / scale).max()) < 2e-6
     assert torch.allclose(ops.amax_of(y_new), ops.amax_of(y_old), rtol=2e-6, atol=0)

@@ -159,7 +159,7 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                     y = ops.conv2d_ups(x, phases, x2=x2)
                     v0 = note()
                     forms = []
-                    if mode == 3 and v0 == "conv_ph4p_kernel":  # the patch-resident kernel reduces in another order: held to float64 only;
+                    if mode == 3 and v0.startswith("conv_ph4p_kernel"):  # the patch-resident kernel reduces in another order: held to float64 only;
                         t15, _ = _try(lambda: ops.conv2d_ups(x, phases, x2=x2, tune=15))  # the tap-outer form claims the four-launch bits
                         note()
                         f4 = ops.conv2d_ups(x, phases, x2=x2, fused=False)
