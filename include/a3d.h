@@ -94,7 +94,10 @@ typedef struct a3d_conv_desc {
                          9 = the wide direct kernel whatever the problem size, 10 / 11 = its narrow kernel with 128 x 64 /
                          128 x 128 tiles, 12 = per-lane accumulator stores instead of the row-major epilogue through LDS (the
                          same bits; A/B runs); precision 3: 13 / 14 = always / never the activation-stationary pointwise kernel on an
-                         eligible 1x1 layer (Cin 64 / 128 / 256, Cout % 128 == 0; the same bits); >= 100: explicit tile variant */
+                         eligible 1x1 layer (Cin 64 / 128 / 256, Cout % 128 == 0; the same bits); 15 / 16 = the tap-outer / the patch-resident
+                         form of a 3x3 s1 p1 layer (phase 5: every launch is patch-resident by default, 15 is the bit-equality link to
+                         the four-launch form; phase 0: 16 forces the patch-resident kernel on a layer whose map its tiles fit badly;
+                         the two forms reduce in different orders: equal to fp32 rounding, not bit for bit); >= 100: explicit tile variant */
     int phase;        /* 0, or 1..4 = output phase (dy,dx) = ((phase-1)>>1, (phase-1)&1) of a 3x3 pad-1 convolution over a
                          nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
                          taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
