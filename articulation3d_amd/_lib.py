@@ -230,6 +230,7 @@ SIGNATURES = {
     # training step
     "a3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "a3d_conv_wgrad_nhwc_f32": (C.c_int, [C.POINTER(WgradDesc), fptr]),
+    "a3d_wgrad_tiles": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "a3d_weight_transpose": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_weight_transpose_batch": (C.c_int, [fptr, C.c_int, C.c_int, fptr]),
     "a3d_wgrad_reduce_batch": (C.c_int, [fptr, C.c_int, fptr]),

@@ -354,6 +354,10 @@ int wgrad_check(const a3d_wgrad_desc *d) {
 }
 }  // namespace
 
+// conv_wgrad_tr.hip: the transposed-read form of the bf16 arithmetic (0 = not a layer of that form)
+int a3d_wgrad_tr_form(const a3d_wgrad_desc *d);
+int a3d_wgrad_launch_tr(const a3d_wgrad_desc *d, hipStream_t s);
+
 extern "C" size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d) {
     if (!d || d->splitk < 1) return 0;
     return (size_t)d->splitk * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
@@ -376,7 +380,10 @@ extern "C" int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream) {
     if (d->precision == 1 || d->precision == 2) {
         if ((size_t)P * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
         const dim3 grid(mtiles * ntiles * d->KH * d->KW, d->splitk);
-        if (d->precision == 1) {
+        if (d->precision == 1 && a3d_wgrad_tr_form(d)) {
+            const int rt = a3d_wgrad_launch_tr(d, s);
+            if (rt != A3D_OK) return rt;
+        } else if (d->precision == 1) {
             switch (d->io_bf16) {
             case 1: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 1>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;
             case 2: hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false, 2>), grid, dim3(256), 0, s, *d, P, mtiles, ntiles, chunk); break;

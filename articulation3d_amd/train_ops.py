@@ -72,11 +72,18 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     d.x, d.dy, d.scale, d.dw = _p(x), _p(dy), _p(scale), _p(dw)
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    tiles = ((Cout + 127) // 128) * ((Cin + 127) // 128) * KH * KW
-    d.splitk = int(splitk) if splitk else choose_wgrad_slices(B * Ho * Wo, tiles)
     d.accumulate = int(accumulate)
     d.precision = int(precision)
     d.io_bf16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if dy.dtype == torch.bfloat16 else 0)
+    d.splitk = 1
+    tiles, red = C.c_int(0), C.c_int(0)
+    form = _lib.lib().a3d_wgrad_tiles(C.byref(d), C.byref(tiles), C.byref(red))  # the kernel form the library runs this layer on
+    if splitk:
+        d.splitk = int(splitk)
+    elif form > 0:  # transposed-read form (one 512-thread workgroup per CU, 64-pixel chunks): two rounds of the chip, >= 8 chunks per slice
+        d.splitk = int(max(1, min(512 // max(tiles.value, 1), red.value // 512, 256)))
+    else:
+        d.splitk = choose_wgrad_slices(B * Ho * Wo, tiles.value)
     nbytes = _lib.lib().a3d_wgrad_workspace_bytes(C.byref(d))
     if defer is not None and not accumulate:
         ws = defer.workspace(dw, nbytes)
@@ -98,6 +105,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
         e1.record()
         fl = 2.0 * B * Ho * Wo * Cout * KH * KW * Cin  # the pixel-reduction GEMM dY^T . X per tap = the layer's forward FLOPs
         label = {0: "conv_wgrad_kernel", 1: f"conv_wgrad_bf16_kernel<false, {d.io_bf16}>", 2: "conv_wgrad_bf16_kernel<true, 0>"}[int(precision)]
+        if form > 0:
+            label = f"conv_wgrad_tr_kernel<{form}, {d.io_bf16}>"
         _ops.CONV_TIMING.append((label, fl, e0, e1, f"{B}x{H}x{W}x{Cin}->{Cout} k{KH} s{stride} wgrad sk{d.splitk}", fl,
                                  {0: "f32", 1: "bf16", 2: "bf16x6"}[int(precision)], _stream()))
         return dw

@@ -418,6 +418,10 @@ typedef struct a3d_wgrad_desc {
 } a3d_wgrad_desc;
 size_t a3d_wgrad_workspace_bytes(const a3d_wgrad_desc *d);
 int a3d_conv_wgrad_nhwc_f32(const a3d_wgrad_desc *d, void *stream);
+/* Workgroup tiles of ONE pixel slice and the length of the pixel reduction of the kernel form the library runs this descriptor on (round 4: the
+ * bf16 arithmetic has two forms -- csrc/conv_wgrad_tr.hip takes the stride-1 3x3 pad-1 and 1x1 layers with three taps / 256 input channels per
+ * workgroup): what a caller sizes `splitk` by.  Returns the form (0: first form, 1 / 3: taps per workgroup of the second) or a negative error. */
+int a3d_wgrad_tiles(const a3d_wgrad_desc *d, int *tiles, int *reduction);
 /* The slice reduction of n deferred weight-gradient launches in ONE launch (round 4: at the reference's 2 images per GPU the 63 per-layer
  * reduce launches of a training step were 17 us of latency each, 11 % of the step).  table: DEVICE array of n a3d_wgrad_desc whose
  * workspace / scale / dw / Cout / KH / KW / Cin / splitk fields are read (x, dy are not).  Every layer: dw = scale * sum over slices

@@ -474,8 +474,11 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("c", [dict(B=2, H=30, W=40, Cin=256, Cout=128, k=1, s=1, p=0), dict(B=2, H=30, W=40, Cin=256, Cout=512, k=1, s=2, p=0),
-                               dict(B=2, H=15, W=20, Cin=128, Cout=192, k=3, s=1, p=1), dict(B=700, H=1, W=1, Cin=1024, Cout=32, k=1, s=1, p=0)],
-                         ids=lambda c: f"{c['Cin']}to{c['Cout']}k{c['k']}s{c['s']}")
+                               dict(B=2, H=15, W=20, Cin=128, Cout=192, k=3, s=1, p=1), dict(B=700, H=1, W=1, Cin=1024, Cout=32, k=1, s=1, p=0),
+                               # (round 4: the transposed-read weight-gradient form -- ragged channel tiles, several chunks and slices, 256-wide ci tile)
+                               dict(B=3, H=31, W=39, Cin=160, Cout=136, k=3, s=1, p=1), dict(B=2, H=60, W=80, Cin=256, Cout=256, k=3, s=1, p=1),
+                               dict(B=5, H=23, W=17, Cin=320, Cout=72, k=1, s=1, p=0)],
+                         ids=lambda c: f"{c['B']}x{c['H']}x{c['Cin']}to{c['Cout']}k{c['k']}s{c['s']}")
 def test_bf16_conv_and_wgrad_kernels(T, ops, c):
     """precision=1: operands rounded to bf16 (nearest-even), products accumulated in fp32 -- against float64 convolutions of the
     SAME bf16-rounded operands (what remains is fp32 accumulation noise), with bias / ReLU / residual / gate fused."""

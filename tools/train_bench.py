@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--storage", default=None, choices=["fp32", "bf16"], help="res3-res5 activations / gradients in HBM (default: bf16 in the bf16 step)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
                     help="bf16 = autocast arithmetic (bf16 MFMA, fp32 accumulate); bf16x3 = fp32-grade 3-way bf16 split on the non-Winograd layers")
+    ap.add_argument("--layers", action="store_true", help="per-launch table of the instrumented step on stderr (developer tool)")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE oracle step (autograd on the host cores)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,10 @@ def main():
     tr.step(frames, gtb, gtc)
     barrier()
     events, ops.CONV_TIMING = ops.CONV_TIMING, None
+    if args.layers and rank == 0:
+        for name, fl, a, b, shape, ex, pipe, _st in events:
+            ms = a.elapsed_time(b)
+            print(f"{name[:40]:40s} {shape:52s} {ex / 1e9:9.2f} GF {ms:8.3f} ms {ex / ms / 1e9 if ms > 0 else 0:8.1f} TF/s", file=sys.stderr)
     per = kernel_sums(events)
     step_sec = elapsed / args.steps
     roofline = dominant_roofline(per, step_sec)
