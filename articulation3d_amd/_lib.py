@@ -240,6 +240,8 @@ SIGNATURES = {
     "a3d_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
     "a3d_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_roi_align_fpn_backward": (C.c_int, [C.POINTER(RoiAlignBwdDesc), fptr]),
+    "a3d_roi_align_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(RoiAlignBwdDesc)]),
+    "a3d_roi_align_fpn_backward_gather": (C.c_int, [C.POINTER(RoiAlignBwdDesc), fptr, fptr]),
     "a3d_match_boxes": (C.c_int, [C.POINTER(MatchDesc), fptr]),
     "a3d_loss_workspace_bytes": (C.c_size_t, []),
     "a3d_rpn_loss": (C.c_int, [C.POINTER(RpnLossDesc), fptr]),

@@ -3,12 +3,16 @@ carry device memory only, all arithmetic happens in liba3d_hip.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib
 from .ops import _p, _req, _stream
+
+
+ROI_BWD_GATHER = os.environ.get("A3D_ROI_BWD_GATHER", "1") != "0"
 
 
 def choose_wgrad_slices(P: int, tiles: int) -> int:
@@ -178,8 +182,9 @@ def colsum(dy: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> tor
 
 def roi_align_fpn_backward(dfeats: Sequence[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, dout: torch.Tensor, *,
                            P: int, sampling_ratio: int, aligned: bool, count: Optional[torch.Tensor] = None,
-                           row_offset: Optional[torch.Tensor] = None) -> None:
-    """dfeats[l] [B,Hf,Wf,C] += gradient of roi_align_fpn with respect to level l.  boxes [B,R,4], dout [rows,P,P,C]."""
+                           row_offset: Optional[torch.Tensor] = None, scatter: bool = False) -> None:
+    """dfeats[l] [B,Hf,Wf,C] += gradient of roi_align_fpn with respect to level l.  boxes [B,R,4], dout [rows,P,P,C].
+    scatter=True (or A3D_ROI_BWD_GATHER=0): the float-atomics form (run-to-run summation order)."""
     d = _lib.RoiAlignBwdDesc()
     for l, f in enumerate(dfeats):
         _req(f)
@@ -188,6 +193,12 @@ def roi_align_fpn_backward(dfeats: Sequence[torch.Tensor], scales: Sequence[floa
     d.boxes, d.count, d.row_offset = _p(_req(boxes)), _p(count), _p(row_offset)
     d.B, d.R, d.P, d.sampling_ratio, d.aligned = boxes.shape[0], boxes.shape[1], P, sampling_ratio, int(aligned)
     d.dout = _p(_req(dout))
+    if ROI_BWD_GATHER and not scatter:  # tile-gather form: no atomics, fixed summation order (csrc/roi_align.hip)
+        ws = torch.empty(max(1, _lib.lib().a3d_roi_align_bwd_workspace_bytes(C.byref(d)) // 4), device=boxes.device, dtype=torch.int32)
+        rc = _lib.lib().a3d_roi_align_fpn_backward_gather(C.byref(d), ws.data_ptr(), _stream())
+        if rc != -3:  # (A3D_ERR_UNSUPPORTED -- P > 7 or C > 256: the scatter form below)
+            _lib.check(rc, "a3d_roi_align_fpn_backward_gather")
+            return
     _lib.check(_lib.lib().a3d_roi_align_fpn_backward(C.byref(d), _stream()), "a3d_roi_align_fpn_backward")
 
 

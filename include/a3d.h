@@ -466,6 +466,11 @@ typedef struct a3d_roialign_bwd_desc {
     const float *dout;     /* [rows,P,P,C] */
 } a3d_roialign_bwd_desc;
 int a3d_roi_align_fpn_backward(const a3d_roialign_bwd_desc *d, void *stream);
+/* The same gradient WITHOUT atomics (round 4): the pyramid in 8 x 8-cell tiles, a bit per (image, tile, ROI slot) marked by a first launch,
+ * one workgroup per tile that sums its ROIs in slot order in LDS and adds the tile to dfeat once -- bit-reproducible, ~8 x fewer bytes
+ * to memory.  workspace: a3d_roi_align_bwd_workspace_bytes(d) bytes (zeroed by the call). */
+size_t a3d_roi_align_bwd_workspace_bytes(const a3d_roialign_bwd_desc *d);
+int a3d_roi_align_fpn_backward_gather(const a3d_roialign_bwd_desc *d, void *workspace, void *stream);
 
 /* detectron2 Matcher over pairwise_iou(gt, boxes) (RPN.label_and_sample_anchors, ROIHeads.label_and_sample_proposals):
  * matched_idx[b,i] = argmax_g IoU (first maximum), label[b,i] = labels[k] for IoU in [thresholds[k-1], thresholds[k]),

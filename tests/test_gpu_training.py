@@ -163,6 +163,24 @@ def test_roi_align_backward_vs_oracle(T, oracle):
                              sampling_ratio=0, aligned=True)
     for d, f in zip(dfe, feats.values()):
         assert l2rel(d, nhwc(f.grad)) < 1e-5
+    # round 4: the default is the tile-gather form (no atomics): fixed summation order -> two runs agree bit for bit, it ADDS to what
+    # dfeat holds, and it agrees with the float-atomics form to fp32 rounding; live counts and compact rows as the forward pooler's
+    args = ([1 / 4, 1 / 8, 1 / 16, 1 / 32], boxes.cuda(), nhwc(dout).contiguous().cuda())
+    again = [torch.ones_like(d) for d in dfe]
+    T.roi_align_fpn_backward(again, *args, P=7, sampling_ratio=0, aligned=True)
+    scat = [torch.zeros_like(d) for d in dfe]
+    T.roi_align_fpn_backward(scat, *args, P=7, sampling_ratio=0, aligned=True, scatter=True)
+    for d, a2, sc in zip(dfe, again, scat):
+        assert torch.equal(a2 - 1.0, (d + 1.0) - 1.0)
+        assert l2rel(d, sc) < 1e-6
+    count = torch.tensor([20, 0], dtype=torch.int32, device="cuda")
+    off = torch.tensor([0, 20], dtype=torch.int32, device="cuda")
+    rows = nhwc(dout).contiguous().cuda()[:20].contiguous()
+    part, part_s = [torch.zeros_like(d) for d in dfe], [torch.zeros_like(d) for d in dfe]
+    T.roi_align_fpn_backward(part, args[0], args[1], rows, P=7, sampling_ratio=0, aligned=True, count=count, row_offset=off)
+    T.roi_align_fpn_backward(part_s, args[0], args[1], rows, P=7, sampling_ratio=0, aligned=True, count=count, row_offset=off, scatter=True)
+    for a2, sc in zip(part, part_s):
+        assert float(a2[1].abs().max()) == 0.0 and l2rel(a2, sc) < 1e-6
 
 
 def test_matcher_bit_exact_vs_oracle(T, oracle):
