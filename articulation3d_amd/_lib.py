@@ -239,6 +239,7 @@ SIGNATURES = {
     "a3d_sumpool2_add_nhwc": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_colsum_workspace_bytes": (C.c_size_t, [C.c_int]),
     "a3d_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
+    "a3d_colsum_bf16": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_roi_align_fpn_backward": (C.c_int, [C.POINTER(RoiAlignBwdDesc), fptr]),
     "a3d_roi_align_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(RoiAlignBwdDesc)]),
     "a3d_roi_align_fpn_backward_gather": (C.c_int, [C.POINTER(RoiAlignBwdDesc), fptr, fptr]),

@@ -218,24 +218,35 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
 // (C % 4 == 0: a lane owns 4 channels and keeps four independent 16-byte loads in flight -- the scalar form above ran the wide layers'
 // 315 MB gradients at 0.7 TB/s, 2.5 ms of a 31 ms step at 16 images; fixed summation order: rows r, r+16, .. per accumulator, then
 // ((a0 + a1) + (a2 + a3)), the 4 row phases as above)
-__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float *__restrict__ dy, float *__restrict__ ws, int M, int C, int rows_per) {
+template <bool BF>  // BF: dy is stored as bf16 (widening is exact: the same sums as on the widened values)
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const void *__restrict__ dyv, float *__restrict__ ws, int M, int C, int rows_per) {
     const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int sub = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    auto ld = [&](const int r) -> f32x4 {
+        if constexpr (BF) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(dyv) + (size_t)r * C + c);
+            f32x4 v;
+            v[0] = __uint_as_float(q.x << 16);
+            v[1] = __uint_as_float(q.x & 0xFFFF0000u);
+            v[2] = __uint_as_float(q.y << 16);
+            v[3] = __uint_as_float(q.y & 0xFFFF0000u);
+            return v;
+        } else {
+            return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(dyv) + (size_t)r * C + c);
+        }
+    };
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (c < C) {
         int r = r0 + sub;
         for (; r + 12 < r1; r += 16) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(dy + (size_t)r * C + c);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(dy + (size_t)(r + 4) * C + c);
-            const f32x4 v2 = *reinterpret_cast<const f32x4 *>(dy + (size_t)(r + 8) * C + c);
-            const f32x4 v3 = *reinterpret_cast<const f32x4 *>(dy + (size_t)(r + 12) * C + c);
+            const f32x4 v0 = ld(r), v1 = ld(r + 4), v2 = ld(r + 8), v3 = ld(r + 12);
             a0 += v0;
             a1 += v1;
             a2 += v2;
             a3 += v3;
         }
-        for (; r < r1; r += 4) a0 += *reinterpret_cast<const f32x4 *>(dy + (size_t)r * C + c);
+        for (; r < r1; r += 4) a0 += ld(r);
     }
     const f32x4 s = (a0 + a1) + (a2 + a3);
     __shared__ f32x4 red[4][64];
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float *__res
 
 #define A3D_COLSUM_SLICES 256
 extern "C" size_t a3d_colsum_workspace_bytes(int C) { return (size_t)A3D_COLSUM_SLICES * C * sizeof(float); }
-extern "C" int a3d_colsum(const float *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream) {
+static int colsum_launch(const void *dy, bool bf, float *out, float *workspace, int M, int C, int accumulate, void *stream) {
     if (!dy || !out || !workspace || M <= 0 || C <= 0) return A3D_ERR_ARG;
     // slices: ~512 rows each, between 32 and the workspace's 256 (the second stage adds them one after the other)
     int want = M / 512;
@@ -255,12 +266,21 @@ extern "C" int a3d_colsum(const float *dy, float *out, float *workspace, int M, 
     const int rows_per = (M + want - 1) / want;
     const int slices = (M + rows_per - 1) / rows_per;
     a3d_begin();
-    if ((C & 3) == 0 && (reinterpret_cast<size_t>(dy) & 15) == 0)
-        hipLaunchKernelGGL(colsum_partial4_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
+    if (bf) {
+        if ((C & 3) || (reinterpret_cast<size_t>(dy) & 7)) return A3D_ERR_ARG;
+        hipLaunchKernelGGL(colsum_partial4_kernel<true>, dim3((C + 255) / 256, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
+    } else if ((C & 3) == 0 && (reinterpret_cast<size_t>(dy) & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial4_kernel<false>, dim3((C + 255) / 256, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, (hipStream_t)stream, dy, workspace, M, C, rows_per);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, (hipStream_t)stream, (const float *)dy, workspace, M, C, rows_per);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, workspace, out, C, slices, accumulate);
     return a3d_check_launch();
+}
+extern "C" int a3d_colsum(const float *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream) {
+    return colsum_launch(dy, false, out, workspace, M, C, accumulate, stream);
+}
+extern "C" int a3d_colsum_bf16(const void *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream) {
+    return colsum_launch(dy, true, out, workspace, M, C, accumulate, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -464,6 +464,14 @@ def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, prec
     d.precision = 1
     b16 = lambda t: t is not None and t.dtype == torch.bfloat16
     d.io_bf16 = (1 if b16(x) else 0) | (2 if b16(out) else 0) | (4 if b16(res) else 0) | (8 if b16(gate) else 0)
+    if CONV_TIMING is not None:  # (tools/train_bench.py's roofline leg: these launches carry most of the bf16 step's FLOPs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+        e1.record()
+        fl = 2.0 * B * Ho * Wo * p.cols * p.KH * p.KW * p.Cin
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, f"{B}x{H}x{W}x{Cin}->{p.cols} k{p.KH} s{p.stride} io{int(d.io_bf16)}", fl, "bf16", _stream()))
+        return out
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
     return out
 

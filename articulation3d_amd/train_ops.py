@@ -176,6 +176,9 @@ def colsum(dy: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> tor
     M = dy.numel() // Cc
     assert _req(out).numel() >= Cc
     ws = torch.empty(_lib.lib().a3d_colsum_workspace_bytes(Cc) // 4, device=dy.device, dtype=torch.float32)
+    if dy.dtype == torch.bfloat16:  # (bf16-stored gradients of the bf16 step: exact widening, the same sums)
+        _lib.check(_lib.lib().a3d_colsum_bf16(_p(_req(dy, torch.bfloat16)), _p(out), _p(ws), M, Cc, int(accumulate), _stream()), "a3d_colsum_bf16")
+        return out
     _lib.check(_lib.lib().a3d_colsum(_p(_req(dy)), _p(out), _p(ws), M, Cc, int(accumulate), _stream()), "a3d_colsum")
     return out
 

@@ -21,7 +21,8 @@ Design (MI355X-first, no autograd engine):
     index sets back and hand them to the oracle.
 Precision: fp32-grade ("bf16x3") by default; `precision="fp32"` is the fp32-input MFMA; `precision="bf16"` is the reference config's autocast arithmetic (bf16 MFMA, fp32 accumulation,
 fp32 master weights) on every trainable layer, with the ResNet stages' activations and gradients STORED as bf16 (round 3:
-a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16; `storage="fp32"` keeps them fp32) and a bf16 gradient all-reduce payload.
+a3d_conv_desc.io_bf16 / a3d_wgrad_desc.io_bf16; `storage="fp32"` keeps them fp32) -- since round 4 also the FPN lateral sums, the RPN
+hidden maps, the box head's hidden rows and the gradients flowing back through them -- and a bf16 gradient all-reduce payload.
 """
 from __future__ import annotations
 
@@ -366,16 +367,20 @@ class DetectorTrainer:
             res[name] = x
         # ---- FPN
         prev, feats = {}, {}
-        prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd())
+        # (bf16 storage, round 4: the lateral sums, the RPN hidden maps, the box head's hidden rows and the gradients flowing back through
+        # them are stored as bf16 too -- what torch.autocast keeps of them; the pyramid p2..p6 itself stays fp32: the pooler and the proposal
+        # decoder read it, and its gradient is accumulated from two branches)
+        st = self._st
+        prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd(), out_dtype=st)
         feats["p5"] = self._conv(prev[5], L["backbone.fpn_output5"].fwd())
         for l in (4, 3, 2):
-            prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True)
+            prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True, out_dtype=st)
             feats[f"p{l}"] = self._conv(prev[l], L[f"backbone.fpn_output{l}"].fwd())
         feats["p6"] = ops.subsample2(feats["p5"])
         names = ("p2", "p3", "p4", "p5", "p6")
         # ---- RPN head
         rp = "proposal_generator.rpn_head."
-        t = [self._conv(feats[n], L[rp + "conv"].fwd()) for n in names]
+        t = [self._conv(feats[n], L[rp + "conv"].fwd(), out_dtype=st) for n in names]
         heads = [self._conv(ti, L[rp + "pred"].fwd()) for ti in t]
         feat_hw = [tuple(feats[n].shape[1:3]) for n in names]
         anchors = self._anchors(feat_hw)
@@ -432,8 +437,8 @@ class DetectorTrainer:
         pooled = ops.roi_align_fpn(pyr, scales, roi_boxes, rcount_d, 7, 0, True, zero=True)
         bh, bp = "roi_heads.box_head.", "roi_heads.box_predictor."
         xrow = pooled.view(M, 1, 1, 49 * 256)
-        h1 = self._conv(xrow, L[bh + "fc1"].fwd())
-        h2 = self._conv(h1, L[bh + "fc2"].fwd())
+        h1 = self._conv(xrow, L[bh + "fc1"].fwd(), out_dtype=st)
+        h2 = self._conv(h1, L[bh + "fc2"].fwd(), out_dtype=st)
         pred = self._conv(h2, L[bp + "pred"].fwd())
         box_l, dpred = T.box_loss(pred.view(M, 32), roi_cls.view(M), roi_boxes.view(M, 4), roi_gt.view(M, 4), num_classes=s.num_classes,
                                   weights=s.box_weights, count=rcount_d, rows_per_image=Rs)
@@ -442,9 +447,9 @@ class DetectorTrainer:
         # ======================================== backward ========================================
         dpred = dpred.view(M, 1, 1, 32)
         self._wgrad(L[bp + "pred"], h2, dpred)
-        dh2 = self._conv(dpred, L[bp + "pred"].bwd(), gate=h2)
+        dh2 = self._conv(dpred, L[bp + "pred"].bwd(), gate=h2, out_dtype=st)
         self._wgrad(L[bh + "fc2"], h1, dh2)
-        dh1 = self._conv(dh2, L[bh + "fc2"].bwd(), gate=h1)
+        dh1 = self._conv(dh2, L[bh + "fc2"].bwd(), gate=h1, out_dtype=st)
         self._wgrad(L[bh + "fc1"], xrow, dh1)
         dpooled = self._conv(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
         dP = {n: torch.zeros_like(feats[n]) for n in ("p2", "p3", "p4", "p5")}
@@ -452,7 +457,7 @@ class DetectorTrainer:
                                  sampling_ratio=0, aligned=True, count=rcount_d)
         # ---- RPN head backward (weights shared by the five levels: gradients accumulate in level order)
         for li, n in enumerate(names):
-            dt = self._conv(dheads[li], L[rp + "pred"].bwd(), gate=t[li])
+            dt = self._conv(dheads[li], L[rp + "pred"].bwd(), gate=t[li], out_dtype=st)
             self._wgrad(L[rp + "pred"], t[li], dheads[li], accumulate=li > 0)
             self._wgrad(L[rp + "conv"], feats[n], dt, accumulate=li > 0)
             if n == "p6":

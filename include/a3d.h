@@ -451,6 +451,9 @@ int a3d_sumpool2_add_nhwc(const float *x, float *y, int B, int H, int W, int C, 
 /* out[c] (=/+=) sum_m dy[m,c]  (bias gradients). */
 size_t a3d_colsum_workspace_bytes(int C);
 int a3d_colsum(const float *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream);
+/* dy stored as bf16 (the bf16 training step keeps its activation gradients that way): the same sums, in the same order, as a3d_colsum on
+ * the widened values.  C % 4 == 0. */
+int a3d_colsum_bf16(const void *dy, float *out, float *workspace, int M, int C, int accumulate, void *stream);
 
 /* Gradient of a3d_roi_align_fpn with respect to the pyramid: dfeat[level] += scatter(dout).  dfeat must hold the
  * gradient accumulated so far (or zeros).  Adaptive sampling (sampling_ratio 0) only: the box pooler. */
