@@ -216,7 +216,9 @@ def kernel_sums(events):
 
 def dominant_roofline(per, step_sec=None):
     """The kernel with the largest summed duration among `per` (kernel_sums) and its matrix-pipe roofline entry."""
-    dname, (dflops, dsec, dn, dexec, dpipe) = max(per.items(), key=lambda kv: kv[1][1])
+    # (among the kernels that multiply: at a couple of frames per rank a zero-FLOP transform can hold the largest summed duration)
+    cand = {k: v for k, v in per.items() if v[3] > 0} or per
+    dname, (dflops, dsec, dn, dexec, dpipe) = max(cand.items(), key=lambda kv: kv[1][1])
     peak = PIPE_PEAK.get(dpipe, FP32_MFMA_PEAK_TFLOPS)
     achieved = dexec * PIPE_FLOPS_PER_FMA[dpipe] / dsec / 1e12  # FLOPs the matrix pipe actually executes
     r = {"kernel": dname, "rocprof_name": rocprof_name(dname), "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
