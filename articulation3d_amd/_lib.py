@@ -207,6 +207,7 @@ SIGNATURES = {
     "a3d_mask_rle": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr]),
     "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_stem_conv_pool": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_last_conv_variant": (C.c_char_p, []),

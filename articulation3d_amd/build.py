@@ -31,6 +31,7 @@ SOURCES = {
     "conv_xs_h2.hip": [],
     "conv_ph4p.hip": [],
     "conv_wgrad_tr.hip": [],
+    "conv_stem_pool.hip": [],
     "spatial_ops.hip": [],
     "roi_align.hip": ["-ffp-contract=off"],  # sample coordinates ~1e2 px: an FMA-rounded coordinate moves the bilinear weights by 1e-5
     "proposals.hip": ["-ffp-contract=off"],

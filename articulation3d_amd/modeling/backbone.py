@@ -27,6 +27,12 @@ class BasicStem(nn.Module):
         c2_msra_fill(self.conv1.weight)
 
     def forward(self, x4):  # [B,H,W,4] normalised
+        from .layers import _CalibrationState
+
+        if not _CalibrationState.active and not self.training:
+            y = ops.stem_pool(x4, self.conv1.packed())  # conv + BN + ReLU + max-pool in one launch (fp16x2 arithmetic; same bits)
+            if y is not None:
+                return y
         return ops.maxpool3x3s2(self.conv1(x4))
 
 

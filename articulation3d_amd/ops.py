@@ -1011,6 +1011,58 @@ def preprocess_f32chw(images: torch.Tensor, mean, std) -> torch.Tensor:
     return out
 
 
+STEM_POOL_FUSED = os.environ.get("A3D_STEM_POOL", "1") != "0"
+
+
+def stem_pool(x: torch.Tensor, p: "PackedConv") -> Optional[torch.Tensor]:
+    """BasicStem in ONE launch (a3d_stem_conv_pool): 7x7 s2 stem conv + folded BN + ReLU + 3x3 s2 max-pool of the fp16x2 arithmetic, bit
+    for bit what conv2d(x, p) + maxpool3x3s2 give.  x [B,H,W,4] normalised.  Returns None where the fused kernel does not apply (another
+    arithmetic, a pinned layer, an audit or timing pass that wants the two launches, tensors past the 32-bit limit): the caller then
+    runs the two launches."""
+    if not (STEM_POOL_FUSED and DEFAULT_PRECISION == 3 and p.stem and p.presplit and p.pin_precision != 2 and AUDIT is None and p.cols == 64):
+        return None
+    _req(x)
+    B, H, W, _ = x.shape
+    if B * H * W * 16 >= (1 << 31) or p.Kpad != 224 or p.w.shape[0] != 64:
+        return None
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    out = torch.empty((B, Hp, Wp, 64), device=x.device, dtype=torch.float32)
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.y = _p(x), _p(p.w), _p(p.scale), _p(p.shift), _p(out)
+    d.B, d.H, d.W, d.Cin, d.Cin2 = B, H, W, 4, 0
+    d.Ho, d.Wo, d.Cout = Ho, Wo, 64
+    d.KH, d.KW, d.stride, d.pad = 7, 7, 2, 3
+    d.Kpad, d.act, d.stem, d.splitk, d.precision = p.Kpad, p.act, 1, 1, 3
+    d.tune = int(os.environ.get("A3D_STEM_ABL", "0"))  # (developer builds with -DA3D_ABLATIONS only: timing-only variants)
+    d.in_amax = amax_of(x).data_ptr()
+    if getattr(p, "_w_scale", None) is None:
+        p._w_scale = _pow2_scale_host(float(p.w.abs().max()))
+    d.w_scale = p._w_scale
+    if p.w_h2 is None or p.w_h2.device != p.w.device:  # (the filter's fp16 planes: the cache ops.conv2d fills for every direct fp16x2 layer)
+        p.w_h2 = torch.empty((p.Kpad // 16, 2, p.w.shape[0], 16), device=p.w.device, dtype=torch.float16)
+        _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w.data_ptr(), p.w_h2.data_ptr(), 1, p.w.shape[0], p.Kpad, 16, d.w_scale, _stream()),
+                   "a3d_split_f16x2_chunk")
+        if not os.environ.get("A3D_NO_PUBLISH"):
+            torch.cuda.current_stream().synchronize()
+    d.w_x3 = p.w_h2.data_ptr()
+    if not os.environ.get("A3D_NO_YAMAX"):
+        out._a3d_amax = amax_slot(B, out.device)
+        d.y_amax = out._a3d_amax.data_ptr()
+    global _LAST_PRECISION
+    _LAST_PRECISION = 3
+    if CONV_TIMING is not None and CONV_TIMING_ONLY is None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().a3d_stem_conv_pool(C.byref(d), _stream()), "a3d_stem_conv_pool")
+        e1.record()
+        fl = 2.0 * B * Ho * Wo * 64 * 147
+        CONV_TIMING.append(("stem_pool_kernel", fl, e0, e1, f"{B}x{H}x{W}x4->64 k7 s2 + pool", fl, "f16x3", _stream()))
+        return out
+    _lib.check(_lib.lib().a3d_stem_conv_pool(C.byref(d), _stream()), "a3d_stem_conv_pool")
+    return out
+
+
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     _req(x)
     B, H, W, Cc = x.shape

@@ -171,6 +171,12 @@ size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
  * precision-3 Winograd layer) */
 size_t a3d_wino_m_bytes(const a3d_conv_desc *d);
 int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
+/* The ResNet stem in ONE launch (round 4, fp16x2 arithmetic): 7x7 s2 p3 convolution + folded FrozenBN + ReLU + 3x3 s2 p1 max-pool
+ * (detectron2 BasicStem.forward behind pkg/modeling/meta_arch/planercnn.py:150).  d as for a3d_conv2d_nhwc_f32 on the stem (stem = 1,
+ * precision 3, w_x3, in_amax, w_scale, Ho x Wo = the CONV output size) except that d->y / d->y_amax are the POOLED tensor
+ * [B, (Ho - 1) / 2 + 1, (Wo - 1) / 2 + 1, 64] and its maxima.  Bit-identical to the conv launch followed by a3d_maxpool3x3s2_nhwc.
+ * A3D_ERR_UNSUPPORTED: not that layer / arithmetic (the caller runs the two launches). */
+int a3d_stem_conv_pool(const a3d_conv_desc *d, void *stream);
 /* src [outer][rows][cols] fp32 (cols % 32 == 0) -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly
  * (round-to-nearest-even at each level). */
 int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream);

@@ -534,6 +534,38 @@ def test_bf16x3_mode_through_the_detector(ops, hip_model, oracle):
     assert torch.equal(out.rec_count, ref.rec_count)
 
 
+@pytest.mark.parametrize("hw", [(480, 640), (96, 128), (61, 75), (250, 330), (14, 18)])
+def test_fused_stem_is_the_two_launches_bit_for_bit(ops, hw):
+    """Round 4: a3d_stem_conv_pool (7x7 s2 conv + BN + ReLU + 3x3 s2 max-pool, input patch resident in LDS, filter stationary in registers)
+    against the stem conv launch followed by the pool launch: the same bits -- chunk order, product terms, un-scaling, epilogue and the
+    pool's comparison order are shared -- and the same recorded maxima; odd sizes, a map smaller than one tile, a NaN pixel."""
+    if ops.DEFAULT_PRECISION != 3:
+        pytest.skip("the fused stem belongs to the fp16x2 arithmetic")
+    torch.manual_seed(hw[0])
+    B = 3 if hw[0] < 400 else 2
+    x = torch.rand(B, 3, *hw) * 255 - 110
+    x[1] *= 3.0  # (per-image scales differ)
+    w = torch.randn(64, 3, 7, 7) / 12
+    bn = (torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(64) * 0.1, torch.rand(64) + 0.5, 1e-5)
+    pk = ops.pack_stem(w, bn)
+    pk.act = ops.ACT_RELU
+    x4 = ops.preprocess_f32chw(x.cuda(), (0, 0, 0), (1, 1, 1))
+    two = ops.maxpool3x3s2(ops.conv2d(x4, pk))
+    assert ops.last_conv_variant() == "conv_h2_kernel<1> stem", ops.last_conv_variant()
+    one = ops.stem_pool(x4, pk)
+    assert one is not None and ops.last_conv_variant() == "stem_pool_kernel", ops.last_conv_variant()
+    assert one.shape == two.shape and torch.equal(one, two)
+    assert torch.equal(ops.amax_of(one), ops.amax_of(two))
+    ref64 = F.max_pool2d(F.relu(F.batch_norm(F.conv2d(x.double(), w.double(), None, 2, 3), bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                             False, 0.0, 1e-5)), 3, 2, 1)
+    assert rel(one.permute(0, 3, 1, 2).double(), ref64) < 2e-6
+    xn = x4.clone()
+    xn[0, hw[0] // 2, hw[1] // 2, 1] = float("nan")  # a NaN input pixel: every conv output it reaches is NaN, and a NaN wins its pool window
+    a, b = ops.maxpool3x3s2(ops.conv2d(xn, pk)), ops.stem_pool(xn, pk)
+    # (NaNs compare by position: the fused pool clears a NaN's sign bit, the only bits that may differ)
+    assert bool(torch.isnan(b).any()) and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 def test_stem_pool_resize_small_ops(ops):
     torch.manual_seed(3)
     x = torch.rand(2, 3, 96, 128) * 255 - 110
