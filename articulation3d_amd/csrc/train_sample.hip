@@ -60,29 +60,81 @@ __device__ u64 kth_smallest(const signed char *lab, int n, int cls, int k, unsig
     return *s_prefix;
 }
 
+// Round 4: three scans of the labels instead of fourteen.  The radix select above re-reads all N labels and re-hashes their keys in each
+// of its 6 passes per class (0.33 ms per step for ONE workgroup per image: 4 % of the step at the reference's 2 images per GPU).  Here
+// one scan builds the top-byte histograms of both classes, a second one gathers the (~N / 256) candidates of each class's deciding bin
+// into LDS, the k-th smallest key is found among those by rank counting, and the third scan writes the labels: the same thresholds, the
+// same output.  A class whose deciding bin overflows the candidate list (it cannot with hashed keys; 2048 slots for ~300) falls back to
+// the radix select.
+#define A3D_SL_CAP 2048
 __global__ __launch_bounds__(1024) void sample_labels_kernel(const signed char *__restrict__ labels, signed char *__restrict__ out, int N, int num,
                                                              int max_pos, unsigned long long seed) {
-    __shared__ unsigned int hist[256];
-    __shared__ u64 s_prefix;
-    __shared__ int s_krem, s_pos, s_neg;
+    __shared__ unsigned int hist[2][256];
+    __shared__ u64 cand[2][A3D_SL_CAP];
+    __shared__ u64 s_prefix, s_thr[2];
+    __shared__ int s_krem, s_k[2], s_bin[2], s_rem[2], s_n[2];
     const int b = blockIdx.x;
     const signed char *lab = labels + (size_t)b * N;
     signed char *o = out + (size_t)b * N;
-    if (threadIdx.x == 0) s_pos = s_neg = 0;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) (&hist[0][0])[i] = 0;
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
     __syncthreads();
-    int p = 0, q = 0;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        p += lab[i] == 1;
-        q += lab[i] == 0;
+        const int l = lab[i];
+        if (l == 0 || l == 1) atomicAdd(&hist[l][(unsigned)(sample_key(seed, b, i) >> 40) & 255u], 1u);
     }
-    atomicAdd(&s_pos, p);
-    atomicAdd(&s_neg, q);
     __syncthreads();
-    const int k_pos = min(s_pos, max_pos);
-    const int k_neg = min(s_neg, num - k_pos);
-    const u64 t_pos = kth_smallest(lab, N, 1, k_pos, seed, b, hist, &s_prefix, &s_krem);
+    if (threadIdx.x == 0) {  // class 1 first: the negatives fill what the positives leave
+        unsigned tot[2] = {0, 0};
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < 256; ++j) tot[c] += hist[c][j];
+        const int k_pos = min((int)tot[1], max_pos);
+        const int k_neg = min((int)tot[0], num - k_pos);
+        s_k[1] = k_pos;
+        s_k[0] = k_neg;
+        for (int c = 0; c < 2; ++c) {
+            int bin = 0;
+            unsigned cum = 0;
+            for (; bin < 255; ++bin) {
+                if (cum + hist[c][bin] >= (unsigned)s_k[c]) break;
+                cum += hist[c][bin];
+            }
+            s_bin[c] = bin;
+            s_rem[c] = s_k[c] - (int)cum;  // rank (1-based) of the threshold key inside its bin
+        }
+    }
     __syncthreads();
-    const u64 t_neg = kth_smallest(lab, N, 0, k_neg, seed, b, hist, &s_prefix, &s_krem);
+    const int k_pos = s_k[1], k_neg = s_k[0];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const int l = lab[i];
+        if (l != 0 && l != 1) continue;
+        if (s_k[l] <= 0) continue;
+        const u64 key = sample_key(seed, b, i);
+        if ((int)((unsigned)(key >> 40) & 255u) != s_bin[l]) continue;
+        const int slot = atomicAdd(&s_n[l], 1);
+        if (slot < A3D_SL_CAP) cand[l][slot] = key;
+    }
+    __syncthreads();
+    for (int c = 0; c < 2; ++c) {
+        const int n = s_n[c];
+        if (s_k[c] <= 0 || n > A3D_SL_CAP) continue;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {  // keys are distinct (their low 17 bits are the index)
+            const u64 ki = cand[c][i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += cand[c][j] < ki;
+            if (rank == s_rem[c] - 1) s_thr[c] = ki;
+        }
+    }
+    __syncthreads();
+    u64 t_pos = s_thr[1], t_neg = s_thr[0];
+    if (k_pos > 0 && s_n[1] > A3D_SL_CAP) {  // (never with hashed keys)
+        t_pos = kth_smallest(lab, N, 1, k_pos, seed, b, hist[0], &s_prefix, &s_krem);
+        __syncthreads();
+    }
+    if (k_neg > 0 && s_n[0] > A3D_SL_CAP) {
+        t_neg = kth_smallest(lab, N, 0, k_neg, seed, b, hist[0], &s_prefix, &s_krem);
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const int l = lab[i];
         signed char r = -1;

@@ -292,6 +292,33 @@ def test_device_samplers_draw_valid_uniform_subsets(T):
         assert bool(((out[b] == 1) <= (lab[b] == 1)).all()) and bool(((out[b] == 0) <= (lab[b] == 0)).all())
     assert torch.equal(out, T.sample_labels(lab.cuda(), num=256, max_pos=128, seed=5).cpu())
     assert not torch.equal(out, T.sample_labels(lab.cuda(), num=256, max_pos=128, seed=6).cpu())
+    # the draw IS the k smallest hashed keys of each class (csrc/train_sample.hip sample_key, replayed here): the round-4 three-scan kernel
+    # and the radix select it replaced pick the same sets
+    import numpy as np
+
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x = (x * np.uint32(0x85EBCA6B)).astype(np.uint32)
+        x ^= x >> np.uint32(13)
+        x = (x * np.uint32(0xC2B2AE35)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+
+    with np.errstate(over="ignore"):
+        idx = np.arange(N, dtype=np.uint32)
+        for b in range(B):
+            hb = mix32(np.array([np.uint32(5) ^ np.uint32(0) ^ (np.uint32(0x9E3779B9) * np.uint32(b + 1))], dtype=np.uint32))[0]
+            h = mix32(hb ^ (np.uint32(0x85EBCA6B) * (idx + np.uint32(1))).astype(np.uint32))
+            key = ((h >> np.uint32(1)).astype(np.uint64) << np.uint64(17)) | idx.astype(np.uint64)
+            lb = lab[b].numpy()
+            npos = min(int((lb == 1).sum()), 128)
+            nneg = min(int((lb == 0).sum()), 256 - npos)
+            want = np.full(N, -1, dtype=np.int8)
+            for cls, k in ((1, npos), (0, nneg)):
+                ids = np.nonzero(lb == cls)[0]
+                want[ids[np.argsort(key[ids])[:k]]] = cls
+            assert np.array_equal(out[b].numpy(), want), b
     # uniformity: over 200 seeds each of the 500 positives of image 1 is kept ~128/500 of the time
     hits = torch.zeros(500)
     for sd in range(200):
