@@ -96,8 +96,11 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
     }
     int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next chunk to load inside the filter
-    f32x4 xs[XR], ws[WR];
-    auto load_chunk = [&]() {
+    // TWO register staging sets (round 4): the loads of chunk c are issued at iteration c - 3 and written to LDS at iteration c - 1, two
+    // iterations of lead instead of one.  The training step's launches at the reference's 2 images per GPU are a handful of workgroups per
+    // CU with 8-64 chunks of 4-8 MFMAs each: every iteration waited out the full latency of loads issued one short iteration earlier.
+    f32x4 xsA[XR], wsA[WR], xsB[XR], wsB[WR];
+    auto load_chunk = [&](f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {
         const int tap = kh * d.KW + kw;
         const unsigned livebit = (kc < nk) ? 1u : 0u;
         const int tapoff = (kh * d.W + kw) * cs4 + c0 * XES;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
             }
         }
     };
-    auto store_chunk = [&](int buf) {  // fp32 -> bf16 (RNE) on the way into LDS
+    auto store_chunk = [&](int buf, const f32x4 (&xs)[XR], const f32x4 (&ws)[WR]) {  // fp32 -> bf16 (RNE) on the way into LDS
         __bf16 *X = lds + buf * BUF;
         __bf16 *Wt = X + BM * LKB;
 #pragma unroll
@@ -140,14 +143,19 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     a3d_stage_scale_shift(ss, d, n0, BN, tid);
-    load_chunk();
-    store_chunk(0);
-    load_chunk();
+    constexpr bool DEEP = !(TN == 2 && !XB);
+    load_chunk(xsA, wsA);  // chunk 0
+    store_chunk(0, xsA, wsA);
+    if constexpr (DEEP) {
+        load_chunk(xsB, wsB);  // chunk 1
+        load_chunk(xsA, wsA);  // chunk 2
+    } else {
+        load_chunk(xsA, wsA);  // chunk 1
+    }
     __syncthreads();
 
     const int frag_off = (lane & 31) * LKB + (lane >> 5) * 8;  // row = lane % 32, k = 8 * (lane / 32) .. + 7
-    for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
+    auto step = [&](const int cur, f32x4 (&xs)[XR], f32x4 (&ws)[WR]) {  // multiplies the chunk in LDS[cur]; xs / ws hold the next one
         const __bf16 *X = lds + cur * BUF + (wm * TM * 32) * LKB + frag_off;
         const __bf16 *Wt = lds + cur * BUF + BM * LKB + (wn * TN * 32) * LKB + frag_off;
         bf16x8 fa[2][TN], fb[2][TM];
@@ -158,8 +166,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) fb[s][mi] = *reinterpret_cast<const bf16x8 *>(X + mi * 32 * LKB + s * 16);
         }
-        store_chunk(cur ^ 1);
-        load_chunk();
+        store_chunk(cur ^ 1, xs, ws);
+        load_chunk(xs, ws);  // (two chunks past the one just stored)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -167,6 +175,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][ni], fb[s][mi], acc[ni][mi], 0, 0, 0);
         __syncthreads();
+    };
+    if constexpr (DEEP) {
+        for (int it = 0; it < nk; it += 2) {
+            step(0, xsB, wsB);
+            if (it + 1 < nk) step(1, xsA, wsA);
+        }
+    } else {  // (the 128 x 128 tile on fp32-stored activations: 168 registers with one staging set -- a second one spills)
+        for (int it = 0; it < nk; ++it) step(it & 1, xsA, wsA);
     }
 
     const bool has_res = d.res != nullptr;
