@@ -1264,3 +1264,18 @@ def test_seeded_fuzz_of_every_fp32_grade_kernel(ops):
             "conv_x3_kernel", "wino_gemm_x3w_kernel",                                          # bf16x3
             "conv_gemm_v2_kernel", "conv_pw_kernel", "wino_fused_kernel", "wino_gemm_kernel"}  # fp32-input MFMA
     assert want <= fam, (want - fam, sorted(fam))
+
+
+def test_seeded_fuzz_of_the_round4_kernels(ops):
+    """tools/fuzz_kernels.py run_round4, fixed seed, 25 s: random image sizes through the one-launch stem (bits of the two launches), random
+    layers through the transposed-read weight gradient (float64 of the bf16-rounded operands; bf16-stored == fp32-stored operands bit for
+    bit), random box sets through the ROIAlign backward's tile gather (two runs bit for bit; the float-atomics form to fp32 rounding)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("a3d_fuzz4", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_kernels.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    out = fuzz.run_round4(seed=20260301, budget_s=25.0, verbose=False)
+    print(out["cases"])
+    assert not out["failures"], out["failures"]
+    assert min(out["cases"].values()) >= 3, out["cases"]

@@ -222,7 +222,90 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
     return dict(cases=cases, failures=fails, variants=sorted(seen))
 
 
+def run_round4(seed: int = 11, budget_s: float = 30.0, verbose: bool = True):
+    """Random-shape fuzz of the three kernels round 4 added outside ops.conv2d's dispatcher:
+      * the one-launch stem (a3d_stem_conv_pool) against the conv launch + the pool launch: the same bits, any image size;
+      * the transposed-read weight gradient (conv_wgrad_tr.hip) of the bf16 step against a float64 gradient of the bf16-rounded
+        operands, and bf16-stored operands against fp32-stored ones holding the same values: the same bits;
+      * the ROIAlign backward as a tile gather against the float-atomics form (fp32 rounding of the sums), two runs of it bit for bit."""
+    from articulation3d_amd import train_ops as T
+
+    rng = random.Random(seed)
+    t_end = time.time() + budget_s
+    fails, cases = [], {"stem": 0, "wgrad": 0, "roi": 0}
+    saved = ops.DEFAULT_PRECISION
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    try:
+        while time.time() < t_end:
+            kind = rng.choice(["stem", "wgrad", "wgrad", "roi"])
+            torch.manual_seed(rng.randrange(1 << 30))
+            if kind == "stem":
+                ops.DEFAULT_PRECISION = 3
+                B, H, W = rng.randint(1, 3), rng.randint(9, 300), rng.randint(9, 400)
+                x4 = torch.randn(B, H, W, 4, device="cuda") * rng.choice([0.01, 1.0, 300.0])
+                x4[..., 3] = 0
+                w = torch.randn(64, 3, 7, 7) / 12
+                bn = (torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(64) * 0.1, torch.rand(64) + 0.5, 1e-5)
+                pk = ops.pack_stem(w, bn)
+                two = ops.maxpool3x3s2(ops.conv2d(x4, pk))
+                one = ops.stem_pool(x4, pk)
+                ok = one is not None and torch.equal(one, two) and torch.equal(ops.amax_of(one), ops.amax_of(two))
+                desc = f"stem {B}x{H}x{W}"
+            elif kind == "wgrad":
+                k = rng.choice([1, 1, 3])
+                B, H, W = rng.randint(1, 4), rng.randint(1, 70), rng.randint(1, 90)
+                if rng.random() < 0.2:
+                    B, H, W = rng.randint(100, 3000), 1, 1  # linear layers
+                Cin, Cout = 8 * rng.randint(1, 80), 8 * rng.randint(1, 48)
+                x, dy = torch.randn(B, Cin, H, W), torch.randn(B, Cout, H, W)
+                xb, dyb = x.bfloat16(), dy.bfloat16()
+                wd = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+                F.conv2d(xb.double(), wd, None, 1, k // 2).backward(dyb.double())
+                ref = wd.grad.permute(0, 2, 3, 1).reshape(Cout, -1)
+                outs = []
+                for xa, dya in ((nhwc(x).cuda(), nhwc(dy).cuda()), (nhwc(xb).cuda(), nhwc(dyb).cuda()), (nhwc(xb.float()).cuda(), nhwc(dyb).cuda())):
+                    dw = torch.empty((Cout, k * k * Cin), device="cuda")
+                    T.conv_wgrad(xa, dya, dw, KH=k, KW=k, stride=1, pad=k // 2, precision=1)
+                    outs.append(dw)
+                err = float((outs[0].double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+                ok = err < 2e-6 and torch.equal(outs[1], outs[2]) and float((outs[1].double().cpu() - ref).norm() / ref.norm().clamp_min(1e-30)) < 2e-6
+                desc = f"wgrad {B}x{H}x{W}x{Cin}->{Cout} k{k} err {err:.1e}"
+            else:
+                B, R, C = rng.randint(1, 3), rng.randint(1, 70), rng.choice([32, 64, 256])
+                Himg, Wimg = 32 * rng.randint(4, 15), 32 * rng.randint(4, 20)
+                wh = torch.rand(B, R, 2) * torch.tensor([float(Wimg), float(Himg)]) * rng.choice([0.1, 0.5, 1.0]) + 2
+                xy = torch.rand(B, R, 2) * torch.tensor([float(Wimg), float(Himg)]) - wh * 0.3
+                boxes = torch.cat([xy, xy + wh], 2).cuda().contiguous()
+                count = torch.tensor([rng.randint(0, R) for _ in range(B)], dtype=torch.int32, device="cuda")
+                off = torch.zeros(B, dtype=torch.int32, device="cuda")
+                off[1:] = torch.cumsum(count, 0)[:-1].to(torch.int32)
+                rows = int(count.sum())
+                dout = torch.randn(max(rows, 1), 7, 7, C, device="cuda")
+                mk = lambda: [torch.zeros(B, Himg // s_, Wimg // s_, C, device="cuda") for s_ in (4, 8, 16, 32)]
+                a, a2, sc = mk(), mk(), mk()
+                args = ([1 / 4, 1 / 8, 1 / 16, 1 / 32], boxes, dout)
+                T.roi_align_fpn_backward(a, *args, P=7, sampling_ratio=0, aligned=True, count=count, row_offset=off)
+                T.roi_align_fpn_backward(a2, *args, P=7, sampling_ratio=0, aligned=True, count=count, row_offset=off)
+                T.roi_align_fpn_backward(sc, *args, P=7, sampling_ratio=0, aligned=True, count=count, row_offset=off, scatter=True)
+                nrm = max(float(torch.cat([t.flatten() for t in sc]).norm()), 1e-30)
+                err = float(torch.cat([(p - q).flatten() for p, q in zip(a, sc)]).norm()) / nrm
+                ok = all(torch.equal(p, q) for p, q in zip(a, a2)) and err < 2e-6
+                desc = f"roi bwd {B}x{R} C{C} {Himg}x{Wimg} rows {rows} err {err:.1e}"
+            cases[kind] += 1
+            if verbose:
+                print(f"{desc}: {'ok' if ok else 'FAIL'}", flush=True)
+            if not ok:
+                fails.append(desc)
+    finally:
+        ops.DEFAULT_PRECISION = saved
+    return dict(cases=cases, failures=fails)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":
+        o4 = run_round4(seed=int(sys.argv[3]) if len(sys.argv) > 3 else 11, budget_s=float(sys.argv[2]) if len(sys.argv) > 2 else 30.0)
+        print(o4["cases"], "FAILURES:", o4["failures"])
+        sys.exit(1 if o4["failures"] else 0)
     out = run(seed=int(sys.argv[2]) if len(sys.argv) > 2 else 7, budget_s=float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
     print(f"\n{out['cases']} random layers x 3 arithmetics; kernel variants the dispatcher reported ({len(out['variants'])}):")
     for v in out["variants"]:
