@@ -43,6 +43,8 @@ class ConvDesc(C.Structure):
         ("io_bf16", C.c_int),
         ("x_h2", fptr),
         ("x2_h2", fptr),
+        ("dot_w", fptr),
+        ("dot_y", fptr),
     ]
 
 
@@ -208,6 +210,7 @@ SIGNATURES = {
     "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_stem_conv_pool": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_tapsum9": (C.c_int, [fptr, C.c_float, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_wino_gemm": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_last_conv_variant": (C.c_char_p, []),

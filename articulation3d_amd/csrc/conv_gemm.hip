@@ -13,7 +13,8 @@
 #include <stdio.h>
 
 static int conv_check(const a3d_conv_desc *d) {
-    if (!d || (!d->x && !d->x_h2) || !d->w || !d->y) return A3D_ERR_ARG;
+    if (!d || (!d->x && !d->x_h2) || !d->w || (!d->y && !d->dot_y)) return A3D_ERR_ARG;
+    if ((d->dot_w || d->dot_y) && d->phase != 5) return A3D_ERR_ARG;  // the tap-product epilogue belongs to the fused four-phase form
     if (d->x_h2 && d->precision != 3) return A3D_ERR_ARG;  // pre-split activations exist in the fp16x2 arithmetic only
     if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return A3D_ERR_ARG;
     if ((d->Cout & 3) || (d->Kpad & 31) || d->splitk < 1) return A3D_ERR_ARG;

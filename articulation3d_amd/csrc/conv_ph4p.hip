@@ -79,9 +79,10 @@ constexpr int pp_start(const int tap) {
 // convolution of the fp16x2 arithmetic with NB x 64 output channels per workgroup (the layers the Winograd form does not take: fewer than
 // 256 input channels -- res2 / res3 conv2, pkg/modeling/meta_arch/planercnn.py:150 -> detectron2 BottleneckBlock), same loop, every block
 // live at every tap.
-template <bool PH, int NB, int TW>
+template <bool PH, int NB, int TW, bool DOT = false>
 __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a3d_conv_desc d, const int tiles_x, const int tiles_y, const int ntiles, const int nblk) {
     static_assert(!PH || NB == 4, "the four phases are the four blocks of a wave");
+    static_assert(!DOT || PH, "the tap-product epilogue belongs to the four-phase form");
     constexpr int PP_TW = TW, PP_TH = 256 / TW, PP_PC = PP_TW + 2;
     constexpr int NPOS_T = PP_PC * (PP_TH + 2), ITEMS_T = NPOS_T * 4;  // positions / loader items of this tile shape
     static_assert(TW == 32 || TW == 16, "8 x 32 or 16 x 16 tiles");
@@ -311,6 +312,69 @@ __global__ __launch_bounds__(512, NB == 1 ? 2 : 1) void conv_ph4p_kernel(const a
     const float unx = 1.f / sx, unw = 1.f / sw;
     float vmax = 0.f;
     const int co_n = d.Cout >> 2;
+    if constexpr (PH && DOT) {
+        {
+            // ---- the output feeds only a 3x3 convolution to one channel (a3d_conv_desc.dot_w): instead of the 64-channel pixels, their nine
+            // tap products.  A lane holds 16 of a pixel-phase's 64 channels (rg, i; its half-wave partner 16 more, the wave with the
+            // other wn the other 32): nine 16-term partial sums, + the partner's by a 32-lane shuffle, then both waves' halves meet in
+            // LDS (the filter ring is idle: every wave is behind the loop's last barrier) and 512 threads store the sums.
+            float *const dw = reinterpret_cast<float *>(Ws);              // [9][64] filter
+            float *const part = dw + 9 * 64;                              // [wn][wm][mi][ni][9][32]
+            for (int i = tid; i < 9 * 64; i += 512) dw[i] = d.dot_w[i];
+            __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (1) the shared epilogue in place: the accumulators become the output values
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int nl = (wn * NB + ni) * 32 + rg * 8 + khalf * 4;
+                        f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                        v = (v * unx) * unw;  // exact: powers of two
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), false, zero);
+                        vmax = fmaxf(vmax, a3d_absmax4(v));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[ni][mi][rg * 4 + i] = v[i];
+                    }
+            // (2) tap by tap (a ROLLED loop: with all nine taps' weights live the kernel spilled ~300 registers): the tap's 16 weights of
+            // this lane's channels, the eight pixel-phases' 16-term sums, the half-wave partner's added
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                f32x4 wq[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) wq[rg] = *reinterpret_cast<const f32x4 *>(dw + t * 64 + wn * 32 + rg * 8 + khalf * 4);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NB; ++ni) {
+                        float ps = 0.f;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ps = __builtin_fmaf(acc[ni][mi][rg * 4 + i], wq[rg][i], ps);
+                        const float s2 = ps + __shfl_xor(ps, 32, 64);
+                        if (khalf == 0) part[((((wn * 4 + wm) * 2 + mi) * NB + ni) * 9 + t) * 32 + frow] = s2;
+                    }
+            }
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const size_t plane = (size_t)(2 * d.H) * (2 * d.W);
+            for (int idx = tid; idx < 4 * 2 * NB * 9 * 32; idx += 512) {  // (wm, mi, ni, t, lane)
+                const int fr = idx & 31, t = (idx >> 5) % 9, q = (idx >> 5) / 9;
+                const int ni = q & 3, mi = (q >> 2) & 1, wmq = q >> 3;
+                const int pr = TW == 32 ? 0 : fr >> 4, pc = TW == 32 ? fr : fr & 15;
+                const int oh = ty0 + RPB * (2 * wmq + mi) + pr, ow = tx0 + pc;
+                if (oh >= d.H || ow >= d.W) continue;
+                const float s2 = part[idx] + part[idx + 4 * 2 * NB * 9 * 32];  // wn = 0 | 1: channels 0-31 | 32-63
+                d.dot_y[((size_t)b * 9 + t) * plane + (size_t)(2 * oh + (ni >> 1)) * (2 * d.W) + (2 * ow + (ni & 1))] = s2;
+            }
+            if (d.y_amax) a3d_note_amax(d.y_amax, b, vmax, true);
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int oh = ty0 + RPB * (2 * wm + mi) + prow, ow = tx0 + pcol;
@@ -356,7 +420,7 @@ static inline int pp_tile_width(int H, int W) {
     return pp_covered(H, W, 16) < pp_covered(H, W, 32) ? 16 : 32;
 }
 
-template <bool PH, int NB, int TW>
+template <bool PH, int NB, int TW, bool DOT = false>
 static int pp_launch_t(const a3d_conv_desc *d, hipStream_t s, const char *label) {
     constexpr int TH = 256 / TW;
     const int tiles_x = (d->W + TW - 1) / TW, tiles_y = (d->H + TH - 1) / TH;
@@ -364,15 +428,18 @@ static int pp_launch_t(const a3d_conv_desc *d, hipStream_t s, const char *label)
     const int nblk = d->B * tiles_x * tiles_y * ntiles;
     static a3d_attr_once attr;
     if (attr.needed()) {
-        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel<PH, NB, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(NB)) != hipSuccess) return A3D_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void *)conv_ph4p_kernel<PH, NB, TW, DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, pp_lds_bytes(NB)) != hipSuccess) return A3D_ERR_LAUNCH;
         attr.mark();
     }
-    a3d_note_variant("%s%d>", label, TW);  // ("conv_ph4p_kernel<16>", "conv_c3p_kernel<2, 32>": the tile width is part of the name rocprofv3 shows)
-    hipLaunchKernelGGL((conv_ph4p_kernel<PH, NB, TW>), dim3(nblk), dim3(512), pp_lds_bytes(NB), s, *d, tiles_x, tiles_y, ntiles, nblk);
+    a3d_note_variant(DOT ? "%s%d> dot" : "%s%d>", label, TW);  // ("conv_ph4p_kernel<16>", "conv_c3p_kernel<2, 32>": the tile width is part of the name rocprofv3 shows)
+    hipLaunchKernelGGL((conv_ph4p_kernel<PH, NB, TW, DOT>), dim3(nblk), dim3(512), pp_lds_bytes(NB), s, *d, tiles_x, tiles_y, ntiles, nblk);
     return a3d_check_launch();
 }
 template <bool PH, int NB>
 static int pp_launch(const a3d_conv_desc *d, hipStream_t s, const char *label) {
+    if constexpr (PH) {
+        if (d->dot_w) return pp_tile_width(d->H, d->W) == 16 ? pp_launch_t<PH, NB, 16, true>(d, s, label) : pp_launch_t<PH, NB, 32, true>(d, s, label);
+    }
     return pp_tile_width(d->H, d->W) == 16 ? pp_launch_t<PH, NB, 16>(d, s, label) : pp_launch_t<PH, NB, 32>(d, s, label);
 }
 
@@ -383,8 +450,9 @@ int a3d_conv_launch_ph4p(const a3d_conv_desc *d, hipStream_t s) {
     if (d->Cin2 && (d->Cin2 != d->Cin || !d->x2)) return A3D_ERR_ARG;
     const int CinT = d->Cin + d->Cin2;
     if ((d->Cin & 15) || (CinT & 31) || d->Kpad != 9 * CinT || (d->Cout & 127)) return A3D_ERR_ARG;
-    if (d->tune == 15) return A3D_ERR_UNSUPPORTED;
-    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+    if ((d->dot_w != nullptr) != (d->dot_y != nullptr) || (d->dot_w && d->Cout != 256)) return A3D_ERR_ARG;
+    if (d->tune == 15) return d->dot_w ? A3D_ERR_ARG : A3D_ERR_UNSUPPORTED;  // (the tap-outer form has no tap-product epilogue)
+    if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 31)) return d->dot_w ? A3D_ERR_ARG : A3D_ERR_UNSUPPORTED;
     // (Measured at 64 frames, tap-outer | this kernel, tools/ups_bench.py: 8x10 0.078 | 0.060 ms, 15x20 0.142 | 0.115, 30x40 0.403 | 0.326, 60x80
     // 1.351 | 1.045, 120x160 2.825 | 1.931 -- ahead on every map of the decoder, also where its tiles cover 1.3-3 x the map: every phase-5
     // launch takes it (16 x 16 tiles where they cover fewer pixels than 8 x 32: the 30x40 and 60x80 stages).  The two forms differ in

@@ -328,6 +328,31 @@ extern "C" int a3d_conv3x3_to1_nhwc(const float *x, const float *w, float bias, 
 }
 
 
+// ---- second half of a 3x3 pad-1 convolution to one channel whose per-pixel tap products a phase-5 conv launch stored (a3d_conv_desc.dot_y) ----
+// y[b][oh][ow] = bias + sum_t g[b][t][oh + t / 3 - 1][ow + t % 3 - 1]: nine shifted planes, taps in order, zero outside the map.
+__global__ __launch_bounds__(256) void tapsum9_kernel(const float *__restrict__ g, float bias, float *__restrict__ y, int B, int H, int W) {
+    const size_t total = (size_t)B * H * W, plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % W);
+        const size_t r = i / W;
+        const int oh = (int)(r % H);
+        const size_t b = r / H;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) s += g[(b * 9 + t) * plane + (size_t)ih * W + iw];
+        }
+        y[i] = s + bias;
+    }
+}
+extern "C" int a3d_tapsum9(const float *g, float bias, float *y, int B, int H, int W, void *stream) {
+    if (!g || !y || B <= 0 || H <= 0 || W <= 0) return A3D_ERR_ARG;
+    a3d_begin();
+    hipLaunchKernelGGL(tapsum9_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, bias, y, B, H, W);
+    return a3d_check_launch();
+}
+
 // ---- per-image maxima of a tensor no kernel of this library produced (a3d_conv_desc.in_amax) --------------------------------
 // Any row count (the grid strides over rows), any row length and alignment (scalar head / tail around the 16-byte body).
 // Non-finite values do not count (conv_common.h a3d_finite_mag): the scale of an image comes from its finite values.

@@ -75,9 +75,13 @@ class PlaneRCNNDepthHead(nn.Module):
         x = D(2, C(2, p5), x)
         x = D(3, C(3, feats["p4"]), x)
         x = D(4, C(4, feats["p3"]), x)
-        x = D(5, C(5, feats["p2"]), x)  # [B,240,320,64]
         w, b = self._pred_packed()
-        d = ops.conv3x3_to1(x, w, b)  # [B,240,320]
+        c5 = C(5, feats["p2"])
+        # deconv5 + depth_pred without the 64-channel 240x320 tensor between them (default arithmetic; ops.conv2d_ups_to1)
+        d = ops.conv2d_ups_to1(c5, self._pk_deconv[4].packed_phases(), w, b, x2=x) if not self.training else None
+        if d is None:
+            x = D(5, c5, x)  # [B,240,320,64]
+            d = ops.conv3x3_to1(x, w, b)  # [B,240,320]
         B, H, W = d.shape
         return ops.resize_bilinear(d.view(B, H, W, 1), 2 * H, 2 * W).view(B, 2 * H, 2 * W)  # depth_head.py:88-89
 

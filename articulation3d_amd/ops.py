@@ -380,7 +380,7 @@ _ADDR_LIMIT = (1 << 32) - 1  # the kernels address every operand with 32-bit buf
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
            res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
            m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None, out_dtype=None) -> torch.Tensor:
+           wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None, out_dtype=None, dot=None) -> torch.Tensor:
     """x: NHWC [B,H,W,Cin] (stem: [B,H,W,4]).  Returns NHWC [B,Ho,Wo,cols] (pixshuf: [B,2Ho,2Wo,cols/4]).
 
     bf16 STORAGE (training step, precision 1 only): x / res / gate may be torch.bfloat16 tensors and `out_dtype=torch.bfloat16`
@@ -407,10 +407,12 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         per_v = ((Hl_ + 1) // 2) * ((Wl_ + 1) // 2) * (x.shape[3] + (0 if x2 is None else x2.shape[3])) * 4 if p.w_wino is not None else 0
         per = max(per_in, per_out, per_v, 1)
         if B * per > _ADDR_LIMIT:
+            if dot is not None:
+                raise RuntimeError("tap-product epilogue (dot): the batch must fit one launch")
             return _conv2d_blocks(x, p, max(1, _ADDR_LIMIT // per), (Ho_, Wo_), x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk,
                                   m_dev=m_dev, out=out, tune=tune, wino=wino, gate=gate, precision=precision)
     return _conv2d_launch(x, p, x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk, m_dev=m_dev, out=out, tune=tune,
-                          wino=wino, gate=gate, precision=precision)
+                          wino=wino, gate=gate, precision=precision, dot=dot)
 
 
 def _conv2d_blocks(x, p, nb, hw_out, *, x2, res, out, gate, m_dev, **kw):
@@ -577,7 +579,7 @@ class _amax_rows:
 def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                    res_ups: bool = False, ups: bool = False, act: Optional[int] = None, splitk: int = 1,
                    m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
-                   wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None) -> torch.Tensor:
+                   wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None, dot=None) -> torch.Tensor:
     _req(x)
     B, H, W, Cin = x.shape
     Cin2 = 0
@@ -610,6 +612,9 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         assert tuple(_req(gate).shape) == tuple(out.shape), (gate.shape, out.shape)
         d.gate = gate.data_ptr()
     d.tune = int(tune)
+    if dot is not None:  # (phase 5 only: the nine tap products of a following 3x3 convolution to one channel instead of the output)
+        assert p.phase == 5 and precision == 3
+        d.dot_w, d.dot_y = _req(dot[0]).data_ptr(), _req(dot[1]).data_ptr()
     wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7, 8) or tune >= 200) and not ups
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
@@ -842,6 +847,35 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out
+
+
+DEPTH_PRED_FUSED = os.environ.get("A3D_DEPTH_PRED_FUSED", "1") != "0"
+
+
+def conv2d_ups_to1(x: torch.Tensor, phases: Sequence[PackedConv], w9: torch.Tensor, bias: float, *, x2: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """conv3x3_to1(conv2d_ups(x, phases, x2), w9, bias) without the [B,2H,2W,64] tensor in between (a3d_conv_desc.dot_w / dot_y + a3d_tapsum9):
+    the patch-resident four-phase launch stores, per output pixel, the nine dot products of its 64 channels with the nine taps' weights, and
+    a second small launch adds the shifted planes.  w9 [3,3,64] (or [9,64]) fp32.  Returns [B,2H,2W], or None where the form does not
+    apply (another arithmetic, a pinned layer, an audit pass, a batch past one launch): the caller runs the two layers.  Equal to them
+    to fp32 rounding of the 576-term sums (another summation order)."""
+    pinned = phases[0].pin_precision == 2
+    if not (DEPTH_PRED_FUSED and UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned and AUDIT is None and phases[0].cols == 64):
+        return None
+    B, H, W, C = x.shape
+    if B * 4 * H * W * 64 * 4 > _ADDR_LIMIT or B * H * W * C * 4 > _ADDR_LIMIT:
+        return None
+    pf = getattr(phases[0], "_fused", None)
+    if pf is None:
+        pf = pack_conv_ups_fused(phases)
+        phases[0]._fused = pf if pf is not None else False
+    if not pf:
+        return None
+    out = torch.empty((B, 2 * H, 2 * W, 64), device=x.device, dtype=torch.float32)  # (never written: the launch stores the tap products)
+    g = torch.empty((B, 9, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    conv2d(x, pf, x2=x2, out=out, precision=3, dot=(w9.reshape(9, 64), g))
+    y = torch.empty((B, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().a3d_tapsum9(g.data_ptr(), float(bias), y.data_ptr(), B, 2 * H, 2 * W, _stream()), "a3d_tapsum9")
+    return y
 
 
 _LAST_PRECISION = -1  # a3d_conv_desc.precision of the calling thread's last conv launch (what the mode rules resolved to)

@@ -69,12 +69,12 @@ def rocprof_name(variant: str) -> str:
     if m:  # (<F16, fused four-phase form, activations pre-split (dual DMA)>)
         return (f"conv_x3w_kernel<{'true' if m.group(1) == 'h2' else 'false'}, {'true' if m.group(2) == ' ph4' else 'false'}, "
                 f"{'true' if m.group(2) == ' xd' else 'false'}>")
-    m = re.match(r"conv_ph4p_kernel<(\d+)>$", v)  # (<four-phase form, 32-column blocks per wave, tile width>)
+    m = re.match(r"conv_ph4p_kernel<(\d+)>( dot)?$", v)  # (<four-phase form, 32-column blocks per wave, tile width, tap-product epilogue>)
     if m:
-        return f"conv_ph4p_kernel<true, 4, {m.group(1)}>"
+        return f"conv_ph4p_kernel<true, 4, {m.group(1)}, {'true' if m.group(2) else 'false'}>"
     m = re.match(r"conv_c3p_kernel<(\d), (\d+)>$", v)
     if m:
-        return f"conv_ph4p_kernel<false, {m.group(1)}, {m.group(2)}>"
+        return f"conv_ph4p_kernel<false, {m.group(1)}, {m.group(2)}, false>"
     if v == "wino_input_kernel":  # (the fp16x2 arithmetic's transform writes V pre-split: its own kernel)
         return "wino_input_h2_kernel"
     m = re.match(r"conv_h2xs_kernel<(\d+)>$", v)  # (activation-stationary pointwise kernel: <Cin / 16, N groups, chunks per ring stage>)

@@ -164,6 +164,13 @@ typedef struct a3d_conv_desc {
      * split arithmetic and no VGPR -> LDS stores in its loop; results are bit-identical to the launch on the fp32 tensor. */
     const void *x_h2;      /* source 0 pre-split, or NULL                                                                            */
     const void *x2_h2;     /* source 1 pre-split (required with x_h2 when Cin2 > 0), or NULL                                        */
+    /* ---- phase 5 only (round 4): the layer's output feeds NOTHING but a 3x3 pad-1 convolution to ONE channel (the depth head's
+     * depth_pred behind deconv5, pkg/modeling/depth_net/depth_head.py:51,88).  With dot_w / dot_y set the launch does not store its
+     * [B,2H,2W,C] output (y may be NULL; C = Cout / 4 must be 64); it stores, per output pixel, the nine dot products of the pixel's
+     * channel vector with the nine taps' weights, dot_y [B][9][2H][2W], and a3d_tapsum9 adds the shifted planes: a 177 MB round trip
+     * instead of the 1.26 GB one (64 frames), one launch less.  Equal to the two launches to fp32 rounding of the 576-term sum. */
+    const float *dot_w;    /* [9][C] = the one-channel filter as [kh][kw][c], or NULL                                                */
+    float *dot_y;          /* [B][9][2H][2W], or NULL                                                                                */
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -177,6 +184,9 @@ int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream);
  * [B, (Ho - 1) / 2 + 1, (Wo - 1) / 2 + 1, 64] and its maxima.  Bit-identical to the conv launch followed by a3d_maxpool3x3s2_nhwc.
  * A3D_ERR_UNSUPPORTED: not that layer / arithmetic (the caller runs the two launches). */
 int a3d_stem_conv_pool(const a3d_conv_desc *d, void *stream);
+/* y[b][oh][ow] = bias + sum over t = 3 kh + kw of g[b][t][oh + kh - 1][ow + kw - 1] (zero outside): the second half of a 3x3 pad-1
+ * convolution to one channel whose per-pixel tap products a phase-5 launch stored (a3d_conv_desc.dot_y). */
+int a3d_tapsum9(const float *g, float bias, float *y, int B, int H, int W, void *stream);
 /* src [outer][rows][cols] fp32 (cols % 32 == 0) -> dst [outer][cols/32][3][rows][32] bf16 with src == hi + mid + lo exactly
  * (round-to-nearest-even at each level). */
 int a3d_split_bf16x3(const float *src, void *dst, int outer, int rows, int cols, void *stream);

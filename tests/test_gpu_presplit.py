@@ -208,3 +208,29 @@ def test_patch_resident_upsampled_conv_matches_the_tap_outer_form(ops, case):
     alone = ops.conv2d_ups(x[-1:].contiguous(), phases, x2=None if x2 is None else x2[-1:].contiguous())
     batch = ops.conv2d_ups(x, phases, x2=x2)
     assert torch.equal(alone[0], batch[-1])
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 40), (3, 61, 79), (1, 8, 10), (2, 120, 160)])
+def test_tap_product_epilogue_equals_the_two_layers(ops, shape):
+    """Round 4: deconv5 + depth_pred of the depth head (pkg/modeling/depth_net/depth_head.py:51,88) without the 64-channel tensor between
+    them -- the four-phase launch stores the nine tap products of every output pixel (a3d_conv_desc.dot_w / dot_y), a3d_tapsum9 adds the
+    shifted planes.  Another summation order of the same 576 products per pixel: both forms against a float64 3x3 convolution of the
+    SAME 64-channel tensor, the same error; results do not depend on the batch."""
+    if ops.DEFAULT_PRECISION != 3:
+        pytest.skip("the fused four-phase form belongs to the fp16x2 arithmetic")
+    B, H, W = shape
+    torch.manual_seed(B * 1000 + H)
+    a = torch.randn(B, H, W, 128, device="cuda")
+    c2 = torch.randn(B, H, W, 128, device="cuda")
+    phases = ops.pack_conv_ups_phases(torch.randn(64, 256, 3, 3) / (3 * 256 ** 0.5), torch.randn(64) * 0.1, None, ops.ACT_RELU)
+    w9 = (torch.randn(3, 3, 64) / 24).cuda()
+    x = ops.conv2d_ups(a, phases, x2=c2)
+    two = ops.conv3x3_to1(x, w9, 0.3)
+    one = ops.conv2d_ups_to1(a, phases, w9, 0.3, x2=c2)
+    assert one is not None and ops.last_conv_variant().endswith(" dot"), ops.last_conv_variant()
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w9.double().permute(2, 0, 1)[None], torch.tensor([0.3], dtype=torch.float64, device="cuda"), 1, 1)[:, 0]
+    e2, e1 = (float((o.double() - ref).abs().max() / ref.abs().max()) for o in (two, one))
+    assert e1 < 1e-6 and e2 < 1e-6 and e1 < 3 * e2 + 1e-7, (e1, e2)
+    if B > 1:  # batch invariance, bit for bit
+        alone = ops.conv2d_ups_to1(a[1:2].contiguous(), phases, w9, 0.3, x2=c2[1:2].contiguous())
+        assert torch.equal(alone[0], one[1])
