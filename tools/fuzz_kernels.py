@@ -232,12 +232,12 @@ def run_round4(seed: int = 11, budget_s: float = 30.0, verbose: bool = True):
 
     rng = random.Random(seed)
     t_end = time.time() + budget_s
-    fails, cases = [], {"stem": 0, "wgrad": 0, "roi": 0}
+    fails, cases = [], {"stem": 0, "wgrad": 0, "roi": 0, "dot": 0}
     saved = ops.DEFAULT_PRECISION
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
     try:
         while time.time() < t_end:
-            kind = rng.choice(["stem", "wgrad", "wgrad", "roi"])
+            kind = rng.choice(["stem", "wgrad", "wgrad", "roi", "dot"])
             torch.manual_seed(rng.randrange(1 << 30))
             if kind == "stem":
                 ops.DEFAULT_PRECISION = 3
@@ -251,6 +251,24 @@ def run_round4(seed: int = 11, budget_s: float = 30.0, verbose: bool = True):
                 one = ops.stem_pool(x4, pk)
                 ok = one is not None and torch.equal(one, two) and torch.equal(ops.amax_of(one), ops.amax_of(two))
                 desc = f"stem {B}x{H}x{W}"
+            elif kind == "dot":  # deconv5 + depth_pred as tap products against the two layers (float64 of the same 64-channel tensor)
+                ops.DEFAULT_PRECISION = 3
+                B, H, W = rng.randint(1, 3), rng.randint(3, 70), rng.randint(3, 90)
+                C1 = 32 * rng.randint(1, 4)
+                two_src = rng.random() < 0.7
+                a = torch.randn(B, H, W, C1, device="cuda") * rng.choice([0.05, 1.0, 40.0])
+                c2 = torch.randn(B, H, W, C1, device="cuda") if two_src else None
+                phases = ops.pack_conv_ups_phases(torch.randn(64, C1 * (2 if two_src else 1), 3, 3) / (3 * (2 * C1) ** 0.5), torch.randn(64) * 0.1, None, ops.ACT_RELU)
+                w9 = (torch.randn(3, 3, 64) / 24).cuda()
+                x = ops.conv2d_ups(a, phases, x2=c2)
+                two = ops.conv3x3_to1(x, w9, 0.25)
+                one = ops.conv2d_ups_to1(a, phases, w9, 0.25, x2=c2)
+                ref = F.conv2d(x.double().permute(0, 3, 1, 2), w9.double().permute(2, 0, 1)[None], torch.tensor([0.25], dtype=torch.float64, device="cuda"), 1, 1)[:, 0]
+                sc = float(ref.abs().max().clamp_min(1e-30))
+                e1 = float((one.double() - ref).abs().max()) / sc if one is not None else 1.0
+                e2 = float((two.double() - ref).abs().max()) / sc
+                ok = one is not None and e1 < 1e-6 and e1 < 3 * e2 + 2e-7
+                desc = f"dot {B}x{H}x{W}x{C1}{'x2' if two_src else ''} err {e1:.1e} | {e2:.1e}"
             elif kind == "wgrad":
                 k = rng.choice([1, 1, 3])
                 B, H, W = rng.randint(1, 4), rng.randint(1, 70), rng.randint(1, 90)
