@@ -63,7 +63,14 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
     const int logical = a3d_xcd_remap(blockIdx.x, nblk);
     const int mt = logical / ntiles, nt = logical - mt * ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = d.Kpad / BKT;
+    // split-K (a3d_conv_desc.splitk > 1, round 4): blockIdx.y owns the chunks [k_first, k_first + nk) of the reduction and stores its raw
+    // accumulators to workspace [split][M][Cout]; conv_bf16_reduce_kernel adds the splits in order and applies the epilogue.  For the
+    // training step at 2 images per GPU: a 3x3 256 -> 256 layer on 2 x 30 x 40 pixels is 76 workgroups walking 72 chunks one
+    // memory round trip at a time.
+    const int nk_all = d.Kpad / BKT;
+    const int per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_first = blockIdx.y * per;
+    const int nk = max(0, min(nk_all, k_first + per) - k_first);
     const int lr = tid / TPR, lc = (tid % TPR) * 4;
     const int lrx = tid / TPRX, lcx = (tid % TPRX) * XE;
     const bool yb = d.io_bf16 & 2, rb = d.io_bf16 & 4, gb = d.io_bf16 & 8;  // tensors stored as bf16
@@ -95,7 +102,9 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         const int n = n0 + lr + RPP * i;
         woff[i] = n < d.Cout ? (n * d.Kpad + lc) * 4 : -1;
     }
-    int kc = 0, c0 = 0, kh = 0, kw = 0;  // position of the next chunk to load inside the filter
+    // position of the next chunk to load inside the filter: chunk k of the reduction = (tap k / (Cin / 32), channels 32 (k % (Cin / 32)))
+    const int cpt = d.Cin / BKT;
+    int kc = 0, c0 = (k_first % cpt) * BKT, kh = (k_first / cpt) / d.KW, kw = (k_first / cpt) % d.KW;
     // TWO register staging sets (round 4): the loads of chunk c are issued at iteration c - 3 and written to LDS at iteration c - 1, two
     // iterations of lead instead of one.  The training step's launches at the reference's 2 images per GPU are a handful of workgroups per
     // CU with 8-64 chunks of 4-8 MFMAs each: every iteration waited out the full latency of loads issued one short iteration earlier.
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
             const bool on = (vmask[i] >> (tap & 31)) & livebit;
             xs[i] = bf_load4(rx, on ? rowoff[i] + tapoff : -1, 0);  // (XB: the four dwords are 8 stored bf16 values)
         }
-        const int soff = kc * (BKT * 4);
+        const int soff = (k_first + kc) * (BKT * 4);
 #pragma unroll
         for (int i = 0; i < WR; ++i) ws[i] = bf_load4(rw, livebit ? woff[i] : -1, soff);
         ++kc;
@@ -186,6 +195,24 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         for (int it = 0; it < nk; ++it) step(it & 1, xsA, wsA);
     }
 
+    if (gridDim.y > 1) {  // raw partial sums of this split
+        float *part = d.workspace + (size_t)blockIdx.y * M * d.Cout;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + (wm * TM + mi) * 32 + (lane & 31);
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    if (n >= d.Cout) continue;
+                    const f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                    *reinterpret_cast<f32x4 *>(part + (size_t)m * d.Cout + n) = v;
+                }
+        }
+        return;
+    }
     const bool has_res = d.res != nullptr;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -226,19 +253,51 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
     }
 }
 
+// second launch of a split-K layer: the splits in order, then the epilogue of the kernel above (scale / shift, residual, activation, gate,
+// fp32 or bf16 stores), per output quad
+__global__ __launch_bounds__(256) void conv_bf16_reduce_kernel(const a3d_conv_desc d, const int M) {
+    const int n4 = d.Cout >> 2;
+    const size_t total = (size_t)M * n4;
+    const bool yb = d.io_bf16 & 2, rb = d.io_bf16 & 4, gb = d.io_bf16 & 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < d.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(d.workspace + ((size_t)z * M + m) * d.Cout + n);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+        if (d.scale) sc = *reinterpret_cast<const f32x4 *>(d.scale + n);
+        if (d.shift) sh = *reinterpret_cast<const f32x4 *>(d.shift + n);
+        const size_t o = (size_t)m * d.Cout + n;
+        if (d.res) rv = bf_read4(d.res, o, rb);
+        v = a3d_epilogue_math(d, v, sc, sh, d.res != nullptr, rv);
+        if (d.gate) {
+            const f32x4 g = bf_read4(d.gate, o, gb);
+            for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
+        }
+        bf_write4(d.y, o, v, yb);
+    }
+}
+
 template <int TN>
 void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     constexpr int BM = 128, BN = 64 * TN;
     const int M = d->B * d->Ho * d->Wo;
     const int mtiles = (M + BM - 1) / BM, ntiles = (d->Cout + BN - 1) / BN;
-    a3d_note_variant("conv_bf16_kernel<%d>", TN);
-    if (d->io_bf16 & 1) hipLaunchKernelGGL((conv_bf16_kernel<TN, true>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
-    else hipLaunchKernelGGL((conv_bf16_kernel<TN, false>), dim3(mtiles * ntiles), dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    a3d_note_variant(d->splitk > 1 ? "conv_bf16_kernel<%d> sk%d" : "conv_bf16_kernel<%d>", TN, d->splitk);
+    const dim3 grid(mtiles * ntiles, d->splitk);
+    if (d->io_bf16 & 1) hipLaunchKernelGGL((conv_bf16_kernel<TN, true>), grid, dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    else hipLaunchKernelGGL((conv_bf16_kernel<TN, false>), grid, dim3(256), 0, s, *d, M, ntiles, mtiles * ntiles);
+    if (d->splitk > 1) {
+        const size_t total = (size_t)M * (d->Cout >> 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv_bf16_reduce_kernel, dim3(blocks), dim3(256), 0, s, *d, M);
+    }
 }
 }  // namespace
 
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
-    if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk != 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk < 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
+    if (d->splitk > 1 && (!d->workspace || d->res_ups || d->splitk > d->Kpad / 32)) return A3D_ERR_ARG;  // (split-K: plain output rows only)
     if (d->io_bf16 & ~15) return A3D_ERR_ARG;
     if ((d->Cin & 31) || d->Kpad != d->KH * d->KW * d->Cin || d->KH * d->KW > 32) return A3D_ERR_UNSUPPORTED;
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;

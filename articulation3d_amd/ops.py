@@ -437,6 +437,23 @@ def _conv2d_blocks(x, p, nb, hw_out, *, x2, res, out, gate, m_dev, **kw):
     return out
 
 
+BF16_SPLITK = os.environ.get("A3D_BF16_SPLITK", "1") != "0"
+# (tiles at most, workgroups aimed at, chunks per split at least, chunks at least, splits at most)
+_BF16_SK_CFG = tuple(int(v) for v in os.environ.get("A3D_BF16_SPLITK_CFG", "128,256,12,24,8").split(","))
+
+
+def _bf16_splitk(M: int, cols: int, Kpad: int) -> int:
+    """Splits of the reduction for a bf16-arithmetic launch (csrc/conv_bf16.hip): layers whose 128 x 64 tiles leave most of the chip idle
+    while each walks a long reduction one memory round trip at a time (the training step at the reference's 2 images per GPU: 3x3
+    256 -> 256 on 2 x 30 x 40 pixels = 76 workgroups x 72 chunks).  A function of the layer's shape and the batch."""
+    tiles = -(-M // 128) * -(-cols // 64)
+    nk = Kpad // 32
+    maxtiles, target, per, minnk, cap = _BF16_SK_CFG
+    if not BF16_SPLITK or tiles > maxtiles or nk < minnk:
+        return 1
+    return int(max(1, min(cap, nk // per, target // tiles)))
+
+
 def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, precision, out_dtype) -> torch.Tensor:
     """The training step's bf16 (autocast) arithmetic with tensors stored as bf16 where the caller says so: plain conv / linear
     layers only (no stem, upsampling, concat, split-K, Winograd), precision 1."""
@@ -466,6 +483,11 @@ def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, prec
     d.precision = 1
     b16 = lambda t: t is not None and t.dtype == torch.bfloat16
     d.io_bf16 = (1 if b16(x) else 0) | (2 if b16(out) else 0) | (4 if b16(res) else 0) | (8 if b16(gate) else 0)
+    sk = 1 if res_ups else _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)
+    if sk > 1:
+        d.splitk = sk
+        ws = torch.empty(sk * B * Ho * Wo * p.cols, device=x.device, dtype=torch.float32)
+        d.workspace = ws.data_ptr()
     if CONV_TIMING is not None:  # (tools/train_bench.py's roofline leg: these launches carry most of the bf16 step's FLOPs)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -643,6 +665,10 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         else:
             precision = 0
     d.precision = int(precision)
+    if (d.precision == 1 and splitk == 1 and not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or m_dev is not None or res_ups)
+            and p.Kpad == p.KH * p.KW * p.Cin and p.Cin % 32 == 0):
+        splitk = _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)  # (bf16 arithmetic: small grids with long reductions)
+        d.splitk = splitk
     global _LAST_PRECISION
     _LAST_PRECISION = int(precision)
     d.phase = int(p.phase)

@@ -84,7 +84,8 @@ typedef struct a3d_conv_desc {
     int res_ups; /* 1: residual is nearest x2 upsampled (FPN top-down add)                          */
     int pixshuf; /* 1: ConvTranspose2d k2 s2 as GEMM with columns (dy,dx,co) scattered to 2x2 blocks */
     int stem;    /* 1: x is [B,H,W,4] (a3d_preprocess_*), 7x7 s2 p3, w packed [Cout][7][8][4]        */
-    int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch            */
+    int splitk;  /* >= 1; >1 writes partials to workspace and reduces in a second launch (precision 1: plain output rows
+                    only -- no res_ups / pixshuf / phase --, splitk <= Kpad / 32)                        */
     const int *m_dev; /* optional DEVICE int: live row count (<= B*Ho*Wo); tiles past it exit at once,
                          so ragged per-ROI batches need no host synchronisation                      */
     int tune;         /* 0 = library picks the kernel variant; 1 = (the round-1 general kernel: removed in round 4, A3D_ERR_UNSUPPORTED);
