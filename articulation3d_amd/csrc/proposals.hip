@@ -361,7 +361,8 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
 // 2 ms per launch on the 2M IoUs of a full group while 246 CUs idle): grid (G, 16), block y owns rows [128y, 128y+128).
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                        const int *__restrict__ g_n, float thr, u64 *__restrict__ gmask) {
-    constexpr int CAP = 2048, W = 32, ROWS = 128;
+    constexpr int CAP = 2048, W = 32;
+    const int ROWS = CAP / (int)gridDim.y;  // (128 rows per workgroup at 16 workgroups per group; 32 at 64, where few groups would leave the chip idle)
     __shared__ f32x4 sb[CAP];
     __shared__ unsigned char sv[CAP];
     const int g = blockIdx.x;
@@ -542,7 +543,9 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     } else {
         hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(d->L, d->B), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(G, 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
+        // (the suppression words of a group by 16 workgroups -- or 64 where the batch is a few images: the first row block of a group carries
+        // most of its upper-triangular work, and 10 groups x 16 blocks left the launch at the length of that one block: 0.23 ms)
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(G, G <= 40 ? 64 : 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
         hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask, 1, d->L);
         hipLaunchKernelGGL((merge_topk_kernel<2048, 16384>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
