@@ -13,6 +13,7 @@
 // 32-deep k chunk, the LDS-staged epilogue.  LDS image: [row][32 k] bf16 with an 80-byte row pitch -- a fragment is
 // ONE ds_read_b128 (8 consecutive k of one row), and 16 rows x 80 B tile the 64 banks exactly once per lane group.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -303,7 +304,12 @@ int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 32) || (size_t)d->Cout * d->Kpad * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
     const int M = d->B * d->Ho * d->Wo;
     const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
-    if (d->Cout <= 64 || n128 <= 1000) launch_bf16<1>(d, s);
+    // (the 128 x 64 tile on small grids -- except deep reductions: the box head's fc1, K = 12544, moves 24 KiB per chunk and 128 x 64 tile
+    // through L2 for 0.5 MFLOP, 383 TFLOP/s at 16 images: 842 -> 848 images/s; under 256 tiles -- 2 images -- the narrow tile
+    // with split-K stays ahead; env A3D_BF16_DEEP_WIDE=0 restores the narrow tile everywhere)
+    static int deep_wide = -1;
+    if (deep_wide < 0) deep_wide = getenv("A3D_BF16_DEEP_WIDE") ? atoi(getenv("A3D_BF16_DEEP_WIDE")) : 1;
+    if (d->Cout <= 64 || (n128 <= 1000 && !(deep_wide && d->Kpad >= 4096 && d->Cout >= 128 && n128 >= 256))) launch_bf16<1>(d, s);
     else launch_bf16<2>(d, s);
     return a3d_check_launch();
 }
