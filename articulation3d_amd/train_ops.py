@@ -15,6 +15,7 @@ from .ops import _p, _req, _stream
 ROI_BWD_GATHER = os.environ.get("A3D_ROI_BWD_GATHER", "1") != "0"
 # workgroups a transposed-read weight-gradient launch aims for (pixel slices = this / the layer's tiles): ONE round of the 256 CUs -- measured 512 / 384 / 256 / 192 / 128: 792 / 787 / 812-822 / 801 / 768 images/s at 16 images (every slice costs the reduce launch a read of the layer's gradient)
 WGRAD_TR_WORKGROUPS = int(os.environ.get("A3D_WGRAD_TR_WGS", "256"))
+WGRAD_TR_MIN_PIXELS = int(os.environ.get("A3D_WGRAD_TR_MINPX", "256"))  # pixels per slice at least (4 chunks of 64; 512 / 256 / 128: 312 / 318 / 312 images/s at 2 images)
 
 
 def choose_wgrad_slices(P: int, tiles: int) -> int:
@@ -86,8 +87,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     form = _lib.lib().a3d_wgrad_tiles(C.byref(d), C.byref(tiles), C.byref(red))  # the kernel form the library runs this layer on
     if splitk:
         d.splitk = int(splitk)
-    elif form > 0:  # transposed-read form (one 512-thread workgroup per CU, 64-pixel chunks): one round of the chip, >= 8 chunks per slice
-        d.splitk = int(max(1, min(WGRAD_TR_WORKGROUPS // max(tiles.value, 1), red.value // 512, 256)))
+    elif form > 0:  # transposed-read form (one 512-thread workgroup per CU, 64-pixel chunks): one round of the chip, >= 4 chunks per slice
+        d.splitk = int(max(1, min(WGRAD_TR_WORKGROUPS // max(tiles.value, 1), red.value // WGRAD_TR_MIN_PIXELS, 256)))
     else:
         d.splitk = choose_wgrad_slices(B * Ho * Wo, tiles.value)
     nbytes = _lib.lib().a3d_wgrad_workspace_bytes(C.byref(d))
