@@ -831,3 +831,31 @@ def test_batched_launches_give_the_per_layer_launches_bits(hip_model, oracle, pr
     assert max(spread.values()) == 0.0, {k: v for k, v in spread.items() if v > 0}
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_roi_align_backward_gather_at_the_training_step_size(T):
+    """BASELINE configs[4]'s shapes (16 images x 512 sampled ROIs, 7x7 bins, 256 channels, the four pyramid levels of a 480x640 frame), boxes
+    clustered around a few objects as the sampler leaves them: the tile-gather form against the float-atomics form (fp32 rounding of the
+    sums) and against itself (bit for bit) -- the property that makes the whole training step reproducible."""
+    g = torch.Generator().manual_seed(5)
+    B, R, C = 16, 512, 256
+    ctr = torch.rand(B, 6, 2, generator=g) * torch.tensor([560.0, 400.0]) + 40
+    pick = torch.randint(0, 6, (B, R), generator=g)
+    c = torch.gather(ctr, 1, pick[:, :, None].expand(B, R, 2)) + torch.randn(B, R, 2, generator=g) * 25
+    wh = torch.rand(B, R, 2, generator=g) * 380 + 20
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 2).clamp(min=0)
+    boxes[..., 2].clamp_(max=640)
+    boxes[..., 3].clamp_(max=480)
+    boxes = boxes.cuda().contiguous()
+    dout = torch.randn(B * R, 7, 7, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    mk = lambda: [torch.zeros(B, 480 // s, 640 // s, C, device="cuda") for s in (4, 8, 16, 32)]
+    a, a2, sc = mk(), mk(), mk()
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    T.roi_align_fpn_backward(a, scales, boxes, dout, P=7, sampling_ratio=0, aligned=True)
+    T.roi_align_fpn_backward(a2, scales, boxes, dout, P=7, sampling_ratio=0, aligned=True)
+    T.roi_align_fpn_backward(sc, scales, boxes, dout, P=7, sampling_ratio=0, aligned=True, scatter=True)
+    assert all(torch.equal(p, q) for p, q in zip(a, a2))
+    num = sum(float((p.double() - q.double()).pow(2).sum()) for p, q in zip(a, sc)) ** 0.5
+    den = sum(float(q.double().pow(2).sum()) for q in sc) ** 0.5
+    assert num / den < 1e-6, num / den
+    assert all(bool(torch.isfinite(p).all()) for p in a) and den > 0
