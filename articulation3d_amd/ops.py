@@ -618,7 +618,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         assert not ups and out is not None, "phase convs run on the source grid and fill a shared [B,2H,2W,C] output"
         Ho, Wo = H, W
         if p.phase == 5:
-            assert precision == 3 and tuple(out.shape) == (B, 2 * H, 2 * W, p.cols // 4), "the fused four-phase form is an fp16x2 launch"
+            assert precision == 3 and (dot is not None or tuple(out.shape) == (B, 2 * H, 2 * W, p.cols // 4)), "the fused four-phase form is an fp16x2 launch"
     if out is None:
         shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
@@ -637,6 +637,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     if dot is not None:  # (phase 5 only: the nine tap products of a following 3x3 convolution to one channel instead of the output)
         assert p.phase == 5 and precision == 3
         d.dot_w, d.dot_y = _req(dot[0]).data_ptr(), _req(dot[1]).data_ptr()
+        d.y = None  # (`out` is the tap-product tensor itself, kept as the handle of the recorded maxima: the [B,2H,2W,C] output is never formed)
     wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7, 8) or tune >= 200) and not ups
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
@@ -896,9 +897,8 @@ def conv2d_ups_to1(x: torch.Tensor, phases: Sequence[PackedConv], w9: torch.Tens
         phases[0]._fused = pf if pf is not None else False
     if not pf:
         return None
-    out = torch.empty((B, 2 * H, 2 * W, 64), device=x.device, dtype=torch.float32)  # (never written: the launch stores the tap products)
     g = torch.empty((B, 9, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-    conv2d(x, pf, x2=x2, out=out, precision=3, dot=(w9.reshape(9, 64), g))
+    conv2d(x, pf, x2=x2, out=g, precision=3, dot=(w9.reshape(9, 64), g))
     y = torch.empty((B, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().a3d_tapsum9(g.data_ptr(), float(bias), y.data_ptr(), B, 2 * H, 2 * W, _stream()), "a3d_tapsum9")
     return y
