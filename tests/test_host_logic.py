@@ -323,3 +323,17 @@ def test_bench_labels_map_onto_the_kernels_of_the_committed_profile():
     # region: they agree to the spread of launch sizes, not to the digit)
     assert 0.7 < avg_us / (roof["avg_launch_ms"] * 1e3) < 1.3, (avg_us, roof["avg_launch_ms"])
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3)
+
+
+def test_split_k_rule_of_the_bf16_conv_kernel_is_a_function_of_the_shape():
+    """Round 4: ops._bf16_splitk (csrc/conv_bf16.hip's split-K, training step only).  Splits only where the 128 x 64 tiles leave most of the
+    chip idle AND the reduction is long; never more splits than chunks allow; large grids and short reductions stay whole."""
+    from articulation3d_amd import ops
+
+    assert ops._bf16_splitk(2 * 30 * 40, 256, 9 * 256) == 3       # res4 conv2 at 2 images: 76 tiles x 72 chunks
+    assert ops._bf16_splitk(2 * 15 * 20, 512, 9 * 512) == 6       # res5 conv2: 40 tiles x 144 chunks
+    assert ops._bf16_splitk(2 * 30 * 40, 1024, 256) == 1          # a short reduction
+    assert ops._bf16_splitk(16 * 120 * 160, 256, 9 * 256) == 1    # a grid that fills the chip
+    for M, cols, K in ((100, 64, 32 * 24), (2400, 256, 32 * 1000), (1, 32, 32 * 24)):
+        sk = ops._bf16_splitk(M, cols, K)
+        assert 1 <= sk <= 8 and sk <= K // 32
