@@ -15,7 +15,7 @@ from torch import nn
 
 from .. import ops
 from ..registry import DEPTH_HEAD_REGISTRY
-from .layers import ACT_LEAKY, ACT_RELU, BNConv2d, to_nhwc
+from .layers import ACT_LEAKY, ACT_RELU, BNConv2d, _CalibrationState, to_nhwc
 
 __all__ = ["build_depth_head", "PlaneRCNNDepthHead", "DEPTH_HEAD_REGISTRY"]
 
@@ -78,7 +78,9 @@ class PlaneRCNNDepthHead(nn.Module):
         w, b = self._pred_packed()
         c5 = C(5, feats["p2"])
         # deconv5 + depth_pred without the 64-channel 240x320 tensor between them (default arithmetic; ops.conv2d_ups_to1)
-        d = ops.conv2d_ups_to1(c5, self._pk_deconv[4].packed_phases(), w, b, x2=x) if not self.training else None
+        # (not while batch-norm statistics are being calibrated: deconv5's BN is calibrated in BNConv2d.forward, which the fused form skips)
+        fused = not self.training and not _CalibrationState.active
+        d = ops.conv2d_ups_to1(c5, self._pk_deconv[4].packed_phases(), w, b, x2=x) if fused else None
         if d is None:
             x = D(5, c5, x)  # [B,240,320,64]
             d = ops.conv3x3_to1(x, w, b)  # [B,240,320]

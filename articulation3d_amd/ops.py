@@ -404,6 +404,8 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
         Wo_ = x.shape[2] if p.phase else (Wl_ + 2 * p.pad - p.KW) // p.stride + 1
         per_in = x.shape[1] * x.shape[2] * max(x.shape[3], 0 if x2 is None else x2.shape[3]) * 4
         per_out = Ho_ * Wo_ * p.cols * 4 * (4 if 0 < p.phase < 5 else 1) * max(1, int(splitk))
+        if dot is not None:  # the tap-product epilogue stores nine planes of the 2x map, not the 64-channel tensor
+            per_out = 9 * 4 * Ho_ * Wo_ * 4
         per_v = ((Hl_ + 1) // 2) * ((Wl_ + 1) // 2) * (x.shape[3] + (0 if x2 is None else x2.shape[3])) * 4 if p.w_wino is not None else 0
         per = max(per_in, per_out, per_v, 1)
         if B * per > _ADDR_LIMIT:
@@ -889,18 +891,26 @@ def conv2d_ups_to1(x: torch.Tensor, phases: Sequence[PackedConv], w9: torch.Tens
     if not (DEPTH_PRED_FUSED and UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned and AUDIT is None and phases[0].cols == 64):
         return None
     B, H, W, C = x.shape
-    if B * 4 * H * W * 64 * 4 > _ADDR_LIMIT or B * H * W * C * 4 > _ADDR_LIMIT:
-        return None
     pf = getattr(phases[0], "_fused", None)
     if pf is None:
         pf = pack_conv_ups_fused(phases)
         phases[0]._fused = pf if pf is not None else False
     if not pf:
         return None
-    g = torch.empty((B, 9, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-    conv2d(x, pf, x2=x2, out=g, precision=3, dot=(w9.reshape(9, 64), g))
+    # What one launch addresses: the nine tap-product planes g [B,9,2H,2W] and the input(s) -- the [B,2H,2W,64] tensor is never
+    # allocated.  A batch past the 32-bit offsets runs as blocks of images through the SAME two kernels (per-image arithmetic: the
+    # bits of a frame do not depend on the block it travels in), never through another algorithm.
+    per_image = max(9 * 4 * H * W * 4, H * W * C * 4, 0 if x2 is None else x2.shape[1] * x2.shape[2] * x2.shape[3] * 4)
+    nb = max(1, min(B, _ADDR_LIMIT // per_image))
     y = torch.empty((B, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.lib().a3d_tapsum9(g.data_ptr(), float(bias), y.data_ptr(), B, 2 * H, 2 * W, _stream()), "a3d_tapsum9")
+    w9 = w9.reshape(9, 64)
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        cut = lambda t: t if (t is None or nb >= B) else keep_amax(t[b0:b1], _amax_rows(t, b0, b1))
+        xb, x2b = cut(x), cut(x2)
+        g = torch.empty((b1 - b0, 9, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        conv2d(xb, pf, x2=x2b, out=g, precision=3, dot=(w9, g))
+        _lib.check(_lib.lib().a3d_tapsum9(g.data_ptr(), float(bias), y[b0:b1].data_ptr(), b1 - b0, 2 * H, 2 * W, _stream()), "a3d_tapsum9")
     return y
 
 

@@ -234,3 +234,12 @@ def test_tap_product_epilogue_equals_the_two_layers(ops, shape):
     if B > 1:  # batch invariance, bit for bit
         alone = ops.conv2d_ups_to1(a[1:2].contiguous(), phases, w9, 0.3, x2=c2[1:2].contiguous())
         assert torch.equal(alone[0], one[1])
+        # a batch past the 32-bit offsets of one launch runs as blocks of images through the SAME two kernels (advisor, round 4: it used to
+        # switch to the two-layer form, another summation order): shrink the limit so that this batch needs one launch per image
+        limit = ops._ADDR_LIMIT
+        try:
+            ops._ADDR_LIMIT = max(9 * 4 * H * W * 4, H * W * 128 * 4)
+            blocks = ops.conv2d_ups_to1(a, phases, w9, 0.3, x2=c2)
+        finally:
+            ops._ADDR_LIMIT = limit
+        assert blocks is not None and torch.equal(blocks, one)
