@@ -90,6 +90,7 @@ class RoiAlignDesc(C.Structure):
         ("out", fptr), ("out_level", fptr), ("order_ws", fptr),
         ("out_amax", fptr), ("level_amax", fptr * 4), ("window_count", fptr),
         ("out_h2", fptr),
+        ("serial", C.c_int),
     ]
 
 

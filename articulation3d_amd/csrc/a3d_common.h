@@ -10,6 +10,19 @@
 
 #define A3D_WAVE 64
 
+// The library reads NO environment variable and keeps no process-global switch (include/a3d.h: re-entrant, no global state): every A/B
+// choice that survives in the tree is either a descriptor field or a compile-time constant.  Developer builds (-DA3D_ABLATIONS, used by
+// the tools/*_abl.sh and A/B scripts only) may override such a constant from the environment, read at every call.
+#ifdef A3D_ABLATIONS
+#include <stdlib.h>
+static inline long a3d_dev_knob(const char *name, long dflt) {
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+#else
+#define a3d_dev_knob(name, dflt) (dflt)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -306,9 +306,8 @@ int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     const long n128 = (long)((M + 127) / 128) * ((d->Cout + 127) / 128);
     // (the 128 x 64 tile on small grids -- except deep reductions: the box head's fc1, K = 12544, moves 24 KiB per chunk and 128 x 64 tile
     // through L2 for 0.5 MFLOP, 383 TFLOP/s at 16 images: 842 -> 848 images/s; under 256 tiles -- 2 images -- the narrow tile
-    // with split-K stays ahead; env A3D_BF16_DEEP_WIDE=0 restores the narrow tile everywhere)
-    static int deep_wide = -1;
-    if (deep_wide < 0) deep_wide = getenv("A3D_BF16_DEEP_WIDE") ? atoi(getenv("A3D_BF16_DEEP_WIDE")) : 1;
+    // with split-K stays ahead; developer builds: A3D_BF16_DEEP_WIDE=0 restores the narrow tile everywhere)
+    const int deep_wide = (int)a3d_dev_knob("A3D_BF16_DEEP_WIDE", 1);
     if (d->Cout <= 64 || (n128 <= 1000 && !(deep_wide && d->Kpad >= 4096 && d->Cout >= 128 && n128 >= 256))) launch_bf16<1>(d, s);
     else launch_bf16<2>(d, s);
     return a3d_check_launch();

@@ -555,7 +555,7 @@ void launch_x3(const a3d_conv_desc *d, hipStream_t s) {
 }  // namespace
 
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
-    static const bool direct_epilogue = [] { const char *e = getenv("A3D_X3_DIRECT_EPILOGUE"); return e && e[0] == '1'; }();  // A/B runs
+    const bool direct_epilogue = a3d_dev_knob("A3D_X3_DIRECT_EPILOGUE", 0) == 1;  // (developer builds, A/B runs; tune 12 selects the same form per launch)
     a3d_conv_desc dd;
     const a3d_conv_desc *d = d0;
     if (direct_epilogue && d0->tune == 0) {

@@ -45,7 +45,7 @@ extern "C" const char *a3d_last_conv_variant(void) { return g_last_variant; }
 extern "C" size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d) {
     if (!d) return 0;
     if (d->tune == 0 && a3d_wino_fused_eligible(d)) return 0;
-    if ((d->tune == 0 || d->tune == 7 || d->tune == 8 || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
+    if ((d->tune == 0 || d->tune == 7 || d->tune == 8 || (d->tune >= 23 && d->tune <= 25) || d->tune >= 200) && a3d_wino_eligible(d)) return a3d_wino_workspace_bytes(d);
     if (d->splitk <= 1) return 0;
     return (size_t)d->splitk * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
@@ -57,12 +57,13 @@ extern "C" int a3d_conv2d_nhwc_f32(const a3d_conv_desc *d, void *stream) {
     a3d_begin();
     if (d->precision == 1) return a3d_conv_launch_bf16(d, s);  // (A3D_ERR_UNSUPPORTED for layer kinds it does not cover)
     if (d->precision == 2) {  // Winograd layers keep the Winograd form (split-operand GEMM, conv_wino.hip 2x), the rest go direct
-        if ((d->tune == 0 || d->tune == 8) && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+        if ((d->tune == 0 || d->tune == 8 || d->tune == 24 || d->tune == 25) && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
         return a3d_conv_launch_bf16x3(d, s);
     }
     if (d->precision == 3 && d->x_h2) return a3d_conv_launch_bf16x3_wide(d, s);  // pre-split activations: the dual-DMA forms only
     if (d->precision == 3) {  // fp16x2 split: Winograd layers (wide kernels) when their pre-split filter is given, the rest direct
-        if (d->tune == 0 && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d)) return a3d_conv_launch_wino(d, s);
+        if ((d->tune == 0 || d->tune == 23 || d->tune == 24) && d->workspace && d->w_wino && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && a3d_wino_eligible(d))
+            return a3d_conv_launch_wino(d, s);
         return a3d_conv_launch_bf16x3(d, s);
     }
     if (d->precision != 0) return A3D_ERR_ARG;

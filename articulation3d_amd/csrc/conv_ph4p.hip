@@ -414,8 +414,7 @@ static inline long pp_covered(int H, int W, int TW) {
     return (long)((W + TW - 1) / TW) * TW * ((H + TH - 1) / TH) * TH;
 }
 static inline int pp_tile_width(int H, int W) {
-    static int force = -1;
-    if (force < 0) force = getenv("A3D_PP_TW") ? atoi(getenv("A3D_PP_TW")) : 0;  // (A/B runs: 16 | 32)
+    const int force = (int)a3d_dev_knob("A3D_PP_TW", 0);  // (developer builds, A/B runs: 16 | 32)
     if (force == 16 || force == 32) return force;
     return pp_covered(H, W, 16) < pp_covered(H, W, 32) ? 16 : 32;
 }

@@ -297,13 +297,13 @@ extern "C" int a3d_stem_conv_pool(const a3d_conv_desc *d, void *stream) {
     if ((size_t)d->B * d->H * d->W * 16 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
     const int Hp = (d->Ho - 1) / 2 + 1, Wp = (d->Wo - 1) / 2 + 1;
     a3d_begin();
-    static int cus = 0, form = -1;
+    int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
         int dev = 0;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    if (form < 0) form = getenv("A3D_STEM_TILE") ? atoi(getenv("A3D_STEM_TILE")) : 0;  // (A/B runs: 2 = the 3 x 8 tile, two workgroups per CU)
+    const int form = (int)a3d_dev_knob("A3D_STEM_TILE", 0);  // (developer builds, A/B runs: 2 = the 3 x 8 tile, two workgroups per CU)
     a3d_note_variant("stem_pool_kernel");
     // (measured at 64 frames: 6 x 9 tiles 0.705 ms, 3 x 8 tiles with two workgroups per CU 0.728 -- what a tile costs beside its MFMAs is
     // vector work of the pool and the epilogue, which a second workgroup on the same SIMDs does not hide)

@@ -233,9 +233,7 @@ int tr_launch_io(const a3d_wgrad_desc *d, hipStream_t s, const int Pp, const int
 
 // 0: not a layer of this form (the caller runs conv_wgrad_bf16_kernel); 3 / 1: taps per workgroup
 int a3d_wgrad_tr_form(const a3d_wgrad_desc *d) {
-    static int off = -1;
-    if (off < 0) off = getenv("A3D_WGRAD_TR") ? atoi(getenv("A3D_WGRAD_TR")) == 0 : 0;  // (A/B runs: A3D_WGRAD_TR=0 keeps the first form)
-    if (off || d->precision != 1 || d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return 0;
+    if (a3d_dev_knob("A3D_WGRAD_TR", 1) == 0 || d->precision != 1 || d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return 0;
     if (((d->io_bf16 & 1) && (d->Cin & 7)) || ((d->io_bf16 & 2) && (d->Cout & 7))) return 0;
     if ((size_t)d->B * d->Ho * d->Wo * d->Cout * 4 >= ((size_t)1 << 31) || (size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31)) return 0;
     if (d->KH == 3 && d->KW == 3 && d->pad == 1) return (size_t)d->B * d->Ho * (d->Wo + 2) < ((size_t)1 << 21) ? 3 : 0;  // (the float divisions of the loader are exact below 2^21)

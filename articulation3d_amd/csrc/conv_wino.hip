@@ -649,8 +649,9 @@ constexpr int x3w_lds_bytes(int WM, int NP) { return x3w_stages(WM, NP) * x3w_bu
 // PS (plane-split, small problems): blockIdx.y = Winograd plane; the workgroup runs that plane's k loop only and stores the raw product
 // tile to a.M [16][T][Cout]; wino_fold_kernel then folds the 16 planes in the same order and applies the same epilogue.  A problem of
 // a few tile blocks otherwise occupies a few CUs for 16 x C/32 latency-bound iterations (a single 30x40 frame: 6 workgroups, 116 us).
-template <int WM, bool F16 = false, bool PS = false>
+template <int WM, bool F16 = false, bool PS = false, int PP = 0>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
+    static_assert(PP == 0 || (F16 && !PS && WM == 4), "ping-pong: the 512-thread fp16x2 form (two waves per SIMD)");
     constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
@@ -955,6 +956,92 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             rdB(F0, 0, 0, p);
         }
         int cf = 0, ckc = 0;
+        if constexpr (PP > 0) {
+            // PING-PONG (round 5).  In the loop below all eight waves run the same instruction stream from the same barrier: the two
+            // waves of a SIMD reach their DMA issue (60-185 cycles each, four per wave and chunk), their fragment waits and the barrier
+            // together, and the matrix pipe idles through all three (0.375 busy; without the DMAs the launch is 20 % shorter).  Here
+            // waves 4-7 (the SIMD partners of waves 0-3: waves go to SIMDs 0, 2, 1, 3, 0, ..) run HALF A CHUNK behind, and every wave
+            // bunches its work: a MEMORY phase (the 12 fragment reads of a whole chunk + its 4 DMA pieces) and a COMPUTE phase (the
+            // chunk's 12 MFMAs back to back, then the fold when a plane ends).  Between two barriers waves 0-3 run memory(c), compute(c)
+            // and waves 4-7 compute(c - 1), memory(c): one wave of each SIMD multiplies while its partner issues memory instructions.
+            // Ring: between BAR_c and BAR_c+1 every wave reads stage(c) only, so the DMA of chunk c - 1 + NST goes into stage(c - 1)
+            // (all its reads lie before BAR_c); chunk c + 1 has landed before BAR_c+1 (own pieces: counted vmcnt; the others': the
+            // barrier).  Same planes, chunks, steps and terms per accumulator as the lockstep loop: the bits do not change.
+            constexpr int OPSP = DPW + DPV;
+            const bool grpB = wave >= NW / 2;
+            int stp = NST - 1;  // stage of the chunk before the one being read
+            auto rd_all = [&]() {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    rdA(F0, st, 0, p);
+                    rdB(F0, st, 0, p);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    rdA(F1, st, 1, p);
+                    rdB(F1, st, 1, p);
+                }
+            };
+            auto compute = [&]() {
+                X3W_FENCE
+                X3W_TERM(F0, 0, 0)
+                X3W_TERM(F0, 0, 1)
+                X3W_TERM(F0, 1, 0)
+                X3W_TERM(F1, 0, 0)
+                X3W_TERM(F1, 0, 1)
+                X3W_TERM(F1, 1, 0)
+                X3W_FENCE
+            };
+            auto plane_end = [&]() {
+                if (++ckc == KC) {
+                    ckc = 0;
+                    fold(mf, cf++);
+                }
+            };
+            auto advance = [&]() {
+                stp = st;
+                st = st == NST - 1 ? 0 : st + 1;
+            };
+            // ONE instruction stream for both halves; only the barrier's place differs: waves 0-3 run memory, compute, BARRIER, waves 4-7
+            // memory, BARRIER, compute -- so between two barriers the former run memory(c), compute(c) and the latter compute(c - 1),
+            // memory(c).
+            for (int it = 0; it < nit; ++it) {
+                X3W_FENCE
+                if (it > 0) plane_end();  // (the fold of the chunk multiplied last, in front of the reads: the fragment registers are free)
+#ifdef A3D_ABLATIONS  // timing-only (results wrong): bit 0 no V DMA, 1 no filter DMA, 3 no fragment reads, 5 no MFMAs
+                if (!(a.abl & 8)) rd_all();
+                if (it > 0) {
+                    if (!(a.abl & 1)) dma_v(stp, dma_c);
+                    if (!(a.abl & 2)) dma_w(stp);
+                    else ++dma_c;
+                }
+#else
+                rd_all();
+                if (it > 0) {
+                    dma_v(stp, dma_c);  // chunk it - 1 + NST into the stage of chunk it - 1
+                    dma_w(stp);
+                }
+#endif
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (grpB) {
+                    __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPSP) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+#ifdef A3D_ABLATIONS
+                if (!(a.abl & 32))
+#endif
+                compute();
+                if (!grpB) {
+                    __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPSP) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                advance();
+            }
+            plane_end();
+            // the DMAs past the last chunk land anywhere in the ring, the epilogue's tiles use the V areas of stages 0 and 1
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
         // (Round 4, measured and not taken: the six fragment reads of a step pinned behind the first three MFMAs of the step before it
         // with sched_group_barriers -- hipcc sinks them to the end of each half, in front of the `lgkmcnt(0)` waits -- 2.16 | 2.26 ms on
         // the p2 layer across two boxes: no gain.  Timing-only decomposition of this loop, p2 256 -> 256, 2.30 ms (tools/wino_abl.sh,
@@ -1033,6 +1120,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         // the DMAs past the last chunk land anywhere in the ring, the epilogue's tiles use the V areas of stages 0 and 1
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        }
     } else {
     // prologue: W(0), W(1) by DMA; V(0) split into stage 0; V(1), V(2) staged in registers; S0(0) read
     dma_w(0);
@@ -1327,8 +1415,7 @@ size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
 // their tiles: 0.218 | 0.216 ms (hybrid | plain), 60x80 256 -> 128 0.475 | 0.416: ring fill, raw-tile epilogue, the M round trip and two
 // more launches cost what the short round costs.)
 extern "C" size_t a3d_wino_m_bytes(const a3d_conv_desc *d) {
-    static int ps_max = -1;
-    if (ps_max < 0) ps_max = getenv("A3D_WINO_PS_BLOCKS") ? atoi(getenv("A3D_WINO_PS_BLOCKS")) : 48;
+    const long ps_max = a3d_dev_knob("A3D_WINO_PS_BLOCKS", 48);
     if (!d || d->precision != 3 || !a3d_wino_eligible(d)) return 0;
     const int C = d->Cin + d->Cin2;
     if ((C & 63) || ((d->Cout + 63) / 64) % 2 != 0) return 0;  // (an even number of 32-deep chunks per plane; the wide tiles' channel blocks)
@@ -1386,29 +1473,26 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.w_scale = d->w_scale;
     a.M = nullptr;
     a.abl = 0;
-#ifdef A3D_ABLATIONS
-    a.abl = getenv("A3D_WINO_ABL") ? atoi(getenv("A3D_WINO_ABL")) : 0;
-#endif
+    a.abl = (int)a3d_dev_knob("A3D_WINO_ABL", 0);
     if (d->precision == 3) {  // fp16x2: the wide kernels only (w_wino_x3 = the filter pre-split by a3d_split_f16x2_chunk(.., 32, w_scale))
         if (!d->w_wino_x3 || (a.C & 31) || !d->in_amax || !(d->w_scale > 0.f) || ((d->Cout + 63) / 64) % 2 != 0 ||
             (size_t)16 * d->Cout * a.C * 4 >= ((size_t)1 << 32))
             return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
-        static int wm_force3 = -1;
-        if (wm_force3 < 0) wm_force3 = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
         const int nt = (d->Cout + X3W_BN - 1) / X3W_BN;
-        const long blocks4 = (long)((T + 127) / 128) * nt;
-        // 64-tile blocks, two independent 256-thread workgroups per CU (with two operand planes the stage is 24 KiB: their barriers
-        // decouple), except where the 128-tile blocks finish in ONE round of the chip (small maps, a few hundred ROIs).  Measured
-        // (ms, 64-tile | 128-tile): p2 256 -> 256 2.67 | 2.66, 60x80x256 0.73 | 0.75, 30x40x256 0.26 | 0.29, 15x20x512 0.25 | 0.24,
-        // 276 ROIs 0.20 | 0.19.  Same kernel template, same operation order: bit-identical.
-        // (with both operands by DMA through a 3- / 4-stage ring: p2 256 -> 256 2.42 | 2.25, 60x80 0.68 | 0.69, 30x40 0.21 | 0.22, 276 ROIs
-        // 0.117 | 0.115 -- the 128-tile form issues 4 instead of 6 DMA instructions per wave and chunk and wins on the largest maps too)
-        const int wmx = wm_force3 ? wm_force3 : ((blocks4 <= 256 || blocks4 >= 2400) ? 4 : 2);
+        // 128-tile blocks, one 512-thread workgroup per CU, ping-pong loop -- on every problem size.  Until round 4 the mid-sized problems
+        // (256 .. 2400 blocks) took 64-tile blocks with two independent 256-thread workgroups per CU, whose barriers decouple (60x80x256
+        // 0.68 | 0.69 ms, 30x40 0.21 | 0.22); with the two halves of the 512-thread workgroup in antiphase the wide form is ahead
+        // everywhere (profiles/r05_wino_pp.txt, 64-tile | 128-tile lockstep | 128-tile ping-pong: 30x40x256 0.215 | 0.237 | 0.211,
+        // 60x80x256 0.676 | 0.697 | 0.599, 1000 ROIs 0.469 | 0.444 | 0.398, 32 frames of p2 1.200 | 1.197 | 1.091, 15x20x512 0.209 | 0.199
+        // | 0.164) and moves two thirds of the narrow form's operand bytes.  Same kernel template, same operation order per output: the
+        // three forms are bit-identical (tune 24: 64-tile blocks, tune 23: the lockstep loop; tests/test_gpu_parity.py).
+        const int wmx = d->tune == 24 ? 2 : 4;
         static a3d_attr_once attr3;
         if (attr3.needed()) {
             if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(2, 2)) != hipSuccess)
                 return A3D_ERR_LAUNCH;
             attr3.mark();
@@ -1424,7 +1508,9 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         a3d_note_variant("wino_gemm_h2w_kernel<%d>", wmx);
         if (wmx == 4) {
             const int m4 = (int)((T + 127) / 128);
-            hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), s, a, nt, m4 * nt);
+            // ping-pong loop (round 5; tune 23: the lockstep loop it replaces -- A/B runs and the bit-equality test)
+            if (d->tune == 23) hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), s, a, nt, m4 * nt);
+            else hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true, false, 1>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), s, a, nt, m4 * nt);
         } else {
             hipLaunchKernelGGL((wino_gemm_x3w_kernel<2, true>), dim3(mtiles * nt), dim3(256), x3w_lds_bytes(2, 2), s, a, nt, mtiles * nt);
         }
@@ -1439,9 +1525,8 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
         // its rate, i.e. one narrow round costs ~0.86 of a wide one.  Measured (tools/x3w_check.py, ms wide | narrow): p2 256->256
         // 3.50 | 4.15, 60x80x256 0.97 | 1.08, 276 ROIs of 14x14 0.18 | 0.28 (one partial round instead of two), 1600 ROIs 1.07 | 1.30,
         // 30x40x256 0.34 | 0.34, 15x20x512 0.33 | 0.34.
-        // tune 8: the narrow form everywhere; A3D_X3W_WM=2|4 forces a wide form (A/B runs and the bit-equality test).
-        static int wm_force = -1;
-        if (wm_force < 0) wm_force = getenv("A3D_X3W_WM") ? atoi(getenv("A3D_X3W_WM")) : 0;
+        // tune 8: the narrow form everywhere; tune 24 | 25 force the 64- | 128-tile wide form (A/B runs and the bit-equality test).
+        const int wm_force = d->tune == 24 ? 2 : (d->tune == 25 ? 4 : 0);
         const int ntw = (d->Cout + X3W_BN - 1) / X3W_BN;
         const long blocks_w = (long)((T + 127) / 128) * ntw, blocks_n = (long)mtiles * ((d->Cout + 63) / 64);
         const long rounds_w = (blocks_w + 255) / 256, rounds_n = ((blocks_n + 255) / 256 + 2) / 3;

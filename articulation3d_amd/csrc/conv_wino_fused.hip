@@ -339,11 +339,7 @@ int a3d_wino_fused_eligible(const a3d_conv_desc *d) {
     // measured (tools/wino_fused_check.py): ahead of the two-launch form from the p3 level (30x40 tiles per image) upwards -- 64- and
     // 128-channel layers by 15-30 %, 256-channel ones by 2-5 % -- behind it on the small maps (p4 and below, the 14x14 ROI heads),
     // where one workgroup per CU leaves the chip half empty in the last round.  A3D_WINO_FUSED_MIN_TILES overrides (A/B runs).
-    static long min_tiles = -1;
-    if (min_tiles < 0) {
-        const char *e = getenv("A3D_WINO_FUSED_MIN_TILES");
-        min_tiles = e ? atol(e) : 1200;
-    }
+    const long min_tiles = a3d_dev_knob("A3D_WINO_FUSED_MIN_TILES", 1200);
     if ((long)Ty * Tx < min_tiles) return 0;
     if ((size_t)d->B * nby * nbx >= ((size_t)1 << 24)) return 0;
     return 1;

@@ -363,8 +363,7 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     a.aligned = d->aligned;
     a.out = d->out;
     a.out_level = d->out_level;
-    const char *ser = getenv("A3D_ROI_SERIAL");
-    a.serial = ser && ser[0] == '1';
+    a.serial = d->serial == 1;
     a.order = nullptr;
     a.nblk = d->B * d->R;
     a.out_amax = d->out_amax;

@@ -640,7 +640,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         assert p.phase == 5 and precision == 3
         d.dot_w, d.dot_y = _req(dot[0]).data_ptr(), _req(dot[1]).data_ptr()
         d.y = None  # (`out` is the tap-product tensor itself, kept as the handle of the recorded maxima: the [B,2H,2W,C] output is never formed)
-    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7, 8) or tune >= 200) and not ups
+    wino_ok = (p.w_wino is not None and res is None and splitk == 1 and m_dev is None and (tune in (0, 7, 8, 23, 24, 25) or tune >= 200) and not ups
                and (wino if wino is not None else True))
     if precision is None or precision == "bf16x3":  # a MODE (module default, or the caller's "bf16x3"): pick per layer kind
         mode = DEFAULT_PRECISION if precision is None else 2
@@ -691,7 +691,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     # batch / ROI count (a frame's result would otherwise depend on how it was batched), so it is a function of the layer
     # only; measured faster than the direct form down to the 8x10 level (tools/conv_bench.py: res5 0.50 -> 0.30 ms,
     # p5 RPN conv 0.18 -> 0.10 ms, res2 64->64 0.40 -> 0.38 ms per 32 frames).  `wino=False` forces the direct form.
-    use_wino = wino_ok and (precision == 0 or (precision in (2, 3) and tune in (0, 8) and (Cin + Cin2) % 32 == 0))
+    use_wino = wino_ok and (precision == 0 or (precision in (2, 3) and tune in (0, 8, 23, 24, 25) and (Cin + Cin2) % 32 == 0))
     if use_wino and precision == 3 and (-(-p.cols // 64) % 2 or (Cin + Cin2 < 256 and wino is None)):
         # fp16x2: the direct form where the wide Winograd kernels' 128-channel tiles do not fit (res2's 64 -> 64) and for layers under
         # 256 input channels -- with three MFMAs per k step the 16-plane round trip costs more than the 2.25x multiply-adds it saves
@@ -705,6 +705,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         d.tune = 9
     ws = None
     if use_wino:
+        if WINO_TUNE and d.tune == 0 and d.precision == 3:
+            d.tune = WINO_TUNE
         d.w_wino = p.w_wino.data_ptr()
         if p.w_wino_cm is not None and d.precision == 0 and tune == 0:
             d.w_wino_cm = p.w_wino_cm.data_ptr()  # the library then takes the one-launch kernel where the layer qualifies
@@ -753,7 +755,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     if use_wino or splitk > 1:
         if use_wino and _WINO_SHARE is not None and x2 is None:
             shared = _WINO_SHARE.get(x.data_ptr())
-            if shared is not None and (shared[0].shape != x.shape or d.tune != 0):
+            if shared is not None and (shared[0].shape != x.shape or d.tune not in (0, 23, 24)):  # (23 | 24: other loops of the same GEMM on the same V)
                 shared = None
             # (the tiles' FORMAT belongs to the arithmetic: fp16x2 consumers read V pre-split into fp16 planes, the others fp32)
             if shared is not None and shared[1] is not None and len(shared) > 2 and shared[2] != int(d.precision):
@@ -846,6 +848,7 @@ def _conv2d_timed(d, p, out, shared, have_v, use_wino, fused_wino, B, H, W, Ho, 
 
 
 WINO_MAX_HW = int(os.environ.get("A3D_WINO_MAX_HW", "0"))
+WINO_TUNE = int(os.environ.get("A3D_WINO_TUNE", "0"))  # measurement knob: 23 | 24 = every fp16x2 Winograd GEMM in its lockstep | 64-tile form (the same bits)
 UPS_FUSED = os.environ.get("A3D_UPS_FUSED", "1") != "0"  # (False: always the four-launch form; same bits)
 
 
@@ -1278,6 +1281,7 @@ def group_nms(g_boxes: torch.Tensor, g_valid: torch.Tensor, g_n: torch.Tensor, t
     return keep
 
 
+ROI_SERIAL = False  # a3d_roialign_desc.serial (schedule only: one cell load at a time, the form the batched loads replaced)
 ROI_SPATIAL_ORDER = True  # walk every image's boxes in (level, y, x) order (schedule only: same output rows, same bits)
 
 
@@ -1318,6 +1322,7 @@ def roi_align_fpn(feats: Sequence[torch.Tensor], scales: Sequence[float], boxes:
     # (measured, tools/roi_bench.py: -7 % on the 1000-proposal box pooler; the 100-detection poolers lose 3-5 % to the sort launch)
     order = torch.empty((B * R,), device=dev, dtype=torch.int32) if (512 <= R <= 1024 and ROI_SPATIAL_ORDER) else None
     d.order_ws = _p(order)
+    d.serial = int(ROI_SERIAL)  # (schedule only: the bit-equality test and tools/roi_bench.py set it)
     ra = None
     if DEFAULT_PRECISION == 3:  # fp16x2: every pooled row records ITS OWN maximum (the scale of the layers that consume it) ...
         ra = amax_slot(nrows, dev)

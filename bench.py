@@ -82,7 +82,8 @@ def rocprof_name(variant: str) -> str:
         return {"64": "conv_xs_kernel<4, 4, 1>", "128": "conv_xs_kernel<8, 2, 2>", "256": "conv_xs_kernel<16, 2, 2>"}[m.group(1)]
     m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>$", v)
     if m:
-        return f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if m.group(1) == 'h2' else 'false'}, false>"  # (<WM, F16, plane-split>)
+        h2 = m.group(1) == "h2"  # (<WM, F16, plane-split, ping-pong loop>: round 5's fp16x2 launches are all <4, true, false, 1>)
+        return f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if h2 else 'false'}, false, {1 if h2 and m.group(2) == '4' else 0}>"
     return v
 
 

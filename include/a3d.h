@@ -98,7 +98,12 @@ typedef struct a3d_conv_desc {
                          eligible 1x1 layer (Cin 64 / 128 / 256, Cout % 128 == 0; the same bits); 15 / 16 = the tap-outer / the patch-resident
                          form of a 3x3 s1 p1 layer (phase 5: every launch is patch-resident by default, 15 is the bit-equality link to
                          the four-launch form; phase 0: 16 forces the patch-resident kernel on a layer whose map its tiles fit badly;
-                         the two forms reduce in different orders: equal to fp32 rounding, not bit for bit); >= 100: explicit tile variant */
+                         the two forms reduce in different orders: equal to fp32 rounding, not bit for bit); Winograd layers: 23 = the
+                         lockstep loop of the 128-tile fp16x2 GEMM instead of its ping-pong loop, 24 = 64-tile blocks (two workgroups per
+                         CU), 25 (precision 2) = 128-tile blocks whatever the problem size -- all the same bits (A/B runs, equality tests);
+                         >= 100: explicit tile variant.
+                         `tune` is the ONLY way to choose a variant: the library reads no environment variable and has no process-global
+                         switch (developer builds with -DA3D_ABLATIONS excepted, see csrc/a3d_common.h). */
     int phase;        /* 0, or 1..4 = output phase (dy,dx) = ((phase-1)>>1, (phase-1)&1) of a 3x3 pad-1 convolution over a
                          nearest-x2 upsampled input, evaluated on the SOURCE grid as a 2x2 convolution with pre-summed
                          taps (KH = KW = 2, stride 1, pad ignored; taps read source rows oh-1+dy .. oh+dy): the four
@@ -209,7 +214,9 @@ int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream);
 int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
 /* The kernel instantiation the LAST conv launch of the calling thread dispatched, as it appears in a rocprofv3 kernel trace
  * ("conv_pw_kernel<2,2,16> 128x128 persistent", "wino_gemm_kernel<1,32>", ...); "" before the first launch.  For measurement
- * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules. */
+ * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules.
+ * This label is the library's one piece of state beside the per-device "dynamic LDS opted in" bits: a thread_local buffer, written and
+ * read by the calling thread only (re-entrancy is not affected; it carries no configuration). */
 const char *a3d_last_conv_variant(void);
 
 /* Max-pool 3x3 stride 2 pad 1 (ResNet stem) and kernel-1 stride-2 pool (FPN LastLevelMaxPool = p6). */
@@ -321,6 +328,8 @@ typedef struct a3d_roialign_desc {
                           power of two that puts out_amax[row] in [2^14, 2^15) -- a3d_conv_desc.x_h2 of the box head's fc1
                           (roi_heads.py:185-187).  The workgroup keeps the row in LDS until its maximum is known.  Same pooled
                           values as `out` (the split is exact to 2^-22 of the row's maximum). */
+    int serial;        /* schedule only: 1 = a bin's cell loads one at a time (the form the batched loads replaced; kept for the
+                          bit-equality test and tools/roi_bench.py).  0 = the default. */
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);

@@ -133,6 +133,32 @@ def test_wide_split_operand_winograd_gemm_is_bit_identical_to_the_64_wide_form(o
     assert rel(y_wide[-2:, :, :, :Cout].permute(0, 3, 1, 2).double(), ref) < 2e-6  # (the last images: the ragged tile block is there)
 
 
+@pytest.mark.parametrize("shape", [(64, 30, 40, 256, 256), (3, 61, 79, 256, 384), (70, 14, 14, 256, 256), (5, 120, 160, 256, 128), (20, 15, 20, 512, 512)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_ping_pong_winograd_gemm_keeps_the_bits_of_the_lockstep_and_64_tile_forms(ops, shape):
+    """Round 5: the fp16x2 Winograd GEMM (the 3x3 layers of the FPN, RPN, depth laterals and ROI heads: planercnn.py:150,168) runs its
+    512-thread workgroup as two halves in antiphase -- waves 4-7 half a chunk behind waves 0-3, each wave alternating a memory phase
+    (a chunk's 12 fragment reads + its 4 DMA pieces) with a compute phase (its 12 MFMAs) -- on every problem size.  Planes, chunks,
+    steps and product terms per accumulator are those of the lockstep loop (tune 23) and of the 64-tile form (tune 24): equal bits, so
+    which form runs is free (ragged tile / channel blocks and a 16-chunk plane included)."""
+    if ops.DEFAULT_PRECISION != 3:
+        pytest.skip("the fp16x2 arithmetic's kernel")
+    B, H, W, Cin, Cout = shape
+    torch.manual_seed(11)
+    x = torch.randn(B, H, W, Cin, device="cuda") * torch.logspace(-2, 2, B, device="cuda").view(B, 1, 1, 1)  # (per-image scales differ)
+    w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5)
+    pk = ops.pack_conv(w, torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_RELU)
+    y = ops.conv2d(x, pk, precision=3)
+    assert ops.last_conv_variant() == "wino_gemm_h2w_kernel<4>", ops.last_conv_variant()
+    lock = ops.conv2d(x, pk, precision=3, tune=23)
+    assert ops.last_conv_variant() == "wino_gemm_h2w_kernel<4>", ops.last_conv_variant()
+    narrow = ops.conv2d(x, pk, precision=3, tune=24)
+    assert ops.last_conv_variant() == "wino_gemm_h2w_kernel<2>", ops.last_conv_variant()
+    assert torch.equal(y, lock) and torch.equal(y, narrow)
+    ref = F.relu(F.conv2d(x[-2:].permute(0, 3, 1, 2).double().cpu(), w.double(), pk.shift[:Cout].double().cpu(), padding=1))
+    assert rel(y[-2:, :, :, :Cout].permute(0, 3, 1, 2).double(), ref) < 2e-6
+
+
 @pytest.mark.parametrize("case", [dict(B=33000, H=1, W=1, Cin=4096, Cout=1024, k=1, s=1, res=False),  # default dispatch: deep reduction
                                   dict(B=3, H=30, W=40, Cin=256, Cout=1000, k=1, s=1, res=True),     # ragged channel tile, residual
                                   dict(B=2, H=33, W=41, Cin=64, Cout=256, k=3, s=2, res=False),      # taps, stride, ragged pixel tile

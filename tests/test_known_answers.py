@@ -158,12 +158,12 @@ def test_torch_ops_give_the_same_bits_as_the_ctypes_wrappers():
     live = torch.cat([torch.arange(600), 600 + torch.arange(333)])
     ref = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
     ops.ROI_SPATIAL_ORDER = False
-    os.environ["A3D_ROI_SERIAL"] = "1"
+    ops.ROI_SERIAL = True
     try:
         plain = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
     finally:
         ops.ROI_SPATIAL_ORDER = True
-        os.environ["A3D_ROI_SERIAL"] = "0"
+        ops.ROI_SERIAL = False
     assert torch.equal(ref[live], plain[live])
     gb = torch.zeros(2, ops.GROUP_CAP, 4).cuda()
     gb[:, :50] = boxes

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): the three ROI poolers on the detector's own proposals / detections of a synthetic clip: time per launch,
-algorithmic bytes, achieved GB/s, and bit equality of the batched-load form with the serialized one (A3D_ROI_SERIAL=1).
+algorithmic bytes, achieved GB/s, and bit equality of the batched-load form with the serialized one (ops.ROI_SERIAL = True).
     python tools/roi_bench.py [--frames 64]"""
 import argparse
 import os
@@ -48,10 +48,10 @@ def main():
     for name, boxes, count, P, ratio, aligned in cases:
         n = int(count.sum())
         f = lambda: ops.roi_align_fpn(lv, scales, boxes, count, P, ratio, aligned)
-        os.environ["A3D_ROI_SERIAL"] = "1"
+        ops.ROI_SERIAL = True
         y_s = f()
         t_s = timeit(f)
-        os.environ["A3D_ROI_SERIAL"] = "0"
+        ops.ROI_SERIAL = False
         ops.ROI_SPATIAL_ORDER = False
         y_u = f()
         t_u = timeit(f)
