@@ -568,6 +568,10 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
         const int rx = a3d_conv_launch_xs_h2(d, s);
         if (rx != A3D_ERR_UNSUPPORTED) return rx;
     }
+    if (d->precision == 3 && !d->x_h2 && (d->tune == 0 || (d->tune >= 26 && d->tune <= 28))) {  // deep 1x1 reductions: ping-pong, both operands by DMA (bit-identical)
+        const int rd = a3d_conv_launch_dk_h2(d, s);
+        if (rd != A3D_ERR_UNSUPPORTED) return rd;
+    }
     if (d->precision == 3 && !d->x_h2) {  // plain 3x3 s1 p1 layers: the patch-resident kernel (another reduction order; chosen by layer and map size)
         const int rc3 = a3d_conv_launch_c3p(d, s);
         if (rc3 != A3D_ERR_UNSUPPORTED) return rc3;

@@ -674,7 +674,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     const int KC = a.C / BKT;
     const int NIT = 16 * KC;
     const int pf = PS ? (int)blockIdx.y : 0;   // plane of a plane-split workgroup
+#ifdef A3D_ABLATIONS
+    if (a.abl & 128) return;                    // timing-only: the launch alone
+    const int nit = (a.abl & 256) ? 4 : (PS ? KC : NIT);  // timing-only: prologue + four chunks
+#else
     const int nit = PS ? KC : NIT;             // chunks this workgroup multiplies
+#endif
 
     int xoff[XR];
     float sxr[XR];  // fp16x2: scale of each loader row (tile) = that of its image
@@ -995,6 +1000,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             auto plane_end = [&]() {
                 if (++ckc == KC) {
                     ckc = 0;
+#ifdef A3D_ABLATIONS
+                    if (!(a.abl & 16))
+#endif
                     fold(mf, cf++);
                 }
             };
@@ -1023,7 +1031,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 }
 #endif
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef A3D_ABLATIONS
+                if (grpB && !(a.abl & 4)) {
+#else
                 if (grpB) {
+#endif
                     __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPSP) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
@@ -1031,7 +1043,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 if (!(a.abl & 32))
 #endif
                 compute();
+#ifdef A3D_ABLATIONS
+                if (!grpB && !(a.abl & 4)) {
+#else
                 if (!grpB) {
+#endif
                     __asm__ volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * OPSP) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
@@ -1203,6 +1219,19 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         }
         return;
     }
+#ifdef A3D_ABLATIONS
+    if (a.abl & 64) {  // timing-only: no epilogue (one store per wave keeps the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += yy[ij][ni][r];
+        if (sacc == 12345.678f) a.y[tid] = sacc;
+        return;
+    }
+#endif
     const int tyx = a.Ty * a.Tx;
     // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
     const float unx = (F16 && tb + pr < a.T) ? 1.f / wino_v_scale(a, (tb + pr) / tyx) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;

@@ -88,6 +88,9 @@ class _LocalHandle(GatherHandle):
 
 
 _verified_blocks = set()
+# measurement record of the exchanges (bench.py resets and reads it): collectives finished, bytes one rank RECEIVED over both phases,
+# host seconds spent inside GatherHandle.wait_compact
+STATS = {"calls": 0, "bytes": 0, "host_s": 0.0}
 
 
 def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: Optional[int] = None) -> GatherHandle:
@@ -149,6 +152,16 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
     keep_alive = [hdr, all_hdr, rec, cnt]  # referenced until the exchange has been collected
 
     def finish():
+        import time as _time
+
+        _t0 = _time.perf_counter()
+        try:
+            return _finish()
+        finally:
+            STATS["calls"] += 1
+            STATS["host_s"] += _time.perf_counter() - _t0
+
+    def _finish():
         keep_alive.clear()
         if ev is not None:
             ev.synchronize()
@@ -162,6 +175,7 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
         live = [int(v) for v in counts.clamp(max=R).sum(1).tolist()]
         mx = max(live)
         all_cnt = counts.reshape(-1).to(dev, non_blocking=True)  # (pinned source on the device path: no host wait)
+        STATS["bytes"] += G * (rows + 1) * 4 + G * mx * F * rec.element_size()
         if mx == 0:
             out = (rec.new_zeros((0, F)), all_cnt)
         else:

@@ -66,7 +66,7 @@ def _get_pcd(verts, normal, offset, h=480, w=640):
 
 def get_boundary_point(y, x, angle, H, W):
     """planercnn_transforms.py:131-176."""
-    if angle == np.float32(-np.pi / 2):
+    if float(angle) == -np.pi / 2:  # (the reference compares with the float64 constant: only ITS OWN sentinel for sin == 0 matches, never a float32 arctan)
         return (x, 0), (x, H - 1)
     if angle == 0.0:
         return (0, y), (W - 1, y)
@@ -94,7 +94,7 @@ def angle_offset_to_axis(angle_offsets: torch.Tensor, centers: torch.Tensor, H=4
     rtn = []
     for ao, c in zip(angle_offsets.detach().cpu().numpy().astype(np.float32), centers.detach().cpu().numpy().astype(np.float32)):
         sin, cos, p = ao[0], ao[1], np.float32(ao[2] * np.float32(100))
-        angle = np.float32(-np.pi / 2) if sin == 0 else np.float32(-np.arctan(cos / sin))
+        angle = -np.pi / 2 if sin == 0 else np.float32(-np.arctan(cos / sin))
         x, y = np.float32(p * cos + c[0]), np.float32(p * sin + c[1])
         p1, p2 = get_boundary_point(y, x, angle, H, W)
         rtn.append([0, 0, 1, 1] if p1 is None else [p1[0], p1[1], p2[0], p2[1]])

@@ -88,3 +88,70 @@ def depth_features():
     g = _gen(303)
     shapes = {"p2": (120, 160), "p3": (60, 80), "p4": (30, 40), "p5": (15, 20), "p6": (8, 10)}
     return {k: torch.randn(1, 256, h, w, generator=g) for k, (h, w) in shapes.items()}
+
+
+def axis_cases():
+    """Inputs of the axis <-> (angle, offset) fixtures (SURVEY 8c fixture 4): pixel axes [n,4] (x1,y1,x2,y2) + box centres [n,2] for
+    axis_to_angle_offset; (sin, cos, offset/100) triples + centres for angle_offset_to_axis; (y, x, angle) triples for
+    get_boundary_point (planercnn_transforms.py:31-68,101-176).  Random in-image axes plus the edge cases the functions branch on:
+    horizontal, vertical, through the centre (C = 0), endpoints outside the image, lines that miss the image, lines through corners."""
+    import numpy as np
+
+    rng = np.random.default_rng(2020)
+    n = 24
+    axes = np.stack([rng.uniform(0, 640, n), rng.uniform(0, 480, n), rng.uniform(0, 640, n), rng.uniform(0, 480, n)], 1)
+    centers = np.stack([rng.uniform(40, 600, n), rng.uniform(40, 440, n)], 1)
+    special = np.array([
+        [100, 200, 500, 200],   # horizontal
+        [320, 30, 320, 450],    # vertical
+        [-50, -20, 700, 520],   # endpoints outside the image
+        [100, 100, 300, 300],   # through its centre (C = 0: sign(C) = 0)
+        [10, 470, 630, 5],
+        [200, 240, 201, 240.5],  # short
+        [0, 0, 639, 479],       # corner to corner
+        [639, 0, 0, 479],
+    ], dtype=np.float64)
+    sc = np.array([[320, 240], [300, 240], [320, 240], [200, 200], [100, 100], [500, 400], [320, 240], [10, 10]], dtype=np.float64)
+    axes = np.concatenate([axes, special]).astype(np.float32)
+    centers = np.concatenate([centers, sc]).astype(np.float32)
+    m = 24
+    th = rng.uniform(-np.pi, np.pi, m)
+    ao = np.stack([np.sin(th), np.cos(th), rng.uniform(0, 3.0, m)], 1)
+    ao_special = np.array([
+        [0.0, 1.0, 0.5],     # sin == 0: vertical line right of the centre
+        [0.0, -1.0, 0.5],    # ... left of it
+        [1.0, 0.0, 0.3],     # cos == 0: angle = -0.0 -> horizontal
+        [-1.0, 0.0, 0.3],
+        [0.6, 0.8, 9.0],     # misses the image -> the reference's except branch ([0,0,1,1])
+        [0.6, -0.8, 0.0],    # through the centre
+        [0.70710678, 0.70710678, 0.0],
+        [0.0, 1.0, 5.0],     # vertical line outside the image
+    ])
+    ao_c = np.concatenate([np.stack([rng.uniform(40, 600, m), rng.uniform(40, 440, m)], 1),
+                           np.array([[320, 240], [320, 240], [320, 240], [320, 240], [320, 240], [100, 400], [0, 0], [320, 240]], dtype=np.float64)])
+    ao = np.concatenate([ao, ao_special]).astype(np.float32)
+    ao_c = ao_c.astype(np.float32)
+    bp = [(240.0, 320.0, -np.pi / 2), (240.0, 320.0, 0.0), (0.0, 0.0, np.pi / 4), (479.0, 0.0, -np.pi / 4), (100.5, 200.25, 0.3),
+          (100.5, 200.25, -1.2), (-30.0, 700.0, 0.7), (240.0, 320.0, 1e-3), (240.0, 320.0, 1.5), (479.0, 639.0, 0.6435011087932844),
+          (1000.0, 1000.0, 0.1), (0.0, 639.0, np.arctan(479.0 / 639.0) - np.pi)]
+    bp += [(float(rng.uniform(0, 480)), float(rng.uniform(0, 640)), float(rng.uniform(-1.55, 1.55))) for _ in range(20)]
+    return axes, centers, ao, ao_c, bp
+
+
+def pcd_cases():
+    """Inputs of the get_pcd / project2D fixture (vis.py:62-102): mask pixels (x, y) incl. the image corners and the principal point, and
+    (unit normal, offset) planes: fronto-parallel, slanted, steep."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    verts = np.concatenate([np.array([[0, 0], [639, 0], [0, 479], [639, 479], [320, 240], [319, 239]]),
+                            np.stack([rng.integers(0, 640, 250), rng.integers(0, 480, 250)], 1)]).astype(np.int64)
+    normals = np.array([[0, 0, 1], [0.3, -0.2, 0.93], [-0.6, 0.1, 0.79], [0.05, 0.9, 0.43], [0.7, 0.7, 0.14]], dtype=np.float64)
+    normals = (normals / np.linalg.norm(normals, axis=1, keepdims=True)).astype(np.float32)
+    offsets = np.array([2.0, 1.3, 3.7, 0.8, 2.2], dtype=np.float32)
+    return verts, [(normals[i], offsets[i]) for i in range(len(offsets))]
+
+
+import numpy as _np
+
+PCD_SHIFT = _np.array([0.013, -0.007, 0.02], dtype=_np.float32)  # fp32 translation applied to the lifted cloud in the pcd_project fixture

@@ -13,6 +13,11 @@ What can be imported from the reference:
         exactly the documented detectron2 wrapper; the two fvcore initialisers).  The arithmetic exercised --
         the layer lists, forward order, flatten order, F.normalize, cat, BatchNorm eps, upsampling and the two
         bilinear resizes -- is all the reference's own code.
+  * data/planercnn_transforms.py (axis_to_angle_offset, angle_offset_to_axis, get_boundary_point) and utils/vis.py (get_pcd,
+        project2D) -- pure numpy / torch functions in modules whose OTHER code imports detectron2, cv2, pytorch3d, mapbox_earcut,
+        imageio, pycocotools and two sibling modules at module scope.  Those imports are satisfied by NAME-ONLY placeholders
+        (_install_placeholder_names: empty modules whose attributes are inert objects; no arithmetic is substituted -- the five
+        functions never touch them).  They are the helpers of the temporal optimiser (SURVEY 8c fixture 4, 8f-3).
 Everything else on the path (backbone, RPN, ROIAlign, NMS, box / mask heads) has no source under
 /root/reference: parity unpinned (oracle/planercnn_oracle.py header).
 
@@ -107,6 +112,40 @@ def _install_d2_names():
     mods["fvcore.nn"].smooth_l1_loss = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError)
     sys.modules.update(mods)
     return ShapeSpec
+
+
+class _Inert:
+    """A name that resolves and does nothing: any attribute is another inert name, calling it raises."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Inert()
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError("placeholder for a third-party name the golden functions never use")
+
+
+def _install_placeholder_names():
+    """Module-scope imports of data/planercnn_transforms.py and utils/vis.py that the five pinned functions never use."""
+
+    class _Mod(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Inert()
+
+    for name in ("detectron2.data", "detectron2.data.detection_utils", "detectron2.data.transforms", "detectron2.structures",
+                 "detectron2.structures.masks", "cv2", "mapbox_earcut", "imageio", "pytorch3d", "pytorch3d.structures",
+                 "pytorch3d.renderer", "pytorch3d.renderer.mesh", "pycocotools", "pycocotools.mask",
+                 "refpkg", "refpkg.utils", "refpkg.utils.mesh_utils", "refpkg.utils.pycococreatortools"):
+        if name not in sys.modules:
+            m = _Mod(name)
+            m.__path__ = []  # (a package: `from x.y import z` resolves through sys.modules)
+            sys.modules[name] = m
+    if not hasattr(sys.modules["detectron2"], "data"):
+        sys.modules["detectron2"].data = sys.modules["detectron2.data"]
+        sys.modules["detectron2"].structures = sys.modules["detectron2.structures"]
 
 
 def _load(path, name):
@@ -212,6 +251,44 @@ def main():
                         depth_strided=d[:, ::16, ::16].numpy(), depth_strided_f64=d64[:, ::16, ::16].numpy(), depth_sum=float(d.double().sum()),
                         depth_abs_sum=float(d.double().abs().sum()), shape=np.array(d.shape))
     print("depth_head", tuple(d.shape), float(d.mean()))
+
+    # ---- (5) axis <-> (angle, offset) transforms and (6) point-cloud lift / projection: the temporal optimiser's helpers --------
+    _install_placeholder_names()
+    tr = _load(os.path.join(REF, "articulation3d", "data", "planercnn_transforms.py"), "ref_planercnn_transforms")
+    axes, centers, ao, ao_centers, bp = G.axis_cases()
+    fwd = tr.axis_to_angle_offset([list(map(float, a)) for a in axes], torch.tensor(centers), mine=False).numpy()
+    fwd_mine = tr.axis_to_angle_offset([list(map(float, a)) for a in axes], torch.tensor(centers), mine=True).numpy()
+    with_none = tr.axis_to_angle_offset([None, list(map(float, axes[0]))], torch.tensor(centers[:2])).numpy()
+    back = tr.angle_offset_to_axis(torch.tensor(ao), torch.tensor(ao_centers)).numpy()
+    # round trip through the reference's own two functions (what the optimiser does with a predicted axis: opt_utils.py:396-400)
+    back_rt = tr.angle_offset_to_axis(torch.tensor(fwd[:, :3]), torch.tensor(centers)).numpy()
+    pts = []
+    for y, x, ang in bp:
+        p1, p2 = tr.get_boundary_point(y, x, ang, 480, 640)
+        pts.append([-1] * 4 if p1 is None else [p1[0], p1[1], p2[0], p2[1]])
+    np.savez_compressed(os.path.join(OUT, "axis_transforms.npz"), axes=axes, centers=centers, angle_offset=fwd, angle_offset_mine=fwd_mine,
+                        with_none=with_none, ao=ao, ao_centers=ao_centers, axis_back=back, axis_round_trip=back_rt,
+                        boundary_in=np.asarray(bp, dtype=np.float64), boundary_out=np.asarray(pts, dtype=np.float64))
+    print("axis_transforms", fwd.shape, back.shape, len(pts))
+
+    sys.modules["refpkg.utils"].__path__ = [os.path.join(REF, "articulation3d", "utils")]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refpkg.utils.vis", os.path.join(REF, "articulation3d", "utils", "vis.py"))
+    vis = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vis)
+    verts, planes = G.pcd_cases()
+    pcds, projs, projs32, projs_sh = [], [], [], []
+    shift = G.PCD_SHIFT  # a translation hypothesis: the lifted points leave the pixel edges the identity puts them on
+    for normal, offset in planes:
+        pcd = vis.get_pcd(verts, normal, offset)                      # float64 (numpy)
+        pcds.append(pcd)
+        projs.append(vis.project2D(pcd))                              # numpy branch on the float64 cloud
+        projs32.append(vis.project2D(pcd.astype(np.float32)))         # numpy branch on the fp32 cloud the optimiser keeps (K stays float64)
+        projs_sh.append(vis.project2D((pcd.astype(np.float32) + shift).astype(np.float32)))
+    np.savez_compressed(os.path.join(OUT, "pcd_project.npz"), verts=verts, normals=np.stack([p[0] for p in planes]),
+                        offsets=np.array([p[1] for p in planes]), pcd=np.stack(pcds), proj=np.stack(projs), proj_from_f32=np.stack(projs32),
+                        shift=shift, proj_shifted=np.stack(projs_sh))
+    print("pcd_project", np.stack(pcds).shape)
 
 
 if __name__ == "__main__":

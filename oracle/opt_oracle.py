@@ -9,7 +9,15 @@ Restates, in numpy, the numerical blocks of the reference's optimize_planes('3dc
 pytorch3d (Transform3d, Rotate, axis_angle_to_matrix) is a third-party dependency that is NOT vendored under
 /root/reference (README install recipe, unpinned) -- its published algorithm is restated: axis-angle -> quaternion ->
 matrix, and Rotate applies points @ R (row vectors), i.e. the TRANSPOSE of the column-vector rotation matrix.
-The reference holds no test or golden vector for any of this -> PARITY UNPINNED; this file is the parity definition.
+PINNED (round 5) for the helpers that are the reference's own pure functions: get_pcd, project2D, axis_to_angle_offset,
+angle_offset_to_axis and get_boundary_point are checked against the outputs of the reference's modules themselves
+(oracle/make_golden.py sections 5-6 import data/planercnn_transforms.py and utils/vis.py behind name-only placeholders for
+their unused imports -> tests/golden/axis_transforms.npz, pcd_project.npz; tests/test_oracle_golden.py).  The pin found one
+deviation: the vertical-line sentinel of get_boundary_point is the float64 constant -pi/2, which only angle_offset_to_axis's
+own `sin == 0` branch produces -- a float32 arctan never equals it (fixed here and in the product's host-side mirror).
+PARITY UNPINNED for the rest -- the clustering / regression control flow of optimize_planes (the reference holds no test or
+vector for it and its module imports pytorch3d at scope) and the pytorch3d rotation, restated from its published algorithm:
+for those this file is the parity definition.
 The projected pixel index is a float -> long truncation, so two fp32 implementations can disagree on the few points
 that land within rounding of a pixel boundary; masks are compared by differing-pixel count and IoU, not bit for bit.
 """
@@ -63,7 +71,7 @@ def axis_angle_to_matrix(axis_angle):
 def get_boundary_point(y, x, angle, H, W):
     """planercnn_transforms.py:131-176: the two points where the line through (x, y) with slope tan(angle) meets the image."""
     p1 = p2 = None
-    if angle == np.float32(-np.pi / 2):
+    if float(angle) == -np.pi / 2:  # (the reference compares with the float64 constant: only ITS OWN sentinel for sin == 0 matches, never a float32 arctan)
         return (x, 0), (x, H - 1)
     if angle == 0.0:
         return (0, y), (W - 1, y)
@@ -97,7 +105,7 @@ def angle_offset_to_axis(angle_offsets, centers, H=IMG_H, W=IMG_W):
     for ao, c in zip(np.asarray(angle_offsets, dtype=np.float32), np.asarray(centers, dtype=np.float32)):
         sin, cos, p = ao[0], ao[1], np.float32(ao[2] * np.float32(100))
         x0, y0 = c
-        angle = np.float32(-np.pi / 2) if sin == 0 else np.float32(-np.arctan(cos / sin))
+        angle = -np.pi / 2 if sin == 0 else np.float32(-np.arctan(cos / sin))
         x, y = np.float32(p * cos + x0), np.float32(p * sin + y0)
         p1, p2 = get_boundary_point(y, x, angle, H, W)
         out.append([0, 0, 1, 1] if p1 is None else [p1[0], p1[1], p2[0], p2[1]])

@@ -136,3 +136,44 @@ def test_optimize_planes_3dc_vs_oracle(OO, kind):
     random.seed(1)
     out2 = PU.optimize_planes(insts2, planes2, "3dc")
     assert planes2[kind][0]["has_rot"] is False and all(abs(o.scores[0] - 0.54) < 1e-9 for o in out2)
+
+
+def test_projection_kernel_on_the_reference_pinned_vectors(OO):
+    """Round 5 (SURVEY 8c fixture 4): opt_sweep.hip's lift + re-projection (a3d_project_hypotheses = get_pcd in float64, the cloud kept
+    in fp32, one translation hypothesis, project2D, truncation) on tests/golden/pcd_project.npz -- the outputs of the REFERENCE's
+    get_pcd / project2D (vis.py:62-102, numpy branch: its K stays float64) for the same pixels, planes and translation.  Every point
+    whose exact projection is not within fp32 rounding of a pixel edge must land on the reference's pixel; the few others may move to
+    the neighbouring pixel and nowhere else."""
+    import os
+
+    from articulation3d_amd import opt_ops
+    from oracle import golden_inputs as G
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcd_project.npz"))
+    verts, planes = G.pcd_cases()
+    assert np.array_equal(verts, g["verts"]) and np.array_equal(G.PCD_SHIFT, g["shift"])
+    mask = np.zeros((H, W), dtype=np.uint8)
+    mask[verts[:, 1], verts[:, 0]] = 1
+    ys, xs = np.nonzero(mask)  # (the kernel walks the mask's pixels: duplicates of the random draw collapse)
+    index = {(int(x), int(y)): i for i, (x, y) in enumerate(verts)}
+    rows = np.array([index[(int(x), int(y))] for x, y in zip(xs, ys)])
+    xf = np.concatenate([np.eye(3, dtype=np.float32).reshape(-1), G.PCD_SHIFT]).astype(np.float32)[None]
+    for i, (normal, offset) in enumerate(planes):
+        bits = opt_ops.project_hypotheses(torch.from_numpy(mask).cuda(), normal, float(offset), (0.0, 0.0, 0.0), torch.from_numpy(xf).cuda(),
+                                          focal=OO.FOCAL, cx=W / 2, cy=H / 2)
+        got = opt_ops.unpack_masks(bits, H, W)[0].cpu().numpy().astype(bool)
+        ref = g["proj_shifted"][i][rows]
+        col = np.clip(ref[:, 0].astype(np.int64), 0, W - 1)
+        row = np.clip(ref[:, 1].astype(np.int64), 0, H - 1)
+        tol = 640 * 2.0 ** -21
+        sure = (np.abs(ref - np.round(ref)) > tol).all(1)
+        want_sure = np.zeros((H, W), dtype=bool)
+        want_sure[row[sure], col[sure]] = True
+        assert (got & want_sure).sum() == want_sure.sum(), (i, int((want_sure & ~got).sum()))
+        allowed = np.zeros((H, W), dtype=bool)  # every point's pixel, plus the neighbours of the points that sit on an edge
+        allowed[row, col] = True
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                allowed[np.clip(row[~sure] + dy, 0, H - 1), np.clip(col[~sure] + dx, 0, W - 1)] = True
+        assert not (got & ~allowed).any(), (i, int((got & ~allowed).sum()))
+        assert sure.mean() > 0.95

@@ -196,3 +196,67 @@ def test_committed_frames_do_not_depend_on_the_nms_formulation(oracle, oracle_pa
     for k, v in r.items():
         if isinstance(v, dict):
             assert v["proposals_identical"] and v["detections_identical"], (k, v)
+
+
+# ---- round 5: the temporal optimiser's helpers, pinned against the reference's own functions (SURVEY 8c fixture 4) ----------------
+def test_axis_transforms_match_the_reference(golden_dir):
+    """oracle/opt_oracle.py's restatements of axis_to_angle_offset / angle_offset_to_axis / get_boundary_point against the outputs of
+    the reference's functions (planercnn_transforms.py:31-68,101-176; oracle/make_golden.py section 5): both directions, the boundary
+    cases of get_boundary_point (vertical, horizontal = angle -0.0, corners, lines that miss the image -> [0,0,1,1]), and the round
+    trip the optimiser performs on a predicted axis."""
+    from oracle import opt_oracle as O
+
+    g = _load(golden_dir, "axis_transforms.npz")
+    axes, centers, ao, ao_c, bp = G.axis_cases()
+    assert np.array_equal(axes, g["axes"]) and np.array_equal(ao, g["ao"]), "seeded inputs drifted"
+    fwd = O.axis_to_angle_offset(axes, centers)
+    ref = g["angle_offset"]
+    ok = np.isfinite(ref).all(1)  # (an axis through its box centre has C = 0: sign(C) = 0 -> sin = cos = 0 in both; none is NaN)
+    assert ok.all()
+    np.testing.assert_allclose(fwd, ref, rtol=2e-6, atol=2e-7)
+    back = O.angle_offset_to_axis(ao, ao_c)
+    assert np.array_equal(back, g["axis_back"]), np.nonzero((back != g["axis_back"]).any(1))
+    rt = O.angle_offset_to_axis(ref[:, :3], centers)
+    assert np.array_equal(rt, g["axis_round_trip"])
+    for (y, x, ang), want in zip(g["boundary_in"], g["boundary_out"]):
+        p1, p2 = O.get_boundary_point(np.float64(y), np.float64(x), np.float64(ang), 480, 640)
+        got = [-1] * 4 if p1 is None else [p1[0], p1[1], p2[0], p2[1]]
+        assert [float(v) for v in got] == [float(v) for v in want], ((y, x, ang), got, want)
+
+
+def test_point_cloud_lift_and_projection_match_the_reference(golden_dir):
+    """get_pcd in float64 and project2D (vis.py:62-102) against the reference's own outputs: the lift to 1e-12 (the oracle writes K^-1 q
+    out instead of calling np.linalg.inv: the same numbers to float64 rounding), the fp32 projection the oracle fixes the evaluation
+    order of to fp32 rounding of the reference's float64 product, and the truncated pixel index equal wherever the exact value is not
+    within that rounding of a pixel edge."""
+    from oracle import opt_oracle as O
+
+    g = _load(golden_dir, "pcd_project.npz")
+    verts, planes = G.pcd_cases()
+    assert np.array_equal(verts, g["verts"])
+    for i, (normal, offset) in enumerate(planes):
+        pcd = O.get_pcd(verts, normal, offset)
+        np.testing.assert_allclose(pcd, g["pcd"][i], rtol=1e-12, atol=1e-12)
+        uv = O.project2d(pcd.astype(np.float32))
+        ref = g["proj_from_f32"][i]
+        np.testing.assert_allclose(uv, ref, rtol=0, atol=640 * 2.0 ** -22)
+        # the lift followed by the projection is the identity on pixel coordinates (every point lands ON a pixel edge: the truncation
+        # is decided by the last bit, which is why the oracle fixes the fp32 evaluation order): to fp32 rounding here
+        np.testing.assert_allclose(g["proj"][i], verts.astype(np.float64), rtol=0, atol=1e-9)
+        far = np.abs(ref - np.round(ref)) > 1e-3
+        assert np.array_equal(uv.astype(np.int64)[far], ref.astype(np.int64)[far])
+
+
+def test_host_side_axis_helpers_match_the_reference(golden_dir):
+    """The product's own host-side mirror of the two transforms (articulation3d_amd/utils/opt_utils.py: the optimiser stays on the host,
+    north star) against the same reference outputs -- the mirror the reference's callers would switch to."""
+    import torch as _t
+
+    from articulation3d_amd.utils import opt_utils as PU
+
+    g = _load(golden_dir, "axis_transforms.npz")
+    axes, centers, ao, ao_c, _ = G.axis_cases()
+    fwd = PU.axis_to_angle_offset([list(map(float, a)) for a in axes], _t.from_numpy(centers)).numpy()
+    np.testing.assert_allclose(fwd, g["angle_offset"], rtol=2e-6, atol=2e-7)
+    assert np.array_equal(PU.angle_offset_to_axis(_t.from_numpy(ao), _t.from_numpy(ao_c)).numpy(), g["axis_back"])
+    assert np.array_equal(PU.angle_offset_to_axis(_t.from_numpy(g["angle_offset"][:, :3]), _t.from_numpy(centers)).numpy(), g["axis_round_trip"])

@@ -37,6 +37,99 @@ def synthetic_targets(n, seed, h=480, w=640):
     return out
 
 
+def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_baseline=False, layers=False, rank=0, world=1, dist=None, model=None):
+    """W untimed + K timed training steps on `batch` synthetic frames per GPU, then ONE fully instrumented step for the roofline object.
+    Returns the result dict of the JSON line (bench.py embeds it as `train_step`; this file's main() prints it)."""
+    from bench import build_detector
+    from articulation3d_amd.training import DetectorTrainer
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
+    if model is None:
+        model, _cfg = build_detector(0.5, dev)
+    tr = DetectorTrainer(model, seed=2020 + rank, precision=precision, storage=storage)
+    B = batch
+    frames = torch.from_numpy(synthetic_frames(B, seed=2020 + rank)).to(dev)
+    tg = synthetic_targets(B, 2020 + rank)
+    gtb, gtc = [t[0] for t in tg], [t[1] for t in tg]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tr.step(frames, gtb, gtc)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses, _ = tr.step(frames, gtb, gtc)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # ---- roofline of the step (VERDICT r3 item 4): ONE fully instrumented step after the timed loop -- HIP events, on the launch stream,
+    # around every conv / linear launch (forward and data gradients: ops.conv2d) and every weight-gradient launch (train_ops.conv_wgrad).
+    # Executed FLOPs: Winograd layers 16 / 36 of the direct count; the fp32-grade step issues SIX bf16 MFMA products per multiply-add.
+    from articulation3d_amd import ops
+    from bench import PIPE_FLOPS_PER_FMA, PIPE_PEAK, dominant_roofline, kernel_sums
+
+    ops.CONV_TIMING = []
+    tr.step(frames, gtb, gtc)
+    barrier()
+    events, ops.CONV_TIMING = ops.CONV_TIMING, None
+    if layers and rank == 0:
+        for name, fl, a, b, shape, ex, pipe, _st in events:
+            ms = a.elapsed_time(b)
+            print(f"{name[:40]:40s} {shape:52s} {ex / 1e9:9.2f} GF {ms:8.3f} ms {ex / ms / 1e9 if ms > 0 else 0:8.1f} TF/s", file=sys.stderr)
+    per = kernel_sums(events)
+    step_sec = elapsed / steps
+    roofline = dominant_roofline(per, step_sec)
+    issued = sum(v[3] * PIPE_FLOPS_PER_FMA[v[4]] for v in per.values())
+    pipes = {v[4] for v in per.values() if v[3]}
+    step_peak = max(PIPE_PEAK[q] for q in pipes)
+    roofline["source"] = "one fully instrumented step after the timed loop (every conv / linear / weight-gradient launch bracketed by HIP events)"
+    roofline["gemm_kernels_ms_per_step"] = round(1e3 * sum(v[1] for v in per.values()), 3)
+    roofline["whole_step"] = {"executed_tflop_per_step": round(issued / 1e12, 3), "achieved": round(issued / step_sec / 1e12, 2), "peak": step_peak,
+                              "unit": "TFLOP/s", "frac": round(issued / step_sec / 1e12 / step_peak, 4),
+                              "fp32_equivalent_tflop_per_step": round(sum(v[3] for v in per.values()) / 1e12, 3),
+                              "note": "all matrix-pipe FLOPs the step executes (forward + data gradients + weight gradients of the trainable layers, frozen "
+                                      "stem / res2 forward included) over the WALL time of a step, against the dense peak of the pipe the step runs on"}
+    roofline["all_gemm_kernels"] = {k: {"pipe": v[4], "ms_per_step": round(1e3 * v[1], 3), "launches_per_step": v[2],
+                                        "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None}
+                                    for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}
+    result = {
+        "metric": "images/sec through the step1_bbox training step at 480x640", "value": round(B * world * steps / elapsed, 2),
+        "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 (fp32 accumulate, fp32 master weights)",
+                                                                         "bf16x3": "f32 via exact 3-way bf16 operand split (forward / data gradients of the non-Winograd layers)"}[precision], "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: Faster R-CNN training step of step1_bbox.yaml (ResNet50-FPN, FREEZE_AT 2, RPN + box head "
+                               "losses, SGD momentum), random-init weights with calibrated BN, synthetic frames and boxes (arithmetic: see `dtype`)",
+                   "precision": precision, "storage": tr.storage,
+                   "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
+                   "gradient_exchange": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "none (1 GPU)"},
+        "losses_last_step": {k: round(float(v), 5) for k, v in losses.items()},
+        "roofline": roofline,
+    }
+    if cpu_baseline and rank == 0:
+        from oracle import planercnn_oracle as O, train_oracle as TO
+
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(avail, 64))
+        torch.set_num_threads(cores)
+        P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        imgs = O.frames_to_chw(synthetic_frames(B, seed=2020))
+        t0 = time.perf_counter()
+        TO.loss_and_grads(imgs, tg, P, O.OracleCfg(), TO.TrainCfg(), gen=torch.Generator().manual_seed(1))
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(B / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+                                  "sample": f"one forward+backward of the autograd oracle on {B} images (no optimiser step)",
+                                  "caveat": "a stated baseline, never the target (oracle/train_oracle.py: torch.autograd over the CPU oracle)"}
+        result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,93 +160,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend=args.dist_backend)
-
-    from bench import build_detector
-    from articulation3d_amd.training import DetectorTrainer
-    from articulation3d_amd.utils.synthetic import synthetic_frames
-
-    model, _cfg = build_detector(0.5, dev)
-    tr = DetectorTrainer(model, seed=2020 + rank, precision=args.precision, storage=args.storage)
-    B = args.batch
-    frames = torch.from_numpy(synthetic_frames(B, seed=2020 + rank)).to(dev)
-    tg = synthetic_targets(B, 2020 + rank)
-    gtb, gtc = [t[0] for t in tg], [t[1] for t in tg]
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        tr.step(frames, gtb, gtc)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses, _ = tr.step(frames, gtb, gtc)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # ---- roofline of the step: ONE fully instrumented step after the timed loop -- HIP events, on the launch stream,
-    # around every conv / linear launch (forward and data gradients: ops.conv2d) and every weight-gradient launch (train_ops.conv_wgrad).
-    # Executed FLOPs: Winograd layers 16 / 36 of the direct count; the fp32-grade step issues SIX bf16 MFMA products per multiply-add.
-    from articulation3d_amd import ops
-    from bench import PIPE_FLOPS_PER_FMA, PIPE_PEAK, dominant_roofline, kernel_sums
-
-    ops.CONV_TIMING = []
-    tr.step(frames, gtb, gtc)
-    barrier()
-    events, ops.CONV_TIMING = ops.CONV_TIMING, None
-    if args.layers and rank == 0:
-        for name, fl, a, b, shape, ex, pipe, _st in events:
-            ms = a.elapsed_time(b)
-            print(f"{name[:40]:40s} {shape:52s} {ex / 1e9:9.2f} GF {ms:8.3f} ms {ex / ms / 1e9 if ms > 0 else 0:8.1f} TF/s", file=sys.stderr)
-    per = kernel_sums(events)
-    step_sec = elapsed / args.steps
-    roofline = dominant_roofline(per, step_sec)
-    issued = sum(v[3] * PIPE_FLOPS_PER_FMA[v[4]] for v in per.values())
-    pipes = {v[4] for v in per.values() if v[3]}
-    step_peak = max(PIPE_PEAK[q] for q in pipes)
-    roofline["source"] = "one fully instrumented step after the timed loop (every conv / linear / weight-gradient launch bracketed by HIP events)"
-    roofline["gemm_kernels_ms_per_step"] = round(1e3 * sum(v[1] for v in per.values()), 3)
-    roofline["whole_step"] = {"executed_tflop_per_step": round(issued / 1e12, 3), "achieved": round(issued / step_sec / 1e12, 2), "peak": step_peak,
-                              "unit": "TFLOP/s", "frac": round(issued / step_sec / 1e12 / step_peak, 4),
-                              "fp32_equivalent_tflop_per_step": round(sum(v[3] for v in per.values()) / 1e12, 3),
-                              "note": "all matrix-pipe FLOPs the step executes (forward + data gradients + weight gradients of the trainable layers, frozen "
-                                      "stem / res2 forward included) over the WALL time of a step, against the dense peak of the pipe the step runs on"}
-    roofline["all_gemm_kernels"] = {k: {"pipe": v[4], "ms_per_step": round(1e3 * v[1], 3), "launches_per_step": v[2],
-                                        "frac_of_pipe_peak": round(v[3] * PIPE_FLOPS_PER_FMA[v[4]] / v[1] / 1e12 / PIPE_PEAK[v[4]], 4) if v[3] else None}
-                                    for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])}
-    result = {
-        "metric": "images/sec through the step1_bbox training step at 480x640", "value": round(B * world * args.steps / elapsed, 2),
-        "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 (fp32 accumulate, fp32 master weights)",
-                                                                         "bf16x3": "f32 via exact 3-way bf16 operand split (forward / data gradients of the non-Winograd layers)"}[args.precision], "data": "synthetic",
-        "config": {"workload": "BASELINE configs[4]: Faster R-CNN training step of step1_bbox.yaml (ResNet50-FPN, FREEZE_AT 2, RPN + box head "
-                               "losses, SGD momentum), random-init weights with calibrated BN, synthetic frames and boxes (arithmetic: see `dtype`)",
-                   "precision": args.precision, "storage": tr.storage,
-                   "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
-                   "gradient_exchange": "one RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none (1 GPU)"},
-        "losses_last_step": {k: round(float(v), 5) for k, v in losses.items()},
-        "roofline": roofline,
-    }
-    if args.cpu_baseline and rank == 0 and world == 1:
-        from oracle import planercnn_oracle as O, train_oracle as TO
-
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = max(1, min(avail, 64))
-        torch.set_num_threads(cores)
-        P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        imgs = O.frames_to_chw(synthetic_frames(B, seed=2020))
-        t0 = time.perf_counter()
-        TO.loss_and_grads(imgs, tg, P, O.OracleCfg(), TO.TrainCfg(), gen=torch.Generator().manual_seed(1))
-        dt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": round(B / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-                                  "sample": f"one forward+backward of the autograd oracle on {B} images (no optimiser step)",
-                                  "caveat": "a stated baseline, never the target (oracle/train_oracle.py: torch.autograd over the CPU oracle)"}
-        result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    result = train_leg(dev, args.batch, args.steps, args.warmup, precision=args.precision, storage=args.storage,
+                       cpu_baseline=args.cpu_baseline and world == 1, layers=args.layers, rank=rank, world=world, dist=dist)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
