@@ -568,10 +568,11 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
         const int rx = a3d_conv_launch_xs_h2(d, s);
         if (rx != A3D_ERR_UNSUPPORTED) return rx;
     }
-    if (d->precision == 3 && !d->x_h2 && (d->tune == 0 || (d->tune >= 26 && d->tune <= 28))) {  // deep 1x1 reductions: ping-pong, both operands by DMA (bit-identical)
-        const int rd = a3d_conv_launch_dk_h2(d, s);
-        if (rd != A3D_ERR_UNSUPPORTED) return rd;
-    }
+    // (Round 5, built, bit-identical, measured and removed -- tools/probes/rejected/conv_dk_h2.hip, profiles/r05_dk_bench.txt: the deep 1x1
+    // reductions (Cin >= 512) with BOTH operands by LDS-DMA -- the raw fp32 activation tile through a 3 - 4 stage ring, split on the fragment --
+    // in the Winograd GEMM's 512-thread ping-pong form: 10 - 15 % SLOWER than conv_x3_kernel<2> on all thirteen such layers of the trunk
+    // (2.96 - 3.04 ms against 2.66 per 64 frames).  Three independent 256-thread workgroups per CU already hide what the antiphase halves
+    // hide, and the one-workgroup-per-CU form exposes its ring fill and epilogue on a k loop of 16 - 64 chunks.)
     if (d->precision == 3 && !d->x_h2) {  // plain 3x3 s1 p1 layers: the patch-resident kernel (another reduction order; chosen by layer and map size)
         const int rc3 = a3d_conv_launch_c3p(d, s);
         if (rc3 != A3D_ERR_UNSUPPORTED) return rc3;

@@ -135,10 +135,6 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
 // layer, tune 14 keeps it off.  A3D_ERR_UNSUPPORTED: not such a layer.
 int a3d_conv_launch_xs_h2(const a3d_conv_desc *d, hipStream_t s);
 
-// fp16x2 pointwise layers with a deep reduction (Cin >= 512): both operands by LDS-DMA, the split on the fragment, ping-pong halves
-// (conv_dk_h2.hip); tune 26 / 27 force its 128- / 256-pixel tile, 28 keeps it off.  A3D_ERR_UNSUPPORTED: not such a layer / too small.
-int a3d_conv_launch_dk_h2(const a3d_conv_desc *d, hipStream_t s);
-
 // Persistent pointwise kernel (conv_pw.hip): 1x1 stride-1 layers with K <= 2048 and enough tiles to keep a persistent
 // grid busy.  Returns A3D_ERR_UNSUPPORTED otherwise.  `force` skips the grid-size heuristic (A/B measurements).
 int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
