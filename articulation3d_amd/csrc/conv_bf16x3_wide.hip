@@ -96,7 +96,6 @@ constexpr int xd_lds_bytes() { return XD_NST * (2 * XW_PX + 2 * XW_PW) * 2 + 2 *
 // order per output as the register-staged loop: bit-identical results (tests/test_gpu_parity.py).
 template <bool F16, bool PH4 = false, bool XD = false>
 __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
-    static_assert(!PH4 || F16, "the fused four-phase form belongs to the fp16x2 arithmetic");
     static_assert(!XD || F16, "pre-split activations belong to the fp16x2 arithmetic");
     constexpr int NP = F16 ? 2 : 3;
     constexpr int XW_XST = NP * XW_PX, XW_WST = NP * XW_PW;  // one stage
@@ -405,37 +404,47 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
         constexpr int b0 = __builtin_ctz(ACT), b1 = NA > 1 ? __builtin_ctz(ACT & (ACT - 1)) : 0;
         const int wnext = wst == 2 ? 0 : wst + 1;
         Split s;
+        // (bf16x3, round 5: a block's three further terms -- m.m, l.h, h.l, XW_REST -- follow its first three and carry no loader work;
+        // the third activation plane of the next chunk is read with the other two.  Same term order per accumulator as conv_x3_kernel's:
+        // bit-identical to the four phase launches of that arithmetic as well.)
         if constexpr (NA == 4) {
             PH_T(0, A0, 0, 0, split(xs[0], 0, s);)
             PH_T(0, A0, 0, 1, put(xst ^ 1, 0, s);)
             PH_T(0, A0, 1, 0, rdA(A1, wst, 1);)
+            XW_REST(0, A0, Bc)
             PH_T(1, A1, 0, 0, split(xs[1], 1, s);)
             PH_T(1, A1, 0, 1, put(xst ^ 1, 1, s);)
             PH_T(1, A1, 1, 0, rdA(A0, wst, 2);)
+            XW_REST(1, A1, Bc)
             __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();
             PH_T(2, A0, 0, 0, dma_w();)
             PH_T(2, A0, 0, 1, load_chunk(xs);)
             PH_T(2, A0, 1, 0, rdA(A1, wst, 3);)
+            XW_REST(2, A0, Bc)
             PH_T(3, A1, 0, 0, rdB(Bn, xst ^ 1, 0); rdB(Bn, xst ^ 1, 1);)
-            PH_T(3, A1, 0, 1, rdA(A0, wnext, nf);)
+            PH_T(3, A1, 0, 1, if constexpr (!F16) rdB(Bn, xst ^ 1, 2); rdA(A0, wnext, nf);)
             PH_T(3, A1, 1, 0, )
+            XW_REST(3, A1, Bc)
         } else if constexpr (NA == 2) {
             PH_T(b0, A0, 0, 0, split(xs[0], 0, s);)
             PH_T(b0, A0, 0, 1, put(xst ^ 1, 0, s); split(xs[1], 1, s);)
             PH_T(b0, A0, 1, 0, put(xst ^ 1, 1, s); rdA(A1, wst, b1);)
+            XW_REST(b0, A0, Bc)
             __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();
             PH_T(b1, A1, 0, 0, dma_w(); rdB(Bn, xst ^ 1, 0);)
             PH_T(b1, A1, 0, 1, load_chunk(xs); rdB(Bn, xst ^ 1, 1);)
-            PH_T(b1, A1, 1, 0, rdA(A0, wnext, nf);)
+            PH_T(b1, A1, 1, 0, if constexpr (!F16) rdB(Bn, xst ^ 1, 2); rdA(A0, wnext, nf);)
+            XW_REST(b1, A1, Bc)
         } else {
             static_assert(NA == 1, "corner, edge or centre tap");
             PH_T(b0, A0, 0, 0, split(xs[0], 0, s); put(xst ^ 1, 0, s);)
             PH_T(b0, A0, 0, 1, split(xs[1], 1, s); put(xst ^ 1, 1, s);)
             __asm__ volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __syncthreads();
-            PH_T(b0, A0, 1, 0, dma_w(); XW_FENCE load_chunk(xs); rdB(Bn, xst ^ 1, 0); rdB(Bn, xst ^ 1, 1);)  // (DMA before the loads: the counted wait)
+            PH_T(b0, A0, 1, 0, dma_w(); XW_FENCE load_chunk(xs); rdB(Bn, xst ^ 1, 0); rdB(Bn, xst ^ 1, 1); if constexpr (!F16) rdB(Bn, xst ^ 1, 2);)  // (DMA before the loads: the counted wait)
+            XW_REST(b0, A0, Bc)
             rdA(A0, wnext, nf);  // (A0 was in use until the last term)
             XW_FENCE
         }
@@ -646,8 +655,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d,
 // offset limits.
 // The fused four-phase form (a3d_conv_desc.phase == 5): see conv_x3w_kernel's PH4.
 static int launch_ph4(const a3d_conv_desc *d, hipStream_t s) {
-    if (d->precision != 3 || !d->w_x3 || !d->in_amax || !(d->w_scale > 0.f)) return A3D_ERR_ARG;
-    {
+    if ((d->precision != 3 && d->precision != 2) || !d->w_x3) return A3D_ERR_ARG;
+    if (d->precision == 3 && (!d->in_amax || !(d->w_scale > 0.f))) return A3D_ERR_ARG;
+    if (d->precision == 3) {
         const int rp = a3d_conv_launch_ph4p(d, s);  // maps that fit its 8 x 32 tiles: the patch-resident form (conv_ph4p.hip)
         if (rp != A3D_ERR_UNSUPPORTED) return rp;
     }
@@ -661,8 +671,16 @@ static int launch_ph4(const a3d_conv_desc *d, hipStream_t s) {
     const int mtiles = (M + XW_BM - 1) / XW_BM, ntiles = (d->Cout + XW_BN - 1) / XW_BN;
     static a3d_attr_once attr_ph4;
     if (attr_ph4.needed()) {
-        if (hipFuncSetAttribute((const void *)conv_x3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(2)) != hipSuccess) return A3D_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void *)conv_x3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(2)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_x3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, xw_lds_bytes(3)) != hipSuccess)
+            return A3D_ERR_LAUNCH;
         attr_ph4.mark();
+    }
+    if (d->precision == 2) {  // round 5: the same loop with three operand planes and six terms (the like-for-like arithmetic)
+        if ((size_t)d->Cout * d->Kpad * 6 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
+        a3d_note_variant("conv_x3w_kernel ph4");
+        hipLaunchKernelGGL((conv_x3w_kernel<false, true>), dim3(mtiles * ntiles, 1), dim3(512), xw_lds_bytes(3), s, *d, M, ntiles, mtiles * ntiles);
+        return a3d_check_launch();
     }
     a3d_note_variant("conv_h2w_kernel ph4");
     hipLaunchKernelGGL((conv_x3w_kernel<true, true>), dim3(mtiles * ntiles, 1), dim3(512), xw_lds_bytes(2), s, *d, M, ntiles, mtiles * ntiles);

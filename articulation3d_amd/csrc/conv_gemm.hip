@@ -25,7 +25,7 @@ static int conv_check(const a3d_conv_desc *d) {
         if (d->Kpad < d->KH * d->KW * (d->Cin + d->Cin2)) return A3D_ERR_ARG;
     }
     if (d->pixshuf && (d->Cout & 15)) return A3D_ERR_ARG;
-    if (d->phase < 0 || d->phase > 5 || (d->phase == 5 && d->precision != 3)) return A3D_ERR_ARG;  // (5: the fused four-phase form, fp16x2 only)
+    if (d->phase < 0 || d->phase > 5 || (d->phase == 5 && d->precision != 3 && d->precision != 2)) return A3D_ERR_ARG;  // (5: the fused four-phase form: the split-operand arithmetics)
     if (d->gate && (d->pixshuf || d->phase)) return A3D_ERR_ARG;
     if (d->io_bf16 && d->precision != 1) return A3D_ERR_ARG;  // bf16 storage belongs to the bf16 (autocast) arithmetic
     if (d->splitk > 1 && !d->workspace) return A3D_ERR_ARG;

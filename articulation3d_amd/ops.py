@@ -620,7 +620,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         assert not ups and out is not None, "phase convs run on the source grid and fill a shared [B,2H,2W,C] output"
         Ho, Wo = H, W
         if p.phase == 5:
-            assert precision == 3 and (dot is not None or tuple(out.shape) == (B, 2 * H, 2 * W, p.cols // 4)), "the fused four-phase form is an fp16x2 launch"
+            assert precision in (2, 3) and (dot is not None or tuple(out.shape) == (B, 2 * H, 2 * W, p.cols // 4)), "the fused four-phase form belongs to the split-operand arithmetics"
     if out is None:
         shape = (B, 2 * Ho, 2 * Wo, p.cols // 4) if p.pixshuf else (B, Ho, Wo, p.cols)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
@@ -741,7 +741,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             if not os.environ.get("A3D_NO_PUBLISH"):
                 torch.cuda.current_stream().synchronize()  # published to every stream, see w_wino_x3 below
         d.w_x3 = p.w_h2.data_ptr()
-    if (d.precision == 2 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9)
+    if (d.precision == 2 and not use_wino and p.presplit and p.cols >= 192 and p.Kpad % 16 == 0 and (p.Kpad >= 4096 or tune == 9 or p.phase == 5)
             and not (p.stem or p.pixshuf)):
         # wide layers: weight planes pre-split once per packed layer, streamed by LDS-DMA (csrc/conv_bf16x3_wide.hip)
         if p.w_x3 is None or p.w_x3.device != p.w.device:
@@ -866,16 +866,16 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
     if AUDIT is not None and not AUDIT.busy and fused is None:
         return AUDIT.conv2d_ups(x, phases, x2)
     out = torch.empty((B, 2 * H, 2 * W, phases[0].cols), device=x.device, dtype=torch.float32)
-    pinned = phases[0].pin_precision == 2  # (the audit pins the LAYER: its four phase launches then run bf16x3)
+    pinned = phases[0].pin_precision == 2  # (the audit pins the LAYER: it then runs bf16x3 -- since round 5 in the fused form as well)
     if fused is None:
-        fused = UPS_FUSED and DEFAULT_PRECISION == 3 and not pinned  # (a function of the layer and the arithmetic: never of the batch)
+        fused = UPS_FUSED and DEFAULT_PRECISION in (2, 3)  # (a function of the layer and the arithmetic: never of the batch)
     if fused:
         pf = getattr(phases[0], "_fused", None)
         if pf is None:
             pf = pack_conv_ups_fused(phases)
             phases[0]._fused = pf if pf is not None else False
         if pf:  # (tune 15 / 16: never / always the patch-resident kernel of csrc/conv_ph4p.hip; 0: by the map's size)
-            return conv2d(x, pf, x2=x2, out=out, precision=3, tune=tune)
+            return conv2d(x, pf, x2=x2, out=out, precision=2 if (pinned or DEFAULT_PRECISION == 2) else 3, tune=tune)
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out

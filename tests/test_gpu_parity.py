@@ -700,6 +700,33 @@ def test_fused_upsampled_conv_equals_the_four_phase_launches(ops, case):
         assert float((one[i].double() - ref[i]).norm() / ref[i].norm()) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(3, 30, 40, 128, 128, 128), (2, 61, 79, 256, 0, 64), (2, 15, 20, 256, 256, 128), (2, 120, 160, 128, 128, 64)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_fused_upsampled_conv_in_the_bf16x3_arithmetic(ops, case):
+    """Round 5: the fused four-phase launch instantiated for the like-for-like arithmetic (exact 3-way bf16 splits, six products per step:
+    conv_x3w_kernel<false, true>) -- the depth decoder's deconv layers (depth_head.py:40-46,58-68) when the package runs bf16x3, and
+    every layer the precision audit pins.  Same term order per accumulator as the four phase launches of conv_x3_kernel: equal bits;
+    fp32-grade against the float64 convolution of the upsampled tensor; a frame's result does not depend on its batch."""
+    B, H, W, C1, C2, Cout = case
+    torch.manual_seed(17)
+    a = torch.randn(B, H, W, C1, device="cuda") * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+    c2 = torch.randn(B, H, W, C2, device="cuda") if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5)
+    b = torch.randn(Cout) * 0.1
+    phases = ops.pack_conv_ups_phases(w, b, None, ops.ACT_RELU)
+    with arithmetic(ops, 2):
+        four = ops.conv2d_ups(a, phases, x2=c2, fused=False)
+        assert ops.last_conv_variant().startswith("conv_x3_kernel"), ops.last_conv_variant()
+        one = ops.conv2d_ups(a, phases, x2=c2)
+        assert ops.last_conv_variant() == "conv_x3w_kernel ph4", ops.last_conv_variant()
+        alone = ops.conv2d_ups(a[-1:].contiguous(), phases, x2=None if c2 is None else c2[-1:].contiguous())
+    assert one.shape == (B, 2 * H, 2 * W, Cout) and torch.equal(one, four) and torch.equal(alone[0], one[-1])
+    xin = a if c2 is None else torch.cat([a, c2], 3)
+    up = F.interpolate(xin[-1:].permute(0, 3, 1, 2).double(), scale_factor=2, mode="nearest")
+    ref = F.relu(F.conv2d(up, w.double().cuda(), b.double().cuda(), padding=1)).permute(0, 2, 3, 1)
+    assert float((one[-1].double() - ref[0]).norm() / ref[0].norm()) < 1e-6
+
+
 @pytest.mark.parametrize("splitk", [1, 7, 64])
 def test_linear_splitk_chw_reorder(ops, splitk):
     torch.manual_seed(4)
