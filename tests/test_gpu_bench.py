@@ -90,6 +90,13 @@ def test_bench_spawns_its_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    # the collective record (round 5): backend, world, every rank's device identity gathered over the group, what the gathers moved
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world"] == 2 and [x["rank"] for x in c["devices"]] == [0, 1]
+    assert c["distinct_devices"] == 1 and c["gathers_per_step"] >= 1 and c["gather_bytes_per_step"] > 0  # (two ranks share this box's one GPU)
+    # ... and the training-step leg runs data-parallel over the same group (one all-reduce per step)
+    t = d["train_step"]["images_per_gpu_2"]
+    assert t["config"]["global_batch"] == 4 and t["value"] > 0 and 0 < t["roofline"]["whole_step"]["frac"] < 1
     # an N > 1 line carries the CPU leg and the matched-detections check too (rank 0 runs them after the timed region)
     assert d["cpu_baseline"]["cores"] >= 1 and d["matched_detections"]["frames"] == 5 and d["matched_detections"]["matched"] is True
     # a launcher / flag disagreement is refused instead of mislabelled
@@ -103,13 +110,14 @@ def test_bench_with_eight_ranks_reports_eight(tmp_path):
     step's records are all-gathered, rank 0 runs the CPU leg and the matched-detections check while the others wait at the barrier,
     and the line says n_gpus = 8 with whole-job frames per step."""
     r = _run(["bench.py", "--gpus", "8", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "2",
-              "--cpu-frames", "2", "--no-alt-modes", "--no-operating-points"], timeout=1800)
+              "--cpu-frames", "2", "--no-alt-modes", "--no-operating-points", "--no-train-leg"], timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 8 and d["config"]["global_frames_per_step"] == 16 and d["scaling"] == "weak" and d["value"] > 0
     assert d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0 and d["matched_detections"]["matched"] is True
     # (eight ranks time-share ONE GPU here: the dominant kernel's rate can round to 0.0000 of the roof -- what must hold is that it was measured)
     assert "RCCL all-gather" in d["config"]["sharding"] and d["roofline"]["launches"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+    assert d["collective"]["world"] == 8 and len(d["collective"]["devices"]) == 8 and d["collective"]["gather_bytes_per_step"] > 0
 
 
 def _two_gpus():
@@ -130,6 +138,10 @@ def test_two_real_rccl_ranks_bench_and_inference(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_frames_per_step"] == 16 and "cpu_baseline" in d and d["matched_detections"]["matched"] is True
+    # RCCL saw two DISTINCT GPUs: checkable from the line alone
+    c = d["collective"]
+    assert c["backend"] == "nccl" and c["world"] == 2 and c["distinct_devices"] == 2 and len({x["pci"] for x in c["devices"]}) == 2
+    assert c["gather_bytes_per_step"] > 0 and d["train_step"]["images_per_gpu_2"]["config"]["global_batch"] == 4
     common = ["--config", "configs/planercnn_inference.yaml", "--input", "synthetic:7", "--random-init", "--calibrate-bn",
               "--conf-threshold", "0.3", "--batch", "2"]
     opts = ["MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.3"]
@@ -147,10 +159,11 @@ def test_two_real_rccl_ranks_bench_and_inference(tmp_path):
 
 def test_bench_single_rank_rccl_gather(tmp_path):
     """The nccl (= RCCL) process group and the asynchronous all-gather of the detection records, with one rank on this box."""
-    r = _run(["bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-alt-modes", "--no-operating-points"],
+    r = _run(["bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-alt-modes", "--no-operating-points", "--no-train-leg"],
              env=dict(ENV, A3D_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
+    assert d["collective"]["backend"] == "nccl" and d["collective"]["world"] == 1 and d["collective"]["devices"][0]["pci"]
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] <= 1.0
     assert d["roofline"]["kernel"].startswith(("wino_", "conv_")) and d["roofline"]["pipe"] in ("f16x3", "bf16x6", "f32")
 
@@ -174,6 +187,14 @@ def test_bench_default_line_has_the_contract_fields():
     assert md["frames"] == 5 and md["matched"] is True, md
     assert all(k in md for k in ("max_raw_plane_err", "max_raw_rot_err", "max_raw_tran_err", "max_plane_cond", "max_tran_axis_cond")), md
     assert d["roi_out_of_window"] == 0 and "22-bit significand" in d["dtype"] and "block exponent" in d["dtype"]
+    # round 5: the transfers ride a copy stream beside the step (the transfer-inclusive figure sits within a few percent of `value` even on
+    # this short run), the collective record is there at N = 1 too, and the training step (BASELINE configs[4]) reports where the driver looks
+    assert d["value_with_transfers"]["vs_resident"] > 0.9 and d["value_transfer_inclusive"] == d["value_with_transfers"]["value"]
+    assert d["collective"]["world"] == 1 and d["collective"]["backend"] is None and len(d["collective"]["devices"]) == 1
+    for k in ("images_per_gpu_2", "images_per_gpu_16"):
+        t = d["train_step"][k]
+        assert t["unit"] == "images/s" and t["value"] > 0 and t["roofline"]["peak"] == 2500.0 and 0 < t["roofline"]["whole_step"]["frac"] < 1
+        assert t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["value"] > 0
 
 
 def test_first_small_batch_of_a_process_equals_the_steady_state():
