@@ -188,8 +188,11 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                             finally:
                                 ops.WINO_PLANE_SPLIT = saved_ps
                         forms.append(("plane-split toggled", other_ps))
+                        # (round 5) the ping-pong loop is the default: the lockstep loop and the 64-tile form claim its bits
+                        forms += [(f"tune {t}", lambda t=t: launch(3, x, pk, tune=t, precision=3, **kw)[0]) for t in (23, 24)]
                     if mode == 2 and v0.startswith("wino"):
-                        forms.append(("tune 8", lambda: launch(2, x, pk, tune=8, precision=2, **kw)[0]))
+                        # (round 5) default = both operands pre-split by DMA, ping-pong; 8 / 24 / 25 = the register-staged narrow / 64-tile / 128-tile forms
+                        forms += [(f"tune {t}", lambda t=t: launch(2, x, pk, tune=t, precision=2, **kw)[0]) for t in (8, 24, 25)]
                     if mode == 0 and v0.startswith("wino"):
                         forms.append(("tune 7", lambda: launch(0, x, pk, tune=7, **kw)[0]))
                     if mode == 0 and kind in ("1x1", "linear"):
