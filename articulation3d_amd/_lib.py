@@ -202,7 +202,6 @@ SIGNATURES = {
                                            C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_wino_m_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
-    "a3d_wino_v_format": (C.c_int, [C.POINTER(ConvDesc)]),
     "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),

@@ -93,19 +93,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 typedef _Float16 wi_h16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int wi_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int wi_u32x4 __attribute__((ext_vector_type(4)));
-// X3 (round 5, a3d_conv_desc.precision == 2): the same kernel for the bf16x3 arithmetic -- (B^T d B) = h + m + l EXACTLY, three bf16 planes,
-// no scale -- Vs [16 planes][C/32 chunks][h | m | l][T tiles][32 k] bf16, 6 bytes per element: what wino_gemm_x3w_kernel<4, false, false, 1>
-// DMAs (the split the register-staged GEMM performs in its loop: wsplit3, element for element the same bits).
-typedef __bf16 wi_bf16x4 __attribute__((ext_vector_type(4)));
-template <bool X3>
 __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restrict__ x, const float *__restrict__ x2, unsigned char *__restrict__ Vs,
                                                             const float *__restrict__ in_amax, const float *__restrict__ in_amax2, int B, int H, int W,
                                                             int Cin, int Cin2, int ups, int Ty, int Tx) {
-    constexpr int NPL = X3 ? 3 : 2;  // operand planes
     const int C = Cin + Cin2;
     const int Hl = ups ? 2 * H : H, Wl = ups ? 2 * W : W;
     const size_t T = (size_t)B * Ty * Tx;
-    const size_t tile = T * 64;  // bytes of one (plane, chunk, operand plane) tile
+    const size_t tile = T * 64;  // bytes of one (plane, chunk, h | l) tile
     const int KC = C >> 5;
     // A wave = 8 consecutive tiles x one 32-channel chunk (lane = 8 * tile + channel quad): a store instruction then writes two runs of
     // 512 B (the h rows and the l rows of the 8 tiles); with a wave = one tile x all channels it wrote 64-byte pieces a whole tile
@@ -124,12 +118,9 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restr
         const bool second = c >= Cin;
         const float *src = second ? x2 : x;
         const int cs = second ? Cin2 : Cin, cc = second ? c - Cin : c;
-        float sv = 1.f;
-        if constexpr (!X3) {
-            float am = in_amax[b];
-            if (in_amax2) am = fmaxf(am, in_amax2[b]);
-            sv = 0.25f * a3d_pow2_scale(am);  // wino_v_scale
-        }
+        float am = in_amax[b];
+        if (in_amax2) am = fmaxf(am, in_amax2[b]);
+        const float sv = 0.25f * a3d_pow2_scale(am);  // wino_v_scale
         f32x4 d[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -157,28 +148,18 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restr
         // 64-byte row, the 8 tiles of the wave one 512-byte run per instruction.  (Pairing lanes into 16-byte stores cost 32 LDS
         // permutes and ~140 selects per thread and was slower.)
         const int kc = c >> 5;
-        unsigned char *oh = Vs + (size_t)kc * NPL * tile + t * 64 + (c & 31) * 2;
-        const size_t pstride = (size_t)KC * NPL * tile;  // one Winograd plane
+        unsigned char *oh = Vs + (size_t)kc * 2 * tile + t * 64 + (c & 31) * 2;
+        const size_t pstride = (size_t)KC * 2 * tile;  // one Winograd plane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // (B^T d) B
             const f32x4 vv[4] = {m[u][0] - m[u][2], m[u][1] + m[u][2], m[u][2] - m[u][1], m[u][1] - m[u][3]};
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                if constexpr (X3) {  // (wsplit3: round to nearest even at each level)
-                    const wi_bf16x4 h = __builtin_convertvector(vv[v], wi_bf16x4);
-                    const f32x4 r1 = vv[v] - __builtin_convertvector(h, f32x4);
-                    const wi_bf16x4 m2 = __builtin_convertvector(r1, wi_bf16x4);
-                    const f32x4 r2 = r1 - __builtin_convertvector(m2, f32x4);
-                    *reinterpret_cast<wi_bf16x4 *>(oh) = h;
-                    *reinterpret_cast<wi_bf16x4 *>(oh + tile) = m2;
-                    *reinterpret_cast<wi_bf16x4 *>(oh + 2 * tile) = __builtin_convertvector(r2, wi_bf16x4);
-                } else {
-                    const f32x4 xs = vv[v] * sv;
-                    const wi_h16x4 h = __builtin_convertvector(xs, wi_h16x4);
-                    const wi_h16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wi_h16x4);
-                    *reinterpret_cast<wi_h16x4 *>(oh) = h;
-                    *reinterpret_cast<wi_h16x4 *>(oh + tile) = l;
-                }
+                const f32x4 xs = vv[v] * sv;
+                const wi_h16x4 h = __builtin_convertvector(xs, wi_h16x4);
+                const wi_h16x4 l = __builtin_convertvector(xs - __builtin_convertvector(h, f32x4), wi_h16x4);
+                *reinterpret_cast<wi_h16x4 *>(oh) = h;
+                *reinterpret_cast<wi_h16x4 *>(oh + tile) = l;
                 oh += pstride;
             }
         }
@@ -658,9 +639,8 @@ constexpr int X3W_BN = 128, X3W_LKB = 32;
 constexpr int x3w_buf(int WM, int NP) { return NP * (32 * WM + X3W_BN) * X3W_LKB; }  // 16-bit elements of one stage: X and W, NP planes each
 // stages of the operand ring: the bf16x3 form double-buffers (V passes through registers); the fp16x2 form receives BOTH operands
 // pre-split by LDS-DMA and keeps 3 (two workgroups per CU) or 4 (one) stages in flight
-// (bf16x3 with BOTH operands by DMA -- round 5, the ping-pong form only: three stages of 48 KiB)
-constexpr int x3w_stages(int WM, int NP, bool vdma = false) { return NP == 2 ? (WM == 2 ? 3 : 4) : (vdma ? 3 : 2); }
-constexpr int x3w_lds_bytes(int WM, int NP, bool vdma = false) { return x3w_stages(WM, NP, vdma) * x3w_buf(WM, NP) * 2 + 2 * X3W_BN * 4; }
+constexpr int x3w_stages(int WM, int NP) { return NP == 2 ? (WM == 2 ? 3 : 4) : 2; }
+constexpr int x3w_lds_bytes(int WM, int NP) { return x3w_stages(WM, NP) * x3w_buf(WM, NP) * 2 + 2 * X3W_BN * 4; }
 
 // WM = wave rows: 2 -> 64 tiles x 128 channels, 256 threads, two workgroups per CU; 4 -> 128 tiles x 128 channels, 512 threads, one
 // workgroup per CU (every 64-tile block streams all of U3 -- 6 B per weight -- from L2: 30 GB per p2 layer; 128-tile blocks halve it)
@@ -671,17 +651,14 @@ constexpr int x3w_lds_bytes(int WM, int NP, bool vdma = false) { return x3w_stag
 // a few tile blocks otherwise occupies a few CUs for 16 x C/32 latency-bound iterations (a single 30x40 frame: 6 workgroups, 116 us).
 template <int WM, bool F16 = false, bool PS = false, int PP = 0>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
-    static_assert(PP == 0 || (!PS && WM == 4), "ping-pong: the 512-thread form (two waves per SIMD)");
+    static_assert(PP == 0 || (F16 && !PS && WM == 4), "ping-pong: the 512-thread fp16x2 form (two waves per SIMD)");
     constexpr int NP = F16 ? 2 : 3;
-    // VDMA: V arrives pre-split (wino_input_h2_kernel) and takes the filter's road, global -> LDS by DMA: every fp16x2 launch, and the bf16x3
-    // ones in their ping-pong form
-    constexpr bool VDMA = F16 || PP > 0;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
     constexpr int PLX = BM * LKB, PLW = BN * LKB, BUF = x3w_buf(WM, NP);
     constexpr int DPW = 8 * NP / NW;  // weight DMA instructions per wave and chunk
     static_assert(XR == 2, "the counted vmcnt waits below assume two V loads per chunk");
-    constexpr int NST = x3w_stages(WM, NP, VDMA);
+    constexpr int NST = x3w_stages(WM, NP);
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     float *ss = reinterpret_cast<float *>(lds + NST * BUF);
 
@@ -736,12 +713,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     // (wino_v_scale) -- and takes the same road as the filter: a (f, chunk, plane) tile of this workgroup's BM rows is a contiguous run
     // of BM / 16 DMA instructions (16 rows x 64 B each), two instructions per wave and chunk, with the filter's slot swizzle.  No V
     // registers, no split in the loop, no VGPR -> LDS stores.  (Rows past T read the next plane's rows or zeros: never stored.)
-    constexpr int DPV = NP * (BM / 16) / NW;
-    static_assert(NP * (BM / 16) == DPV * NW, "the V DMA instructions of a chunk divide over the waves");
+    constexpr int DPV = 2;
+    static_assert(2 * (BM / 16) == DPV * NW, "two V DMA instructions per wave and chunk");
     auto dma_v = [&](const int buf, const int c) {  // c = flat (f, kc) index of the chunk (clamped like the filter's)
         __bf16 *X = lds + buf * BUF;
         const size_t tile = (size_t)a.T * 64;  // bytes of one (f, chunk, plane) tile
-        const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(reinterpret_cast<const char *>(a.V) + (size_t)min(c, NIT - 1) * NP * tile, (unsigned)(NP * tile));
+        const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(reinterpret_cast<const char *>(a.V) + (size_t)min(c, NIT - 1) * 2 * tile, (unsigned)(2 * tile));
 #pragma unroll
         for (int i = 0; i < DPV; ++i) {
             const int j = wave * DPV + i;
@@ -961,7 +938,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     };
 
     Frags F0, F1;
-    if constexpr (VDMA) {
+    if constexpr (F16) {
         // fp16x2 schedule.  Chunk c lives in stage c % NST.  An iteration = the two 16-deep steps of one chunk (three product terms of
         // two MFMAs each) with ONE barrier between them.  Behind that barrier every wave has read all fragments of chunk c (S0(c)
         // during the previous iteration, S1(c) during step 0), so the DMA of chunk c + NST goes straight into the stage of chunk c:
@@ -1015,19 +992,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 X3W_TERM(F0, 0, 0)
                 X3W_TERM(F0, 0, 1)
                 X3W_TERM(F0, 1, 0)
-                if constexpr (!F16) {  // (bf16x3: the six terms of wino_gemm_x3_kernel, in its order)
-                    X3W_TERM(F0, 1, 1)
-                    X3W_TERM(F0, 2 % NP, 0)
-                    X3W_TERM(F0, 0, 2 % NP)
-                }
                 X3W_TERM(F1, 0, 0)
                 X3W_TERM(F1, 0, 1)
                 X3W_TERM(F1, 1, 0)
-                if constexpr (!F16) {
-                    X3W_TERM(F1, 1, 1)
-                    X3W_TERM(F1, 2 % NP, 0)
-                    X3W_TERM(F1, 0, 2 % NP)
-                }
                 X3W_FENCE
             };
             auto plane_end = [&]() {
@@ -1461,23 +1428,10 @@ int a3d_wino_eligible(const a3d_conv_desc *d) {
     return 1;
 }
 
-// Format of the transformed tiles V a descriptor's launches write and read: 0 = fp32 [16][T][C]; 1 = the two scaled fp16 planes of the
-// fp16x2 arithmetic, chunk-major; 2 = the three bf16 planes of the bf16x3 arithmetic, chunk-major (round 5: the layers whose channel
-// counts fit the 128-tile ping-pong GEMM; tune 8 / 24 / 25 keep the register-staged forms and their fp32 V).  Consumers that share one V
-// (ops.share_wino_input) must agree on it.
-extern "C" int a3d_wino_v_format(const a3d_conv_desc *d) {
-    if (!d) return 0;
-    if (d->precision == 3) return 1;
-    if (d->precision == 2 && d->tune == 0 && d->w_wino_x3 && ((d->Cin + d->Cin2) & 31) == 0 && ((d->Cout + 63) / 64) % 2 == 0 &&
-        (size_t)16 * d->Cout * (d->Cin + d->Cin2) * 6 < ((size_t)1 << 32))
-        return 2;
-    return 0;
-}
-
 size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
     const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
     const size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
-    return 16 * T * ((size_t)d->Cin + d->Cin2) * (a3d_wino_v_format(d) == 2 ? 6 : sizeof(float));
+    return 16 * T * ((size_t)d->Cin + d->Cin2) * sizeof(float);
 }
 
 // Plane-split form (precision 3): worth it while the one-launch form would start at most 48 128-tile workgroups -- they leave most
@@ -1511,13 +1465,8 @@ static int wino_launch_input(const a3d_conv_desc *d, hipStream_t s) {
     if (blocks > 16384) blocks = 16384;
     if (d->precision == 3) {  // fp16x2: V pre-split into the two fp16 planes, chunk-major (what wino_gemm_x3w_kernel<.., true> DMAs)
         if ((C & 31) || !d->in_amax) return A3D_ERR_ARG;
-        hipLaunchKernelGGL(wino_input_h2_kernel<false>, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, reinterpret_cast<unsigned char *>(d->workspace), d->in_amax,
+        hipLaunchKernelGGL(wino_input_h2_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, reinterpret_cast<unsigned char *>(d->workspace), d->in_amax,
                            d->in_amax2, d->B, d->H, d->W, d->Cin, d->Cin2, d->ups, Ty, Tx);
-        return A3D_OK;
-    }
-    if (a3d_wino_v_format(d) == 2) {  // bf16x3, ping-pong GEMM: V pre-split into its three bf16 planes
-        hipLaunchKernelGGL(wino_input_h2_kernel<true>, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, reinterpret_cast<unsigned char *>(d->workspace), nullptr,
-                           nullptr, d->B, d->H, d->W, d->Cin, d->Cin2, d->ups, Ty, Tx);
         return A3D_OK;
     }
     hipLaunchKernelGGL(wino_input_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, d->workspace, d->B, d->H, d->W,
@@ -1599,21 +1548,11 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     if (d->precision == 2) {  // fp32-grade products on the bf16 pipe (2x); C % 32 == 0 is required by its 32-deep chunks
         if (!d->w_wino_x3 || (a.C & 31)) return A3D_ERR_ARG;
         a.U3 = reinterpret_cast<const __bf16 *>(d->w_wino_x3);
-        if (a3d_wino_v_format(d) == 2) {
-            // Round 5: both operands pre-split, global -> LDS by DMA through three 48 KiB stages, the 512-thread workgroup's halves in
-            // antiphase (the fp16x2 form's ping-pong loop with three planes and six terms): every layer whose channel counts fit the
-            // 128 x 128 blocks, whatever the problem size.  Bit-identical to the register-staged forms below (tune 8 / 24 / 25).
-            static a3d_attr_once attr_x3d;
-            if (attr_x3d.needed()) {
-                if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 3, true)) != hipSuccess)
-                    return A3D_ERR_LAUNCH;
-                attr_x3d.mark();
-            }
-            const int nt = (d->Cout + X3W_BN - 1) / X3W_BN, m4 = (int)((T + 127) / 128);
-            a3d_note_variant("wino_gemm_x3w_kernel<4> pp");
-            hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, false, false, 1>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 3, true), s, a, nt, m4 * nt);
-            return A3D_OK;
-        }
+        // (Round 5, built, bit-identical -- fuzz + equality tests --, measured and removed: the fp16x2 form's recipe for this arithmetic, V
+        // pre-split into its three bf16 planes by the transform (6 bytes per element), both operands by LDS-DMA through three 48 KiB stages,
+        // the workgroup's halves in antiphase.  GEMM per layer, 64 frames, that form | the register-staged 128-tile loop below: p2 256 -> 256
+        // 3.497 | 3.526 ms, 60x80 0.954 | 0.916, 30x40 0.328 | 0.342, 276 ROIs 0.188 | 0.191, 15x20x512 0.319 | 0.317 -- a tie, with six
+        // MFMAs per product the loop is not short of overlap -- while the transform writes 1.5 x the bytes: the bf16x3 step 59.3 -> 64.5 ms.)
         // 128 tiles x 128 channels with DMA-staged weights (one 512-thread workgroup per CU) or 64 x 64 (three 256-thread workgroups
         // per CU)?  Both are bit-identical, so the choice is free; it goes by the rounds the busiest CU runs.  A CU works through
         // ceil(blocks / 256) blocks, the narrow form three at a time; three narrow blocks are 0.75 of a wide block's work at ~0.87 of

@@ -758,7 +758,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             if shared is not None and (shared[0].shape != x.shape or d.tune not in (0, 23, 24)):  # (23 | 24: other loops of the same GEMM on the same V)
                 shared = None
             # (the tiles' FORMAT belongs to the arithmetic: fp16x2 consumers read V pre-split into fp16 planes, the others fp32)
-            if shared is not None and shared[1] is not None and len(shared) > 2 and shared[2] != (int(d.precision), _lib.lib().a3d_wino_v_format(C.byref(d))):
+            if shared is not None and shared[1] is not None and len(shared) > 2 and shared[2] != int(d.precision):
                 shared = None
         if shared is not None:
             d.w_wino_cm = None  # consumers of a shared input take the two-launch form so that V exists once for all of them
@@ -778,11 +778,10 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
                 d.wino_m = wino_m.data_ptr()
     if shared is not None:
         have_v, shared[1] = shared[1] is not None, ws
-        fmt = (int(d.precision), _lib.lib().a3d_wino_v_format(C.byref(d)))
         if len(shared) > 2:
-            shared[2] = fmt
+            shared[2] = int(d.precision)
         else:
-            shared.append(fmt)
+            shared.append(int(d.precision))
     # CONV_TIMING_ONLY (a set of variant labels): event pairs only around the launches whose label -- remembered from the last fully
     # instrumented pass over the same layer and shape -- is in the set; every other launch goes out as if nothing were measured
     # (700 event pairs per 64-frame step cost 0.8 ms of its 44).

@@ -212,11 +212,6 @@ int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream);
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */
 int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream);
 int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
-/* Format of the transformed tiles the two launches above exchange through d->workspace: 0 = fp32 [16][tiles][C]; 1 = the two scaled fp16
- * planes of precision 3, chunk-major [16][C/32][2][tiles][32]; 2 = the three bf16 planes of precision 2 (round 5: the layers whose channel
- * counts fit the 128-tile ping-pong GEMM), [16][C/32][3][tiles][32], 6 bytes per element -- a3d_conv_workspace_bytes() sizes it.  Layers that
- * share one transformed input must agree on the format. */
-int a3d_wino_v_format(const a3d_conv_desc *d);
 /* The kernel instantiation the LAST conv launch of the calling thread dispatched, as it appears in a rocprofv3 kernel trace
  * ("conv_pw_kernel<2,2,16> 128x128 persistent", "wino_gemm_kernel<1,32>", ...); "" before the first launch.  For measurement
  * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules.

@@ -109,7 +109,7 @@ def test_shared_winograd_input_transform_is_bit_identical(ops, precision):
     for a, b, c in zip(alone, two_launch, shared):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert torch.equal(unlisted, ops.conv2d(other, pks[0], precision=precision))
-    gemm = "wino_gemm_x3_kernel" if precision == 2 else "wino_gemm_kernel"
+    gemm = "wino_gemm_x3" if precision == 2 else "wino_gemm_kernel"  # (bf16x3: the narrow or a wide split-operand GEMM, by problem size)
     assert sum(n.startswith(gemm) for n in names) >= 2
 
 

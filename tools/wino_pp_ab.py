@@ -14,17 +14,18 @@ for B, H, W, Cin, Cout in shapes:
     torch.manual_seed(1)
     x = torch.randn(B, H, W, Cin, device="cuda")
     pk = ops.pack_conv(torch.randn(Cout, Cin, 3, 3) / (3 * Cin ** 0.5), torch.randn(Cout) * 0.1, None, 1, 1, ops.ACT_RELU)
-    outs = {t: ops.conv2d(x, pk, precision=3, tune=t).clone() for t in TUNES}
+    PREC = int(os.environ.get("PREC", "3"))
+    outs = {t: ops.conv2d(x, pk, precision=PREC, tune=t).clone() for t in TUNES}
     variant = ops.last_conv_variant()
     times = {t: [] for t in TUNES}
     for _ in range(9):
         for t in TUNES:
             ops.CONV_TIMING = []
-            ops.conv2d(x, pk, precision=3, tune=t)
+            ops.conv2d(x, pk, precision=PREC, tune=t)
             torch.cuda.synchronize()
             times[t].append(ops.CONV_TIMING[-1][2].elapsed_time(ops.CONV_TIMING[-1][3]))
     ops.CONV_TIMING = None
-    fl = 2.0 * B * ((H + 1) // 2) * ((W + 1) // 2) * 16 * Cout * Cin * 3
+    fl = 2.0 * B * ((H + 1) // 2) * ((W + 1) // 2) * 16 * Cout * Cin * (3 if PREC == 3 else 6)
     ref = outs[TUNES[0]]
     print(f"{B}x{H}x{W}x{Cin}->{Cout} [{variant}]: " + " | ".join(
         f"tune {t}: {sorted(times[t])[4]:.3f} ms ({fl / sorted(times[t])[4] / 1e9:.0f} TF/s){'' if torch.equal(outs[t], ref) else ' BITS DIFFER ' + str(float((outs[t] - ref).abs().max()))}"
