@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("x2_h2", fptr),
         ("dot_w", fptr),
         ("dot_y", fptr),
+        ("wino_t_off", C.c_int), ("wino_t_total", C.c_int),
     ]
 
 
@@ -202,6 +203,7 @@ SIGNATURES = {
                                            C.POINTER(C.c_float), fptr]),
     "a3d_conv_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "a3d_wino_m_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "a3d_wino_gemm_levels": (C.c_int, [C.POINTER(ConvDesc), C.c_int, fptr]),
     "a3d_split_bf16x3": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_bf16x3_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_split_f16x2_chunk": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, fptr]),

@@ -95,11 +95,12 @@ typedef unsigned int wi_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int wi_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restrict__ x, const float *__restrict__ x2, unsigned char *__restrict__ Vs,
                                                             const float *__restrict__ in_amax, const float *__restrict__ in_amax2, int B, int H, int W,
-                                                            int Cin, int Cin2, int ups, int Ty, int Tx) {
+                                                            int Cin, int Cin2, int ups, int Ty, int Tx, int t_off, int t_total) {
     const int C = Cin + Cin2;
     const int Hl = ups ? 2 * H : H, Wl = ups ? 2 * W : W;
     const size_t T = (size_t)B * Ty * Tx;
-    const size_t tile = T * 64;  // bytes of one (plane, chunk, h | l) tile
+    // (a3d_conv_desc.wino_t_off / wino_t_total: this layer's tiles are the slice [t_off, t_off + T) of a buffer of t_total tiles per run)
+    const size_t tile = (size_t)t_total * 64;  // bytes of one (plane, chunk, h | l) tile
     const int KC = C >> 5;
     // A wave = 8 consecutive tiles x one 32-channel chunk (lane = 8 * tile + channel quad): a store instruction then writes two runs of
     // 512 B (the h rows and the l rows of the 8 tiles); with a wave = one tile x all channels it wrote 64-byte pieces a whole tile
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void wino_input_h2_kernel(const float *__restr
         // 64-byte row, the 8 tiles of the wave one 512-byte run per instruction.  (Pairing lanes into 16-byte stores cost 32 LDS
         // permutes and ~140 selects per thread and was slower.)
         const int kc = c >> 5;
-        unsigned char *oh = Vs + (size_t)kc * 2 * tile + t * 64 + (c & 31) * 2;
+        unsigned char *oh = Vs + (size_t)kc * 2 * tile + ((size_t)t_off + t) * 64 + (c & 31) * 2;
         const size_t pstride = (size_t)KC * 2 * tile;  // one Winograd plane
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // (B^T d) B
@@ -182,7 +183,34 @@ struct WinoArgs {
     float w_scale;                    // precision 3: scale of the pre-split filter planes in U3
     float *M;                         // plane-split form: [16][T][Cout] per-plane products (a3d_conv_desc.wino_m)
     int abl;                          // developer builds (-DA3D_ABLATIONS, env A3D_WINO_ABL): timing-only variants of the ring loop; 0 otherwise
+    int Toff, Ttot;                   // precision 3: the layer's tiles are the slice [Toff, Toff + T) of a V buffer of Ttot tiles per run
+    // multi-level launch (a3d_wino_gemm_levels; the kernel's ML form): T = Ttot = all levels' tiles, level k owns [t0[k], t0[k + 1])
+    struct Levels {
+        int n;
+        int t0[6];
+        int Ty[5], Tx[5], Hl[5], Wl[5];
+        float *y[5];
+        const float *in_amax[5];
+        float *y_amax[5];
+    } lv;
 };
+// level of tile t and its index inside the level (n <= 5: four compares)
+__device__ __forceinline__ void wino_level_of(const WinoArgs::Levels &L, const int t, int &l, int &tl) {
+    l = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) l = (k < L.n && t >= L.t0[k]) ? k : l;
+    int base = L.t0[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k) base = l == k ? L.t0[k] : base;
+    tl = t - base;
+}
+template <typename V>
+__device__ __forceinline__ V wino_level_sel(const V (&arr)[5], const int l) {
+    V v = arr[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k) v = l == k ? arr[k] : v;
+    return v;
+}
 
 typedef _Float16 wh16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 wh16x8 __attribute__((ext_vector_type(8)));
@@ -649,9 +677,12 @@ constexpr int x3w_lds_bytes(int WM, int NP) { return x3w_stages(WM, NP) * x3w_bu
 // PS (plane-split, small problems): blockIdx.y = Winograd plane; the workgroup runs that plane's k loop only and stores the raw product
 // tile to a.M [16][T][Cout]; wino_fold_kernel then folds the 16 planes in the same order and applies the same epilogue.  A problem of
 // a few tile blocks otherwise occupies a few CUs for 16 x C/32 latency-bound iterations (a single 30x40 frame: 6 workgroups, 116 us).
-template <int WM, bool F16 = false, bool PS = false, int PP = 0>
+// ML (round 5): ONE launch over the tiles of several maps that share the filter (a3d_wino_gemm_levels; WinoArgs::lv): the loop is the same --
+// it walks tiles of the concatenated V --, the epilogue looks every tile's level up (output map, per-image scale, recorded maxima).
+template <int WM, bool F16 = false, bool PS = false, int PP = 0, bool ML = false>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
     static_assert(PP == 0 || (F16 && !PS && WM == 4), "ping-pong: the 512-thread fp16x2 form (two waves per SIMD)");
+    static_assert(!ML || (F16 && !PS), "multi-level launches: the fp16x2 form");
     constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
@@ -717,13 +748,13 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     static_assert(2 * (BM / 16) == DPV * NW, "two V DMA instructions per wave and chunk");
     auto dma_v = [&](const int buf, const int c) {  // c = flat (f, kc) index of the chunk (clamped like the filter's)
         __bf16 *X = lds + buf * BUF;
-        const size_t tile = (size_t)a.T * 64;  // bytes of one (f, chunk, plane) tile
+        const size_t tile = (size_t)a.Ttot * 64;  // bytes of one (f, chunk, plane) tile (Ttot = T unless the layer's tiles are a slice)
         const __amdgpu_buffer_rsrc_t rv = wuni_rsrc(reinterpret_cast<const char *>(a.V) + (size_t)min(c, NIT - 1) * 2 * tile, (unsigned)(2 * tile));
 #pragma unroll
         for (int i = 0; i < DPV; ++i) {
             const int j = wave * DPV + i;
             const int p = j / (BM / 16), g = j % (BM / 16);
-            wdma16(rv, X + p * PLX + g * 16 * LKB, wvoff, __builtin_amdgcn_readfirstlane(p * (int)tile + (t0 + g * 16) * 64));
+            wdma16(rv, X + p * PLX + g * 16 * LKB, wvoff, __builtin_amdgcn_readfirstlane(p * (int)tile + (a.Toff + t0 + g * 16) * 64));
         }
     };
     f32x4 xsA[XR], xsB[XR];
@@ -1234,8 +1265,36 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 #endif
     const int tyx = a.Ty * a.Tx;
     // (two exact factors, applied one after the other: their product can leave fp32's range for images of extreme magnitude)
-    const float unx = (F16 && tb + pr < a.T) ? 1.f / wino_v_scale(a, (tb + pr) / tyx) : 1.f, unw = F16 ? 1.f / a.w_scale : 1.f;
+    float unx = 1.f;
+    const float unw = F16 ? 1.f / a.w_scale : 1.f;
     int jb[4], jy[4], jx[4];  // image / first output row / first output column of the tile this lane stores in pass j (-1: none)
+    // ML: the output map of each tile this lane stores (its level's)
+    int jH[4], jW[4];
+    float *jyp[4], *jya[4];
+    if constexpr (ML) {
+        {
+            int l, tl;
+            wino_level_of(a.lv, min(tb + pr, a.T - 1), l, tl);
+            const int b = tl / (wino_level_sel(a.lv.Ty, l) * wino_level_sel(a.lv.Tx, l));
+            if (tb + pr < a.T) unx = 1.f / (0.25f * a3d_pow2_scale(wino_level_sel(a.lv.in_amax, l)[b]));  // (1 / wino_v_scale of the tile's image)
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = tb + qr + 8 * j;
+            int l, tl;
+            wino_level_of(a.lv, min(t, a.T - 1), l, tl);
+            const int Tx = wino_level_sel(a.lv.Tx, l), Ty = wino_level_sel(a.lv.Ty, l);
+            const int r = tl / Tx;
+            jx[j] = 2 * (tl - r * Tx);
+            jy[j] = 2 * (r % Ty);
+            jb[j] = t < a.T ? r / Ty : -1;
+            jH[j] = wino_level_sel(a.lv.Hl, l);
+            jW[j] = wino_level_sel(a.lv.Wl, l);
+            jyp[j] = wino_level_sel(a.lv.y, l);
+            jya[j] = wino_level_sel(a.lv.y_amax, l);
+        }
+    } else {
+    if (F16 && tb + pr < a.T) unx = 1.f / wino_v_scale(a, (tb + pr) / tyx);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int t = tb + qr + 8 * j;
@@ -1243,6 +1302,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
         jx[j] = 2 * (t - r * a.Tx);
         jy[j] = 2 * (r % a.Ty);
         jb[j] = t < a.T ? r / a.Ty : -1;
+        jH[j] = a.Hl;
+        jW[j] = a.Wl;
+        jyp[j] = a.y;
+        jya[j] = a.y_amax;
+    }
     }
     float vmax[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1267,8 +1331,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int oy = jy[j] + (ij >> 1), ox = jx[j] + (ij & 1);
-                if (jb[j] < 0 || oy >= a.Hl || ox >= a.Wl || n >= a.Cout) continue;
-                const size_t ooff = (((size_t)jb[j] * a.Hl + oy) * a.Wl + ox) * a.Cout + n;
+                if (jb[j] < 0 || oy >= jH[j] || ox >= jW[j] || n >= a.Cout) continue;
+                const size_t ooff = (((size_t)jb[j] * jH[j] + oy) * jW[j] + ox) * a.Cout + n;
                 f32x4 v = tv[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
@@ -1277,14 +1341,36 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 } else if (a.act == A3D_ACT_LEAKY) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
                 }
-                if (a.gate) {
+                if (!ML && a.gate) {
                     const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff);
                     for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
                 }
                 vmax[j] = fmaxf(vmax[j], a3d_absmax4(v));
-                *reinterpret_cast<f32x4 *>(a.y + ooff) = v;
+                *reinterpret_cast<f32x4 *>(jyp[j] + ooff) = v;
             }
         }
+    }
+    if constexpr (ML) {
+        // the wave's 32 tiles in one image of one level (the rule at 64 frames: every level's tile count is a multiple of 128): one reduction;
+        // otherwise the 8 lanes of a tile reduce and one of them raises the slot of ITS level and image
+        int l0, tl0, l1, tl1;
+        wino_level_of(a.lv, min(tb, a.T - 1), l0, tl0);
+        wino_level_of(a.lv, min(tb + 31, a.T - 1), l1, tl1);
+        const int tyx0 = wino_level_sel(a.lv.Ty, l0) * wino_level_sel(a.lv.Tx, l0);
+        float *ya0 = wino_level_sel(a.lv.y_amax, l0);
+        if (tb < a.T && l0 == l1 && tl0 / tyx0 == tl1 / tyx0) {
+            if (ya0) a3d_note_amax(ya0, tl0 / tyx0, fmaxf(fmaxf(vmax[0], vmax[1]), fmaxf(vmax[2], vmax[3])), true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = vmax[j];
+                v = fmaxf(v, __shfl_xor(v, 1, 64));
+                v = fmaxf(v, __shfl_xor(v, 2, 64));
+                v = fmaxf(v, __shfl_xor(v, 4, 64));
+                if (jb[j] >= 0 && qc == 0 && jya[j] && v > jya[j][jb[j]]) atomicMax(reinterpret_cast<int *>(jya[j] + jb[j]), __float_as_int(v));
+            }
+        }
+        return;
     }
     if (a.y_amax) {
         const int tl = min(tb + 31, a.T - 1);
@@ -1430,7 +1516,8 @@ int a3d_wino_eligible(const a3d_conv_desc *d) {
 
 size_t a3d_wino_workspace_bytes(const a3d_conv_desc *d) {
     const int Hl = d->ups ? 2 * d->H : d->H, Wl = d->ups ? 2 * d->W : d->W;
-    const size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
+    size_t T = (size_t)d->B * ((Hl + 1) / 2) * ((Wl + 1) / 2);
+    if (d->precision == 3 && d->wino_t_total > 0) T = (size_t)d->wino_t_total;  // (the layer's tiles are a slice of a buffer shared by several maps)
     return 16 * T * ((size_t)d->Cin + d->Cin2) * sizeof(float);
 }
 
@@ -1465,8 +1552,10 @@ static int wino_launch_input(const a3d_conv_desc *d, hipStream_t s) {
     if (blocks > 16384) blocks = 16384;
     if (d->precision == 3) {  // fp16x2: V pre-split into the two fp16 planes, chunk-major (what wino_gemm_x3w_kernel<.., true> DMAs)
         if ((C & 31) || !d->in_amax) return A3D_ERR_ARG;
+        if (d->wino_t_total && (d->wino_t_off < 0 || (size_t)d->wino_t_off + T > (size_t)d->wino_t_total)) return A3D_ERR_ARG;
+        if ((size_t)(d->wino_t_total ? d->wino_t_total : T) * C * 4 >= ((size_t)1 << 32)) return A3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(wino_input_h2_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, reinterpret_cast<unsigned char *>(d->workspace), d->in_amax,
-                           d->in_amax2, d->B, d->H, d->W, d->Cin, d->Cin2, d->ups, Ty, Tx);
+                           d->in_amax2, d->B, d->H, d->W, d->Cin, d->Cin2, d->ups, Ty, Tx, d->wino_t_total ? d->wino_t_off : 0, d->wino_t_total ? d->wino_t_total : (int)T);
         return A3D_OK;
     }
     hipLaunchKernelGGL(wino_input_kernel, dim3((int)blocks), dim3(256), 0, s, d->x, d->x2, d->workspace, d->B, d->H, d->W,
@@ -1501,8 +1590,15 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.in_amax2 = d->in_amax2;
     a.w_scale = d->w_scale;
     a.M = nullptr;
-    a.abl = 0;
     a.abl = (int)a3d_dev_knob("A3D_WINO_ABL", 0);
+    a.Toff = 0;
+    a.Ttot = (int)T;
+    a.lv.n = 0;
+    if (d->wino_t_total) {  // a slice of a shared V buffer: the fp16x2 forms only
+        if (d->precision != 3 || d->wino_t_off < 0 || (size_t)d->wino_t_off + T > (size_t)d->wino_t_total) return A3D_ERR_ARG;
+        a.Toff = d->wino_t_off;
+        a.Ttot = d->wino_t_total;
+    }
     if (d->precision == 3) {  // fp16x2: the wide kernels only (w_wino_x3 = the filter pre-split by a3d_split_f16x2_chunk(.., 32, w_scale))
         if (!d->w_wino_x3 || (a.C & 31) || !d->in_amax || !(d->w_scale > 0.f) || ((d->Cout + 63) / 64) % 2 != 0 ||
             (size_t)16 * d->Cout * a.C * 4 >= ((size_t)1 << 32))
@@ -1622,6 +1718,69 @@ extern "C" int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream) {
     a3d_begin();
     const int r = wino_launch_input(d, (hipStream_t)stream);
     if (r != A3D_OK) return r;
+    return a3d_check_launch();
+}
+
+extern "C" int a3d_wino_gemm_levels(const a3d_conv_desc *lv, int n, void *stream) {
+    if (!lv || n < 1 || n > 5) return A3D_ERR_ARG;
+    const a3d_conv_desc *d0 = lv;
+    if (d0->precision != 3 || !a3d_wino_eligible(d0) || !d0->workspace || !d0->w_wino_x3 || !(d0->w_scale > 0.f) || d0->wino_t_total <= 0) return A3D_ERR_ARG;
+    const int C = d0->Cin + d0->Cin2;
+    if ((C & 31) || ((d0->Cout + 63) / 64) % 2 != 0 || (size_t)16 * d0->Cout * C * 4 >= ((size_t)1 << 32)) return A3D_ERR_ARG;
+    WinoArgs a;
+    a.V = d0->workspace;
+    a.U = d0->w_wino;
+    a.U3 = reinterpret_cast<const __bf16 *>(d0->w_wino_x3);
+    a.scale = d0->scale;
+    a.shift = d0->shift;
+    a.gate = nullptr;
+    a.y = nullptr;
+    a.y_amax = nullptr;
+    a.in_amax = nullptr;
+    a.in_amax2 = nullptr;
+    a.w_scale = d0->w_scale;
+    a.M = nullptr;
+    a.abl = 0;
+    a.C = C;
+    a.Cout = d0->Cout;
+    a.act = d0->act;
+    a.B = d0->B;
+    a.Hl = a.Wl = a.Ty = a.Tx = 1;
+    a.Toff = 0;
+    a.Ttot = a.T = d0->wino_t_total;
+    a.lv.n = n;
+    size_t t = 0;
+    for (int k = 0; k < 5; ++k) {
+        const a3d_conv_desc *d = lv + (k < n ? k : n - 1);
+        if (k < n) {
+            if (d->precision != 3 || !a3d_wino_eligible(d) || d->workspace != d0->workspace || d->w_wino_x3 != d0->w_wino_x3 || d->Cout != d0->Cout ||
+                d->Cin + d->Cin2 != C || d->Cin2 || d->x2 || d->ups || d->gate || d->act != d0->act || d->scale != d0->scale || d->shift != d0->shift ||
+                d->w_scale != d0->w_scale || d->wino_t_total != d0->wino_t_total || (size_t)d->wino_t_off != t || !d->in_amax || !d->y)
+                return A3D_ERR_ARG;
+        }
+        const int Ty = (d->H + 1) / 2, Tx = (d->W + 1) / 2;
+        a.lv.t0[k] = (int)t;
+        a.lv.Ty[k] = Ty;
+        a.lv.Tx[k] = Tx;
+        a.lv.Hl[k] = d->H;
+        a.lv.Wl[k] = d->W;
+        a.lv.y[k] = d->y;
+        a.lv.in_amax[k] = d->in_amax;
+        a.lv.y_amax[k] = d->y_amax;
+        if (k < n) t += (size_t)d->B * Ty * Tx;
+    }
+    a.lv.t0[5] = (int)t;
+    if (t != (size_t)d0->wino_t_total || t * C * 4 >= ((size_t)1 << 32)) return A3D_ERR_ARG;
+    a3d_begin();
+    static a3d_attr_once attr_ml;
+    if (attr_ml.needed()) {
+        if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess)
+            return A3D_ERR_LAUNCH;
+        attr_ml.mark();
+    }
+    const int nt = (a.Cout + X3W_BN - 1) / X3W_BN, m4 = (int)((t + 127) / 128);
+    a3d_note_variant("wino_gemm_h2w_kernel<4> levels%d", n);
+    hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true, false, 1, true>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), (hipStream_t)stream, a, nt, m4 * nt);
     return a3d_check_launch();
 }
 

@@ -84,6 +84,10 @@ class StandardRPNHead(nn.Module):
         """-> per level [B,Hf,Wf,16]: channels 0..2 objectness, 3..14 deltas (a*4+coord), 15 unused."""
         fused = self._fused.packed()
         level = lambda f: ops.conv2d(self.conv(f), fused)
+        if len(feats) >= 2 and feats[0].is_cuda and feats[0].shape[0] > SMALL_BATCH and not self.training:
+            # the shared-filter 3x3 conv over ALL levels as one Winograd GEMM launch (ops.conv2d_levels: bit-identical to the per-level
+            # launches, which it falls back to where the form does not apply)
+            return [ops.conv2d(h, fused) for h in ops.conv2d_levels(feats, self.conv.packed())]
         if len(feats) >= 3 and feats[0].is_cuda and feats[0].shape[0] <= SMALL_BATCH:
             # 1-2 frames: the levels are independent chains of latency-bound launches -- three concurrent branches
             # (stride 4 | stride 8 | the rest), streams.py

@@ -375,6 +375,84 @@ class share_wino_input:
 
 
 _ADDR_LIMIT = (1 << 32) - 1  # the kernels address every operand with 32-bit buffer offsets: one launch sees < 4 GiB per tensor
+WINO_LEVELS = os.environ.get("A3D_WINO_LEVELS", "1") != "0"  # schedule-only switch (False: one launch per map; same bits)
+
+
+def conv2d_levels(xs: Sequence[torch.Tensor], p: PackedConv) -> list:
+    """The SAME 3x3 s1 p1 layer applied to several maps (the RPN head's conv over the pyramid levels: StandardRPNHead, planercnn.py:168;
+    SURVEY K5) as ONE Winograd GEMM launch over the concatenated tiles (a3d_wino_gemm_levels): every map is transformed into its slice
+    of one V buffer, the GEMM walks all tiles and looks each tile's map up in its epilogue.  The partial rounds of the small maps vanish
+    (p2-p6 at 64 frames: 19 + 5 + 2 + 1 + 1 rounds of the chip -> 25) and four launches with them.  Every output element is computed
+    exactly as by `conv2d(x, p)`: bit-identical (tests/test_gpu_parity.py), so the choice may depend on the batch.  Falls back to one
+    launch per map where the form does not apply (another arithmetic, a pinned / audited layer, channel counts the 128-tile blocks do
+    not fit, more than five maps).  Inside `share_wino_input` every map's slice is published for the layer's co-readers."""
+    xs = list(xs)
+    ok = (WINO_LEVELS and DEFAULT_PRECISION == 3 and AUDIT is None and 2 <= len(xs) <= 5 and p.w_wino is not None
+          and p.pin_precision != 2 and p.KH == 3 and p.stride == 1 and p.pad == 1 and not (p.stem or p.phase or p.pixshuf)
+          and all(x.is_cuda and x.dtype == torch.float32 and x.shape[0] == xs[0].shape[0] and x.shape[3] == p.Cin for x in xs)
+          and p.Cin % 32 == 0 and p.Cin >= 256 and -(-p.cols // 64) % 2 == 0)
+    if ok and _WINO_SHARE is not None:  # (a co-reader already transformed one of the maps into a buffer of its own: keep the per-map form)
+        ok = all((_WINO_SHARE.get(x.data_ptr()) or [None, None])[1] is None for x in xs)
+    tiles = [x.shape[0] * ((x.shape[1] + 1) // 2) * ((x.shape[2] + 1) // 2) for x in xs]
+    total = sum(tiles)
+    if not ok or total * p.Cin * 4 > _ADDR_LIMIT:
+        return [conv2d(x, p) for x in xs]
+    dev = xs[0].device
+    if getattr(p, "_u_scale", None) is None:
+        p._u_scale = _pow2_scale_host(float(p.w_wino.abs().max()))
+    if p.w_wino_h2 is None or p.w_wino_h2.device != p.w_wino.device:
+        rows, cols = p.w_wino.shape[1], p.w_wino.shape[2]
+        p.w_wino_h2 = torch.empty((16, cols // 32, 2, rows, 32), device=p.w_wino.device, dtype=torch.float16)
+        _lib.check(_lib.lib().a3d_split_f16x2_chunk(p.w_wino.data_ptr(), p.w_wino_h2.data_ptr(), 16, rows, cols, 32, p._u_scale, _stream()), "a3d_split_f16x2_chunk")
+        if not os.environ.get("A3D_NO_PUBLISH"):
+            torch.cuda.current_stream().synchronize()
+    ws = torch.empty(16 * total * p.Cin, device=dev, dtype=torch.float32)
+    descs = (_lib.ConvDesc * len(xs))()
+    outs, off = [], 0
+    global _LAST_PRECISION
+    _LAST_PRECISION = 3
+    # measurement (bench.py): event pairs around the transforms and around the one GEMM launch, under the same rule as _conv2d_launch
+    label = f"wino_gemm_h2w_kernel<4> levels{len(xs)}"
+    timing = CONV_TIMING is not None and (CONV_TIMING_ONLY is None or label in CONV_TIMING_ONLY or "wino_input_kernel" in CONV_TIMING_ONLY)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
+    if timing:
+        ev[0].record()
+    for k, x in enumerate(xs):
+        _req(x)
+        B, H, W, Cin = x.shape
+        out = torch.empty((B, H, W, p.cols), device=dev, dtype=torch.float32)
+        d = descs[k]
+        d.x, d.w, d.scale, d.shift, d.y = _p(x), _p(p.w), _p(p.scale), _p(p.shift), _p(out)
+        d.B, d.H, d.W, d.Cin, d.Cin2 = B, H, W, Cin, 0
+        d.Ho, d.Wo, d.Cout = H, W, p.cols
+        d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+        d.Kpad, d.ups, d.act = p.Kpad, 0, p.act
+        d.res_ups, d.pixshuf, d.stem, d.splitk = 0, 0, 0, 1
+        d.tune, d.phase, d.precision = 0, 0, 3
+        d.w_wino, d.w_wino_x3, d.w_scale = p.w_wino.data_ptr(), p.w_wino_h2.data_ptr(), p._u_scale
+        d.in_amax = amax_of(x).data_ptr()
+        if not os.environ.get("A3D_NO_YAMAX"):
+            out._a3d_amax = amax_slot(B, dev)
+            d.y_amax = out._a3d_amax.data_ptr()
+        d.workspace = ws.data_ptr()
+        d.wino_t_off, d.wino_t_total = off, total
+        _lib.check(_lib.lib().a3d_wino_input_transform(C.byref(d), _stream()), "a3d_wino_input_transform")
+        if _WINO_SHARE is not None:
+            ent = _WINO_SHARE.get(x.data_ptr())
+            if ent is not None and ent[0].shape == x.shape:
+                ent[1:] = [ws, 3, (off, total)]  # [tensor, V buffer, arithmetic of its format, (slice offset, tiles per run)]
+        off += tiles[k]
+        outs.append(out)
+    if timing:
+        ev[1].record()
+    _lib.check(_lib.lib().a3d_wino_gemm_levels(descs, len(xs), _stream()), "a3d_wino_gemm_levels")
+    if timing:
+        ev[2].record()
+        px = sum(x.shape[0] * x.shape[1] * x.shape[2] for x in xs)
+        shape = f"{xs[0].shape[0]}x[{'+'.join(str(x.shape[1]) + 'x' + str(x.shape[2]) for x in xs)}]x{p.Cin}->{p.cols} k3 s1"
+        CONV_TIMING.append(("wino_input_kernel", 0.0, ev[0], ev[1], shape, 0.0, "none", _stream()))
+        CONV_TIMING.append((label, 2.0 * px * p.cols * 9 * p.Cin, ev[1], ev[2], shape, 2.0 * total * 16 * p.cols * p.Cin, "f16x3", _stream()))
+    return outs
 
 
 def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
@@ -762,6 +840,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
                 shared = None
         if shared is not None:
             d.w_wino_cm = None  # consumers of a shared input take the two-launch form so that V exists once for all of them
+            if len(shared) > 3 and shared[1] is not None:  # (the tensor's tiles are a slice of a multi-level buffer: conv2d_levels)
+                d.wino_t_off, d.wino_t_total = shared[3]
         nbytes = _lib.lib().a3d_conv_workspace_bytes(C.byref(d))
         fused_wino = use_wino and nbytes == 0  # the one-launch Winograd kernel needs no V tensor
         if shared is not None and shared[1] is not None:

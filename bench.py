@@ -80,10 +80,11 @@ def rocprof_name(variant: str) -> str:
     m = re.match(r"conv_h2xs_kernel<(\d+)>$", v)  # (activation-stationary pointwise kernel: <Cin / 16, N groups, chunks per ring stage>)
     if m:
         return {"64": "conv_xs_kernel<4, 4, 1>", "128": "conv_xs_kernel<8, 2, 2>", "256": "conv_xs_kernel<16, 2, 2>"}[m.group(1)]
-    m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>( pp)?$", v)
-    if m:  # (<WM, F16, plane-split, ping-pong loop>: round 5's fp16x2 launches are all <4, true, false, 1>, the bf16x3 ones carry " pp")
+    m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>( levels\d)?$", v)
+    if m:  # (<WM, F16, plane-split, ping-pong loop, multi-level>: round 5's fp16x2 launches are <4, true, false, 1, false | true>)
         h2 = m.group(1) == "h2"
-        return f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if h2 else 'false'}, false, {1 if (h2 and m.group(2) == '4') or m.group(3) else 0}>"
+        return (f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if h2 else 'false'}, false, {1 if h2 and m.group(2) == '4' else 0}, "
+                f"{'true' if m.group(3) else 'false'}>")
     return v
 
 

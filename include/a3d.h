@@ -177,6 +177,11 @@ typedef struct a3d_conv_desc {
      * instead of the 1.26 GB one (64 frames), one launch less.  Equal to the two launches to fp32 rounding of the 576-term sum. */
     const float *dot_w;    /* [9][C] = the one-channel filter as [kh][kw][c], or NULL                                                */
     float *dot_y;          /* [B][9][2H][2W], or NULL                                                                                */
+    /* ---- Winograd layers, precision 3 (round 5): the layer's transformed tiles are a SLICE of a larger V buffer -- its tiles occupy
+     * [wino_t_off, wino_t_off + tiles) of `wino_t_total` tiles per (plane, chunk, h | l) run of `workspace`.  0 / 0 = the layer's own
+     * buffer.  Several layers that apply the SAME filter to different maps (the RPN head's 3x3 conv over the pyramid levels,
+     * SURVEY K5) then transform into one buffer and a3d_wino_gemm_levels multiplies all of it in ONE launch. */
+    int wino_t_off, wino_t_total;
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);
@@ -212,6 +217,12 @@ int a3d_absmax_rows(const float *x, float *out, int B, size_t n, void *stream);
  * x (+x2) -> d->workspace = V[16][tiles][Cin+Cin2]   (HBM-bound), then V, d->w_wino -> y   (MFMA-bound). */
 int a3d_wino_input_transform(const a3d_conv_desc *d, void *stream);
 int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
+/* ONE GEMM launch for n <= 5 Winograd layers (precision 3) that share filter (w_wino_x3, w_scale, scale, shift, act), channel counts and
+ * `workspace`, whose slices [wino_t_off, wino_t_off + tiles) are consecutive and fill wino_t_total: the shared-filter RPN conv over the
+ * pyramid levels (StandardRPNHead, planercnn.py:168) as one launch over the concatenated tiles, with a per-level table for the output
+ * maps, the per-image scales and the recorded maxima.  The partial rounds of the small levels vanish (p3-p6 at 64 frames: 5 + 2 + 1 + 1
+ * rounds of the chip -> 6.25) and every output element is computed exactly as by its own launch: bit-identical. */
+int a3d_wino_gemm_levels(const a3d_conv_desc *levels, int n, void *stream);
 /* The kernel instantiation the LAST conv launch of the calling thread dispatched, as it appears in a rocprofv3 kernel trace
  * ("conv_pw_kernel<2,2,16> 128x128 persistent", "wino_gemm_kernel<1,32>", ...); "" before the first launch.  For measurement
  * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules.

@@ -1332,3 +1332,35 @@ def test_seeded_fuzz_of_the_round4_kernels(ops):
     print(out["cases"])
     assert not out["failures"], out["failures"]
     assert min(out["cases"].values()) >= 3, out["cases"]
+
+
+@pytest.mark.parametrize("B", [5, 64])
+def test_shared_filter_conv_over_the_pyramid_levels_as_one_launch(ops, B):
+    """Round 5, SURVEY K5: the RPN head's 3x3 conv (StandardRPNHead, planercnn.py:168 -> detectron2) applies ONE filter to p2..p6.
+    ops.conv2d_levels transforms every level into its slice of one V buffer and runs ONE Winograd GEMM launch over the concatenated
+    tiles (a3d_wino_gemm_levels; a per-tile level table in the epilogue).  Outputs and recorded maxima equal the per-level launches
+    bit for bit -- at 64 frames (every level a whole number of 128-tile blocks) and at 5 frames (blocks that straddle levels and
+    images) -- and a layer that reads one level's slice afterwards (the depth head's lateral conv shares the transform) gets the
+    bits of its own launch too."""
+    if ops.DEFAULT_PRECISION != 3:
+        pytest.skip("the fp16x2 arithmetic's form")
+    torch.manual_seed(23)
+    sizes = [(120, 160), (60, 80), (30, 40), (15, 20), (8, 10)] if B <= 8 else [(60, 80), (30, 40), (15, 20), (8, 10)]  # (64 frames: p3-p6 keep the test light)
+    feats = [torch.randn(B, h, w, 256, device="cuda") * (1 + l) * torch.logspace(-1, 1, B, device="cuda").view(B, 1, 1, 1) for l, (h, w) in enumerate(sizes)]
+    pk = ops.pack_conv(torch.randn(256, 256, 3, 3) / 48, torch.randn(256) * 0.1, None, 1, 1, ops.ACT_RELU)
+    other = ops.pack_conv(torch.randn(128, 256, 3, 3) / 48, torch.randn(128) * 0.1, None, 1, 1, ops.ACT_LEAKY)
+    per_level = [ops.conv2d(f, pk) for f in feats]
+    other_ref = ops.conv2d(feats[1], other, wino=True)
+    with ops.share_wino_input(feats):
+        one = ops.conv2d_levels(feats, pk)
+        assert ops.last_conv_variant() == f"wino_gemm_h2w_kernel<4> levels{len(feats)}", ops.last_conv_variant()
+        co = ops.conv2d(feats[1], other, wino=True)  # reads level 1's slice of the shared buffer
+    for a, b in zip(one, per_level):
+        assert torch.equal(a, b) and torch.equal(a._a3d_amax, b._a3d_amax)
+    assert torch.equal(co, other_ref)
+    ops.WINO_LEVELS = False
+    try:
+        assert all(torch.equal(a, b) for a, b in zip(ops.conv2d_levels(feats, pk), per_level))
+        assert ops.last_conv_variant().startswith("wino_gemm_h2w_kernel<") and "levels" not in ops.last_conv_variant()
+    finally:
+        ops.WINO_LEVELS = True
