@@ -94,6 +94,11 @@ constexpr int xd_lds_bytes() { return XD_NST * (2 * XW_PX + 2 * XW_PW) * 2 + 2 *
 // fragment read of the chunk (a(c)[3], issued under block 2's MFMAs), after which the DMA of chunk c + 4 goes straight into the
 // stage of chunk c and has three iterations to land (fc1 streams its 3.2 GB of activations from HBM).  Same fragments, same term
 // order per output as the register-staged loop: bit-identical results (tests/test_gpu_parity.py).
+// (Round 5, built, bit-identical, measured and removed -- profiles/r05_x3w_pp_ab.txt: this kernel's plain fp16x2 loop in the Winograd GEMM's
+// PING-PONG form -- the workgroup's halves in antiphase, a memory phase (12 fragment reads, split + LDS stores of the next chunk, filter
+// DMA, global loads) alternating with 24 MFMAs back to back.  4-15 % SLOWER on all eight layers (fc1 4.445 | 4.073 ms, fc2 0.490 | 0.425,
+// p2 lateral 0.825 | 0.773, 6400-row head FC 2.187 | 2.013): here the activations pass through registers, and the hand-dealt loop below
+// already runs the split and the LDS stores in the MFMAs' shadows -- bunching them leaves the partner's 24 MFMAs too short a cover.)
 template <bool F16, bool PH4 = false, bool XD = false>
 __global__ __launch_bounds__(512, 1) void conv_x3w_kernel(const a3d_conv_desc d, const int M, const int ntiles, const int nblk) {
     static_assert(!XD || F16, "pre-split activations belong to the fp16x2 arithmetic");
