@@ -471,6 +471,10 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
     if AUDIT is not None and not AUDIT.busy and precision is None and x.dtype == torch.float32 and out_dtype is None and not p.phase:
         return AUDIT.conv2d(x, p, x2=x2, res=res, res_ups=res_ups, ups=ups, act=act, splitk=splitk, m_dev=m_dev, out=out, tune=tune, wino=wino, gate=gate)
     if x.dtype == torch.float16:
+        # (pre-split activations: ONE kernel form reads them -- nothing it cannot honour may be dropped silently)
+        if splitk != 1 or m_dev is not None or gate is not None or tune or out_dtype is not None or ups or dot is not None or wino or precision not in (None, 3):
+            raise RuntimeError("pre-split (float16) activations run the dual-DMA fp16x2 kernel only: splitk, m_dev, gate, tune, out_dtype, ups, dot, "
+                               "wino and any precision other than 3 are not available with them")
         return _conv2d_presplit(x, p, x2=x2, res=res, res_ups=res_ups, act=act, out=out)
     if out_dtype is not None or x.dtype == torch.bfloat16 or (res is not None and res.dtype == torch.bfloat16) or (gate is not None and gate.dtype == torch.bfloat16):
         return _conv2d_bf16_storage(x, p, res=res, res_ups=res_ups, act=act, out=out, gate=gate, precision=precision, out_dtype=out_dtype)
@@ -518,6 +522,11 @@ def _conv2d_blocks(x, p, nb, hw_out, *, x2, res, out, gate, m_dev, **kw):
 
 
 BF16_SPLITK = os.environ.get("A3D_BF16_SPLITK", "1") != "0"
+# Auto split-K sizes the number of reduction splits by M = B * Ho * Wo: the bf16 summation order then depends on the batch.  That is the
+# training step's business (DetectorTrainer.forward_backward turns it on for its launches; a training batch is one unit anyway) -- the
+# opt-in bf16 INFERENCE mode (A3D_PRECISION=1 / bench.py --precision bf16) keeps one launch per layer, so that a frame's result stays
+# independent of its batch in every mode and `conv2d`'s blocks-of-images form reproduces the single launch there too.
+BF16_SPLITK_AUTO = False
 # (tiles at most, workgroups aimed at, chunks per split at least, chunks at least, splits at most)
 _BF16_SK_CFG = tuple(int(v) for v in os.environ.get("A3D_BF16_SPLITK_CFG", "128,256,12,24,8").split(","))
 
@@ -746,7 +755,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         else:
             precision = 0
     d.precision = int(precision)
-    if (d.precision == 1 and splitk == 1 and not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or m_dev is not None or res_ups)
+    if (d.precision == 1 and splitk == 1 and BF16_SPLITK_AUTO and not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or m_dev is not None or res_ups)
             and p.Kpad == p.KH * p.KW * p.Cin and p.Cin % 32 == 0):
         splitk = _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)  # (bf16 arithmetic: small grids with long reductions)
         d.splitk = splitk

@@ -343,6 +343,13 @@ class DetectorTrainer:
                          samples: Optional[dict] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
         """frames_u8 [B,H,W,3] uint8 BGR on the device; per image gt_boxes [G,4] fp32 / gt_classes [G] int64 (CPU or device).
         Fills self.grads; returns ({loss name: 0-d device tensor}, aux with the sampled index sets)."""
+        saved, ops.BF16_SPLITK_AUTO = ops.BF16_SPLITK_AUTO, True  # (split-K by batch size: the training step's launches only, ops.py)
+        try:
+            return self._forward_backward(frames_u8, gt_boxes, gt_classes, samples)
+        finally:
+            ops.BF16_SPLITK_AUTO = saved
+
+    def _forward_backward(self, frames_u8, gt_boxes, gt_classes, samples):
         s, L, m = self.s, self.layers, self.model
         B, H, W, _ = frames_u8.shape
         self._prepare_filters()

@@ -1,6 +1,8 @@
 # Counters of wino_input_h2_kernel on the p2 layer (the transform runs at 4.6-4.8 TB/s and four store layouts tied
 # without anyone looking at its TCP / TCC counters).  Separate --pmc passes; sums over all XCDs / instances, last dispatch.
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+mkdir -p gpurun_out
 i=0
 for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
          "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum" "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WR_UNCACHED_32B_sum" "TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TCP_TCC_READ_REQ_LATENCY_sum" \

@@ -1,5 +1,6 @@
+import os
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from articulation3d_amd import ops
 torch.manual_seed(0)
 K, N, M = 50176, 1024, 6400

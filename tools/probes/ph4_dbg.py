@@ -1,5 +1,6 @@
+import os
 import sys, os, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from articulation3d_amd import ops
 for act in (ops.ACT_RELU, ops.ACT_NONE, ops.ACT_LEAKY):
   for (B,H,W,C1,C2,Cout) in [(3,13,42,128,0,64),(3,13,42,128,0,128),(3,13,42,64,0,64),(3,13,42,128,128,64),(2,24,40,128,0,64),(1,3,5,128,0,64)]:

@@ -5,7 +5,9 @@
 set -u
 TAG=${1:-r03}
 OUT=gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+mkdir -p gpurun_out
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points"
 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for MODE in fp16x2 bf16x3 fp32; do

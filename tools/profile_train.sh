@@ -5,7 +5,9 @@
 set -u
 TAG=${1:-r04}
 OUT=gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+mkdir -p gpurun_out
 python3 tools/train_bench.py --precision bf16 --batch 2 --cpu-baseline > $OUT/${TAG}_train_bench_b2.json 2> $OUT/${TAG}_train_bench_b2.err
 python3 tools/train_bench.py --precision bf16 --batch 16 > $OUT/${TAG}_train_bench_b16.json 2> $OUT/${TAG}_train_bench_b16.err
 python3 tools/train_bench.py --precision bf16x3 --batch 2 > $OUT/${TAG}_train_bench_x3_b2.json 2>/dev/null
