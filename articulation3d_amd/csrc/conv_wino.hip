@@ -677,12 +677,13 @@ constexpr int x3w_lds_bytes(int WM, int NP) { return x3w_stages(WM, NP) * x3w_bu
 // PS (plane-split, small problems): blockIdx.y = Winograd plane; the workgroup runs that plane's k loop only and stores the raw product
 // tile to a.M [16][T][Cout]; wino_fold_kernel then folds the 16 planes in the same order and applies the same epilogue.  A problem of
 // a few tile blocks otherwise occupies a few CUs for 16 x C/32 latency-bound iterations (a single 30x40 frame: 6 workgroups, 116 us).
-// ML (round 5): ONE launch over the tiles of several maps that share the filter (a3d_wino_gemm_levels; WinoArgs::lv): the loop is the same --
-// it walks tiles of the concatenated V --, the epilogue looks every tile's level up (output map, per-image scale, recorded maxima).
-template <int WM, bool F16 = false, bool PS = false, int PP = 0, bool ML = false>
+// The ping-pong form's epilogue is TABLE-DRIVEN (round 5; WinoArgs::lv): a launch may cover the tiles of several maps that share the filter
+// (a3d_wino_gemm_levels: the RPN conv over the pyramid levels; a single layer is a table of one) -- the loop walks the tiles of the
+// concatenated V, the epilogue looks every tile's map up (output tensor, per-image scale, recorded maxima).
+template <int WM, bool F16 = false, bool PS = false, int PP = 0>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
     static_assert(PP == 0 || (F16 && !PS && WM == 4), "ping-pong: the 512-thread fp16x2 form (two waves per SIMD)");
-    static_assert(!ML || (F16 && !PS), "multi-level launches: the fp16x2 form");
+    constexpr bool ML = PP > 0;
     constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
@@ -1276,7 +1277,11 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
             int l, tl;
             wino_level_of(a.lv, min(tb + pr, a.T - 1), l, tl);
             const int b = tl / (wino_level_sel(a.lv.Ty, l) * wino_level_sel(a.lv.Tx, l));
-            if (tb + pr < a.T) unx = 1.f / (0.25f * a3d_pow2_scale(wino_level_sel(a.lv.in_amax, l)[b]));  // (1 / wino_v_scale of the tile's image)
+            if (tb + pr < a.T) {  // 1 / wino_v_scale of the tile's image (a second source -- channel concat, single-map launches -- shares it)
+                float m = wino_level_sel(a.lv.in_amax, l)[b];
+                if (a.in_amax2) m = fmaxf(m, a.in_amax2[b]);
+                unx = 1.f / (0.25f * a3d_pow2_scale(m));
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
                 } else if (a.act == A3D_ACT_LEAKY) {
                     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.01f * v[k];
                 }
-                if (!ML && a.gate) {
+                if (a.gate) {  // (single-map launches only: a3d_wino_gemm_levels refuses a gate)
                     const f32x4 g = *reinterpret_cast<const f32x4 *>(a.gate + ooff);
                     for (int k = 0; k < 4; ++k) v[k] = g[k] > 0.f ? v[k] : 0.f;
                 }
@@ -1593,7 +1598,18 @@ static int wino_launch_gemm(const a3d_conv_desc *d, hipStream_t s) {
     a.abl = (int)a3d_dev_knob("A3D_WINO_ABL", 0);
     a.Toff = 0;
     a.Ttot = (int)T;
-    a.lv.n = 0;
+    a.lv.n = 1;  // (the ping-pong form's epilogue is table-driven: this layer's map is the table)
+    for (int k = 0; k < 5; ++k) {
+        a.lv.t0[k] = k == 0 ? 0 : (int)T;
+        a.lv.Ty[k] = Ty;
+        a.lv.Tx[k] = Tx;
+        a.lv.Hl[k] = Hl;
+        a.lv.Wl[k] = Wl;
+        a.lv.y[k] = d->y;
+        a.lv.in_amax[k] = d->in_amax;
+        a.lv.y_amax[k] = d->y_amax;
+    }
+    a.lv.t0[5] = (int)T;
     if (d->wino_t_total) {  // a slice of a shared V buffer: the fp16x2 forms only
         if (d->precision != 3 || d->wino_t_off < 0 || (size_t)d->wino_t_off + T > (size_t)d->wino_t_total) return A3D_ERR_ARG;
         a.Toff = d->wino_t_off;
@@ -1774,13 +1790,13 @@ extern "C" int a3d_wino_gemm_levels(const a3d_conv_desc *lv, int n, void *stream
     a3d_begin();
     static a3d_attr_once attr_ml;
     if (attr_ml.needed()) {
-        if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)wino_gemm_x3w_kernel<4, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, x3w_lds_bytes(4, 2)) != hipSuccess)
             return A3D_ERR_LAUNCH;
         attr_ml.mark();
     }
     const int nt = (a.Cout + X3W_BN - 1) / X3W_BN, m4 = (int)((t + 127) / 128);
     a3d_note_variant("wino_gemm_h2w_kernel<4> levels%d", n);
-    hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true, false, 1, true>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), (hipStream_t)stream, a, nt, m4 * nt);
+    hipLaunchKernelGGL((wino_gemm_x3w_kernel<4, true, false, 1>), dim3(m4 * nt), dim3(512), x3w_lds_bytes(4, 2), (hipStream_t)stream, a, nt, m4 * nt);
     return a3d_check_launch();
 }
 

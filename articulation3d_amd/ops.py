@@ -412,7 +412,7 @@ def conv2d_levels(xs: Sequence[torch.Tensor], p: PackedConv) -> list:
     global _LAST_PRECISION
     _LAST_PRECISION = 3
     # measurement (bench.py): event pairs around the transforms and around the one GEMM launch, under the same rule as _conv2d_launch
-    label = f"wino_gemm_h2w_kernel<4> levels{len(xs)}"
+    label = "wino_gemm_h2w_kernel<4>"  # (the same kernel as a single map's launch -- the table in its epilogue has five rows instead of one)
     timing = CONV_TIMING is not None and (CONV_TIMING_ONLY is None or label in CONV_TIMING_ONLY or "wino_input_kernel" in CONV_TIMING_ONLY)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
     if timing:

@@ -80,11 +80,10 @@ def rocprof_name(variant: str) -> str:
     m = re.match(r"conv_h2xs_kernel<(\d+)>$", v)  # (activation-stationary pointwise kernel: <Cin / 16, N groups, chunks per ring stage>)
     if m:
         return {"64": "conv_xs_kernel<4, 4, 1>", "128": "conv_xs_kernel<8, 2, 2>", "256": "conv_xs_kernel<16, 2, 2>"}[m.group(1)]
-    m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>( levels\d)?$", v)
-    if m:  # (<WM, F16, plane-split, ping-pong loop, multi-level>: round 5's fp16x2 launches are <4, true, false, 1, false | true>)
+    m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>$", v)
+    if m:  # (<WM, F16, plane-split, ping-pong loop>: round 5's fp16x2 launches are all <4, true, false, 1>, one map or several)
         h2 = m.group(1) == "h2"
-        return (f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if h2 else 'false'}, false, {1 if h2 and m.group(2) == '4' else 0}, "
-                f"{'true' if m.group(3) else 'false'}>")
+        return f"wino_gemm_x3w_kernel<{m.group(2)}, {'true' if h2 else 'false'}, false, {1 if h2 and m.group(2) == '4' else 0}>"
     return v
 
 
@@ -528,7 +527,7 @@ def main():
         roofline["main_stream"] = {"launches": mn, "avg_launch_ms": round(1e3 * ms_ / mn, 4), "achieved": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12, 2),
                                    "frac": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12 / peak, 4),
                                    "note": "the same kernel over its launches on the trunk's stream only (side-stream launches share the chip and read long)"}
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (4, 3, 2)) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (5, 4, 3, 2)) if os.path.exists(q)), "")
     if tpath:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
         rname = rocprof_name(dname)

@@ -338,7 +338,7 @@ def test_bench_labels_map_onto_the_kernels_of_the_committed_profile():
         squeeze = lambda s: re.sub(r"(conv_x3w_kernel<\w+,\w+),false>", r"\1>", re.sub(r"\s+", "", s))
     if rnd in ("r03", "r04"):  # (round 5 added the Winograd GEMM's fourth template argument, the ping-pong loop)
         base = squeeze
-        squeeze = lambda s: re.sub(r"(wino_gemm_x3w_kernel<\d,\w+,\w+),[01](,\w+)?>", r"\1>", base(s))
+        squeeze = lambda s: re.sub(r"(wino_gemm_x3w_kernel<\d,\w+,\w+),[01]>", r"\1>", base(s))
     names = [squeeze(r["Name"]) for r in rows]
     for label in line["roofline"]["all_conv_kernels"]:
         if label.endswith("wino_fold_kernel"):

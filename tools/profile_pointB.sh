@@ -9,7 +9,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-operating-points --score-thresh 0.0"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-alt-modes --no-operating-points --no-train-leg --score-thresh 0.0"
 CMD="python3 bench.py $ARGS"
 rm -rf $OUT/${TAG}_prof_pointB
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_pointB --output-format csv -- python3 bench.py $ARGS > $OUT/${TAG}_bench_prof_pointB.json 2> $OUT/${TAG}_prof_pointB.err

@@ -3,12 +3,12 @@
 # passes), matrix-pipe occupancy.  Summaries land in gpurun_out/ (copy the ones to be judged into profiles/).
 #   bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 OUT=gpurun_out
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 mkdir -p gpurun_out
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-alt-modes --no-operating-points --no-train-leg"
 python3 bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 for MODE in fp16x2 bf16x3 fp32; do
   SUF=""; [ $MODE = fp32 ] && SUF="_fp32"; [ $MODE = bf16x3 ] && SUF="_bf16x3"

@@ -19,7 +19,7 @@ from collections import defaultdict
 
 def main():
     d, bench_json, steps, warmup, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    command = sys.argv[6] if len(sys.argv) > 6 else (f"python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes --no-operating-points")
+    command = sys.argv[6] if len(sys.argv) > 6 else (f"python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-alt-modes --no-operating-points --no-train-leg")
     stats = max(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     trace = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
