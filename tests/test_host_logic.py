@@ -341,7 +341,7 @@ def test_bench_labels_map_onto_the_kernels_of_the_committed_profile():
         squeeze = lambda s: re.sub(r"(wino_gemm_x3w_kernel<\d,\w+,\w+),[01]>", r"\1>", base(s))
     names = [squeeze(r["Name"]) for r in rows]
     for label in line["roofline"]["all_conv_kernels"]:
-        if label.endswith("wino_fold_kernel"):
+        if label.endswith("wino_fold_kernel") and rnd in ("r03", "r04"):  # (those rounds also launched the 64-tile form unsplit)
             label = label.split(" planes")[0]
         want = squeeze(bench.rocprof_name(label))
         assert any(want in n for n in names), (label, want)
