@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
         ("dot_w", fptr),
         ("dot_y", fptr),
         ("wino_t_off", C.c_int), ("wino_t_total", C.c_int),
+        ("w_bf16", fptr),
     ]
 
 

@@ -26,6 +26,7 @@ SOURCES = {
     "conv_wino_fused.hip": [],
     "conv_pw.hip": [],
     "conv_bf16.hip": [],
+    "conv_bf16w.hip": [],
     "conv_bf16x3.hip": [],
     "conv_bf16x3_wide.hip": [],
     "conv_xs_h2.hip": [],

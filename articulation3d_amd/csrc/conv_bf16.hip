@@ -297,6 +297,10 @@ void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
 }  // namespace
 
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
+    {
+        const int rw = a3d_conv_launch_bf16w(d, s);  // large launches with a bf16 filter: both operands by DMA, 256-pixel tiles (the same bits)
+        if (rw != A3D_ERR_UNSUPPORTED) return rw;
+    }
     if (d->stem || d->ups || d->phase || d->pixshuf || d->x2 || d->Cin2 || d->splitk < 1 || d->m_dev) return A3D_ERR_UNSUPPORTED;
     if (d->splitk > 1 && (!d->workspace || d->res_ups || d->splitk > d->Kpad / 32)) return A3D_ERR_ARG;  // (split-K: plain output rows only)
     if (d->io_bf16 & ~15) return A3D_ERR_ARG;

@@ -104,6 +104,7 @@ class PackedConv:
     w_x3: Optional[torch.Tensor] = None  # [Kpad/16, 3, cols, 16] bf16 planes of w (a3d_conv_desc.w_x3), made at the first such use
     w_wino_h2: Optional[torch.Tensor] = None  # [16, Cin/32, 2, cols, 32] fp16 planes of w_wino * its scale (precision 3)
     w_h2: Optional[torch.Tensor] = None  # [Kpad/16, 2, cols, 16] fp16 planes of w * w_scale (a3d_conv_desc.w_x3 at precision 3)
+    w_b16: Optional[torch.Tensor] = None  # [cols, Kpad] bf16 = w rounded to nearest even (a3d_conv_desc.w_bf16; the trainer refreshes it once per step)
     pin_precision: Optional[int] = None  # 2: this layer runs bf16x3 (exact splits, no window) whatever the mode -- set by the precision audit
     name: str = ""  # owner module's qualified name, when known (audit reports)
 
@@ -477,7 +478,7 @@ def conv2d(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor] = None,
                                "wino and any precision other than 3 are not available with them")
         return _conv2d_presplit(x, p, x2=x2, res=res, res_ups=res_ups, act=act, out=out)
     if out_dtype is not None or x.dtype == torch.bfloat16 or (res is not None and res.dtype == torch.bfloat16) or (gate is not None and gate.dtype == torch.bfloat16):
-        return _conv2d_bf16_storage(x, p, res=res, res_ups=res_ups, act=act, out=out, gate=gate, precision=precision, out_dtype=out_dtype)
+        return _conv2d_bf16_storage(x, p, res=res, res_ups=res_ups, act=act, out=out, gate=gate, precision=precision, out_dtype=out_dtype, tune=tune)
     _req(x)
     B = x.shape[0]
     if B > 1:
@@ -543,7 +544,7 @@ def _bf16_splitk(M: int, cols: int, Kpad: int) -> int:
     return int(max(1, min(cap, nk // per, target // tiles)))
 
 
-def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, precision, out_dtype) -> torch.Tensor:
+def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, precision, out_dtype, tune=0) -> torch.Tensor:
     """The training step's bf16 (autocast) arithmetic with tensors stored as bf16 where the caller says so: plain conv / linear
     layers only (no stem, upsampling, concat, split-K, Winograd), precision 1."""
     if precision != 1:
@@ -572,7 +573,10 @@ def _conv2d_bf16_storage(x, p: PackedConv, *, res, res_ups, act, out, gate, prec
     d.precision = 1
     b16 = lambda t: t is not None and t.dtype == torch.bfloat16
     d.io_bf16 = (1 if b16(x) else 0) | (2 if b16(out) else 0) | (4 if b16(res) else 0) | (8 if b16(gate) else 0)
-    sk = 1 if res_ups else _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)
+    d.tune = int(tune)
+    if p.w_b16 is not None:  # the filter as bf16: large launches take both operands by LDS-DMA (csrc/conv_bf16w.hip; the same bits)
+        d.w_bf16 = p.w_b16.data_ptr()
+    sk = 1 if (res_ups or not BF16_SPLITK_AUTO) else _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)  # (split-K by batch size: inside the training step only)
     if sk > 1:
         d.splitk = sk
         ws = torch.empty(sk * B * Ho * Wo * p.cols, device=x.device, dtype=torch.float32)
@@ -755,6 +759,8 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         else:
             precision = 0
     d.precision = int(precision)
+    if d.precision == 1 and p.w_b16 is not None:
+        d.w_bf16 = p.w_b16.data_ptr()
     if (d.precision == 1 and splitk == 1 and BF16_SPLITK_AUTO and not (p.stem or ups or p.phase or p.pixshuf or x2 is not None or m_dev is not None or res_ups)
             and p.Kpad == p.KH * p.KW * p.Cin and p.Cin % 32 == 0):
         splitk = _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)  # (bf16 arithmetic: small grids with long reductions)

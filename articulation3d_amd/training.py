@@ -105,6 +105,8 @@ class _Layer:
     b: Optional[torch.Tensor] = None  # [rows] or None
     db: Optional[torch.Tensor] = None
     wt: torch.Tensor = None  # transposed filter scratch [cin, k*k*rows]
+    wb: Optional[torch.Tensor] = None   # bf16 step: w rounded to bf16 (view of the flat bf16 copy of the parameters, refreshed once per step)
+    wtb: Optional[torch.Tensor] = None  # ... and the data-gradient filter
     U: Optional[torch.Tensor] = None   # Winograd-domain forward filter (3x3 only)
     Ut: Optional[torch.Tensor] = None  # Winograd-domain data-gradient filter
     U3: Optional[torch.Tensor] = None   # precision "bf16x3": U / Ut split into three bf16 planes, refreshed once per step by
@@ -120,12 +122,14 @@ class _Layer:
         if self.U is not None:
             p.w_wino = self.U
             p.w_wino_x3 = self.U3
+        p.w_b16 = self.wb
         return p
 
     def bwd(self) -> PackedConv:
         """The data-gradient conv: input channels = forward rows, stride 1 (stride-2 layers scatter afterwards)."""
         K = self.k * self.k * self.rows
         p = PackedConv(self.wt, None, None, self.k, self.k, 1, self.k - 1 - self.pad, self.rows, self.cin, K, ACT_NONE)
+        p.w_b16 = self.wtb
         if self.Ut is not None:
             p.w_wino = self.Ut
             p.w_wino_x3 = self.Ut3
@@ -220,11 +224,19 @@ class DetectorTrainer:
         nu = sum(16 * ly.rows * ly.cin for ly in L.values() if ly.k == 3)
         self._U = torch.empty(nu, device=self.dev)
         self._Ut = torch.empty(nu, device=self.dev)
+        # bf16 step: the parameters and the data-gradient filters ALSO as bf16 (rounded once per step in _prepare_filters: two launches), in
+        # the same flat layouts -- what csrc/conv_bf16w.hip DMAs (every filter starts at a multiple of 8 elements: 16-byte aligned)
+        self._p16 = torch.empty(n, device=self.dev, dtype=torch.bfloat16) if self.prec == 1 else None
+        self._wt16 = torch.empty(nw, device=self.dev, dtype=torch.bfloat16) if self.prec == 1 else None
         off = woff = uoff = 0
         for ly in L.values():
             nwl = ly.rows * ly.k * ly.k * ly.cin
             ly.w = self.params[off:off + nwl].view(ly.rows, -1)
             ly.dw = self.grads[off:off + nwl].view(ly.rows, -1)
+            if self._p16 is not None:
+                assert off % 8 == 0 and woff % 8 == 0
+                ly.wb = self._p16[off:off + nwl].view(ly.rows, -1)
+                ly.wtb = self._wt16[woff:woff + nwl].view(ly.cin, -1)
             off += nwl
             if has_bias(ly):
                 ly.b, ly.db = self.params[off:off + ly.rows], self.grads[off:off + ly.rows]
@@ -304,9 +316,14 @@ class DetectorTrainer:
             if getattr(self, "_tbatch", None) is None:
                 self._tbatch = T.TransposeBatch([(ly.w, ly.scale, ly.wt, ly.rows, ly.k, ly.k, ly.cin) for ly in self.layers.values()], self.dev)
             self._tbatch.run()
-        for ly in self.layers.values():
-            if not BATCHED_LAUNCHES:
+        if not BATCHED_LAUNCHES:
+            for ly in self.layers.values():
                 T.weight_transpose(ly.w, ly.wt, ly.rows, ly.k, ly.k, ly.cin, scale=ly.scale)
+        if self._p16 is not None:  # (bf16 step: both filter sets rounded to bf16, nearest even -- what the kernels' loaders round to)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().a3d_f32_to_bf16_scaled(self.params.data_ptr(), self._p16.data_ptr(), self.params.numel(), 1.0, st), "a3d_f32_to_bf16_scaled")
+            _lib.check(_lib.lib().a3d_f32_to_bf16_scaled(self._wt.data_ptr(), self._wt16.data_ptr(), self._wt.numel(), 1.0, st), "a3d_f32_to_bf16_scaled")
+        for ly in self.layers.values():
             if ly.k == 3 and self.prec != 1:  # (the bf16 step runs its 3x3 layers as direct convolutions)
                 T.wino_weight_transform(ly.w, ly.U, ly.rows, ly.cin)
                 T.wino_weight_transform(ly.wt, ly.Ut, ly.cin, ly.rows)

@@ -182,6 +182,11 @@ typedef struct a3d_conv_desc {
      * buffer.  Several layers that apply the SAME filter to different maps (the RPN head's 3x3 conv over the pyramid levels,
      * SURVEY K5) then transform into one buffer and a3d_wino_gemm_levels multiplies all of it in ONE launch. */
     int wino_t_off, wino_t_total;
+    /* ---- precision 1 (round 5): the filter ALSO as bf16, [Cout][Kpad] in w's layout, rounded to nearest even from w (the training step keeps
+     * fp32 master weights and rounds its flat parameter buffer once per step: a3d_f32_to_bf16_scaled).  With it large launches run the
+     * kernel that moves both operands global -> LDS by LDS-DMA on 256-pixel tiles (csrc/conv_bf16w.hip); the products are those of the
+     * kernel that rounds w on the fly: bit-identical results.  NULL: that kernel. */
+    const void *w_bf16;
 } a3d_conv_desc;
 
 size_t a3d_conv_workspace_bytes(const a3d_conv_desc *d);

@@ -859,3 +859,38 @@ def test_roi_align_backward_gather_at_the_training_step_size(T):
     den = sum(float(q.double().pow(2).sum()) for q in sc) ** 0.5
     assert num / den < 1e-6, num / den
     assert all(bool(torch.isfinite(p).all()) for p in a) and den > 0
+
+
+@pytest.mark.parametrize("case", [(4, 60, 80, 256, 256, 3, 1, "bf16", "f32", False),   # FPN output conv: bf16-stored lateral sums in, fp32 pyramid out
+                                  (4, 60, 80, 256, 256, 3, 1, "f32", "bf16", False),   # RPN conv: fp32 pyramid in (converted on the fragment), bf16 out
+                                  (3, 61, 79, 128, 128, 3, 1, "bf16", "bf16", False),  # ragged pixel tile, one 128-channel tile
+                                  (6, 30, 40, 1024, 256, 1, 1, "bf16", "bf16", True),  # deep 1x1 + residual
+                                  (2, 60, 80, 256, 384, 3, 2, "bf16", "bf16", False),  # strided, ragged channel tile
+                                  (1, 1, 700, 12544, 1024, 1, 1, "bf16", "bf16", False)],  # fc1 rows
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_bf16_dma_kernel_equals_the_register_staged_one_bit_for_bit(ops, case):
+    """Round 5: conv_bf16w_kernel (csrc/conv_bf16w.hip) -- the training step's bf16 launches with BOTH operands by LDS-DMA (the filter from
+    the trainer's per-step bf16 copy, a3d_conv_desc.w_bf16), 256-pixel tiles, ping-pong halves -- against conv_bf16_kernel, which rounds
+    the fp32 filter on the fly: the same rounded operands, the same chunk and step order -> equal bits, for bf16- and fp32-stored
+    activations and outputs, with residual and the ReLU-backward gate, 3x3 taps in the zero padding, strided and ragged tiles."""
+    B, H, W, Cin, Cout, k, st, xs, os_, has_res = case
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}
+    torch.manual_seed(31)
+    x = torch.randn(B, H, W, Cin, device="cuda").to(dt[xs])
+    pk = ops.pack_conv(torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5), torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+    Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+    res = torch.randn(B, Ho, Wo, Cout, device="cuda").to(dt[os_]) if has_res else None
+    gate = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
+    old = ops.conv2d(x, pk, res=res, precision=1, out_dtype=dt[os_])
+    assert ops.last_conv_variant().startswith("conv_bf16_kernel"), ops.last_conv_variant()
+    pk.w_b16 = pk.w.to(torch.bfloat16)  # (the trainer's per-step copy: a3d_f32_to_bf16_scaled rounds like torch, test_bf16_gradient_payload_casts_equal_torchs)
+    for tune in (30, 31):
+        new = ops.conv2d(x, pk, res=res, precision=1, out_dtype=dt[os_], tune=tune)
+        assert ops.last_conv_variant() == f"conv_bf16w_kernel<{2 if tune == 30 else 4}>", ops.last_conv_variant()
+        assert new.dtype == old.dtype and torch.equal(new, old), (tune, float((new.float() - old.float()).abs().max()))
+    if os_ == "bf16":  # the data-gradient form: gate + no activation
+        pk.w_b16 = None
+        og = ops.conv2d(x, pk, gate=gate, precision=1, act=ops.ACT_NONE, out_dtype=torch.bfloat16)
+        pk.w_b16 = pk.w.to(torch.bfloat16)
+        ng = ops.conv2d(x, pk, gate=gate, precision=1, act=ops.ACT_NONE, out_dtype=torch.bfloat16, tune=30)
+        assert ops.last_conv_variant() == "conv_bf16w_kernel<2>" and torch.equal(ng, og)

@@ -180,8 +180,8 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sid, cls in _lib.STRUCT_IDS.items():
         assert lib.a3d_struct_size(sid) == ctypes.sizeof(cls), cls.__name__
     # 8 ptrs, 19 ints, pad, m_dev, tune + phase, w_wino, gate, precision + pad, w_wino_x3, w_wino_cm, w_x3, in_amax, in_amax2, y_amax, w_scale + pad,
-    # wino_m, io_bf16 + pad, x_h2, x2_h2, dot_w, dot_y, wino_t_off + wino_t_total
-    assert ctypes.sizeof(_lib.ConvDesc) == 8 * 8 + 19 * 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    # wino_m, io_bf16 + pad, x_h2, x2_h2, dot_w, dot_y, wino_t_off + wino_t_total, w_bf16
+    assert ctypes.sizeof(_lib.ConvDesc) == 8 * 8 + 19 * 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
