@@ -41,6 +41,7 @@ FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
 # One launch for all data-gradient filters and one for all weight-gradient slice reductions of a step instead of one per layer (round 4;
 # "0": the per-layer launches -- the same bits either way, tests/test_gpu_training.py).
 BATCHED_LAUNCHES = os.environ.get("A3D_TRAIN_BATCHED", "1") != "0"
+WGRAD_SIDE_STREAM = os.environ.get("A3D_TRAIN_WGRAD_STREAM", "1") != "0"  # weight gradients on a side stream beside the data-gradient chain (same bits)
 RES_STAGES = (("res3", 4, 128, 512), ("res4", 6, 256, 1024), ("res5", 3, 512, 2048))  # name, blocks, mid, out
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
 
@@ -213,6 +214,7 @@ class DetectorTrainer:
         K = self.s.num_classes
         L[bp + "pred"] = _Layer(bp + "pred", 32, 1024, 1, 1, 0, ACT_NONE, sources=[(bp + "cls_score", 0, K + 1), (bp + "bbox_pred", K + 1, 4 * K)])
         self.layers = L
+        self._wg_stream = torch.cuda.Stream(device=self.dev) if WGRAD_SIDE_STREAM else None
         has_bias = lambda ly: ly.scale is None
         n = sum(ly.rows * ly.k * ly.k * ly.cin + (ly.rows if has_bias(ly) else 0) for ly in L.values())
         n = (n + 3) // 4 * 4
@@ -344,6 +346,24 @@ class DetectorTrainer:
         return ops.conv2d(x, pk, precision=self.prec, **kw)
 
     def _wgrad(self, ly: _Layer, x, dy, accumulate=False):
+        """A layer's weight (and bias) gradient.  It hangs OFF the backward pass's critical chain -- it needs the layer's input and the
+        gradient of its output, and nothing waits for it before the optimiser step -- so (round 5) it runs on a side stream beside the
+        data-gradient chain: at the reference's 2 images per GPU every launch of the step is a fraction of a round of the chip, and the
+        ~60 weight-gradient launches hide under the chain.  Same kernels in the same order on ONE side stream (the RPN head's five
+        accumulating launches stay ordered): the step's gradients keep their bits."""
+        side = self._wg_stream
+        if side is None:
+            return self._wgrad_now(ly, x, dy, accumulate)
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        x.record_stream(side)
+        dy.record_stream(side)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            self._wgrad_now(ly, x, dy, accumulate)
+
+    def _wgrad_now(self, ly: _Layer, x, dy, accumulate=False):
         # The slice reductions of the step's weight gradients are folded in ONE launch at the end of the backward pass (self._defer.flush()
         # in forward_backward): 63 reduce launches of ~17 us each were 11 % of the step at the reference's 2 images per GPU.  Layers whose
         # gradient accumulates over several launches (the RPN head over its five levels) keep the per-launch reduce, which orders them.
@@ -522,6 +542,8 @@ class DetectorTrainer:
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
                     g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
+        if self._wg_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)  # every weight gradient has been launched and is waited for here
         if getattr(self, "_defer", None) is not None:
             self._defer.flush()  # every parked weight gradient: one reduce launch
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
