@@ -643,8 +643,8 @@ def main():
         del model, out
         torch.cuda.empty_cache()
         legs = {}
-        for tb, tsteps in ((2, 10), (16, 6)):
-            r = train_leg(dev, tb, tsteps, 3, precision="bf16", cpu_baseline=(world == 1 and not args.no_cpu_baseline), rank=rank, world=world,
+        for tb, tsteps in ((2, 10), (16, 10)):
+            r = train_leg(dev, tb, tsteps, 5, precision="bf16", cpu_baseline=(world == 1 and not args.no_cpu_baseline), rank=rank, world=world,
                           dist=dist if use_dist else None)
             roof = r["roofline"]
             legs[f"images_per_gpu_{tb}"] = {

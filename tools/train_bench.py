@@ -75,10 +75,14 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
     from articulation3d_amd import ops
     from bench import PIPE_FLOPS_PER_FMA, PIPE_PEAK, dominant_roofline, kernel_sums
 
+    # The instrumented step runs its weight gradients on the main stream (the timed steps above keep them on the side stream): an event
+    # bracket then times one launch alone, not the span it shares the GPU with the other stream.
+    side, tr._wg_stream = tr._wg_stream, None
     ops.CONV_TIMING = []
     tr.step(frames, gtb, gtc)
     barrier()
     events, ops.CONV_TIMING = ops.CONV_TIMING, None
+    tr._wg_stream = side
     if layers and rank == 0:
         for name, fl, a, b, shape, ex, pipe, _st in events:
             ms = a.elapsed_time(b)
