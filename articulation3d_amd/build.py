@@ -27,6 +27,7 @@ SOURCES = {
     "conv_pw.hip": [],
     "conv_bf16.hip": [],
     "conv_bf16w.hip": [],
+    "conv_bf16xs.hip": [],
     "conv_bf16x3.hip": [],
     "conv_bf16x3_wide.hip": [],
     "conv_xs_h2.hip": [],

@@ -222,27 +222,32 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
+        // Residual AND gate quads of the whole output row are requested before its first store (round 5): y / res / gate may alias, so the
+        // compiler keeps every load in program order with the stores -- a gate read in front of each store was one memory round trip per
+        // quad, and the gated launches (every data gradient of the step) took up to twice the time of their ungated twins.
+        const bool has_gate = d.io_bf16 && d.gate != nullptr;
+        f32x4 rv[TN][4], gv[TN][4];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                if (has_res) rv[ni][rg] = bf_read4(d.res, res_row * (size_t)d.Cout + min(n, d.Cout - 4), rb);
+                if (has_gate) gv[ni][rg] = bf_read4(d.gate, (size_t)m * d.Cout + min(n, d.Cout - 4), gb);
+            }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
-            f32x4 rv[4];
-            if (has_res) {
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
-                    rv[rg] = bf_read4(d.res, res_row * (size_t)d.Cout + min(n, d.Cout - 4), rb);
-                }
-            }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
                 const int n = n0 + nl;
                 if (n >= d.Cout) continue;
                 f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
-                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
+                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[ni][rg]);
                 if (d.io_bf16) {  // (plain output layout only: the launcher refuses pixshuf / phase with bf16 storage)
                     const size_t o = (size_t)m * d.Cout + n;
-                    if (d.gate) {
-                        const f32x4 g = bf_read4(d.gate, o, gb);
+                    if (has_gate) {
+                        const f32x4 g = gv[ni][rg];
                         for (int i = 0; i < 4; ++i) v[i] = g[i] > 0.f ? v[i] : 0.f;
                     }
                     bf_write4(d.y, o, v, yb);
@@ -298,6 +303,8 @@ void launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
 
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s) {
     {
+        const int rx = a3d_conv_launch_bf16xs(d, s);  // HBM-bound pointwise layers: activations stationary in registers (the same bits)
+        if (rx != A3D_ERR_UNSUPPORTED) return rx;
         const int rw = a3d_conv_launch_bf16w(d, s);  // large launches with a bf16 filter: both operands by DMA, 256-pixel tiles (the same bits)
         if (rw != A3D_ERR_UNSUPPORTED) return rw;
     }

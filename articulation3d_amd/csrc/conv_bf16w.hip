@@ -224,32 +224,39 @@ __global__ __launch_bounds__(512, 2) void conv_bf16w_kernel(const a3d_conv_desc 
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
+        // (residual and gate quads of two 32-channel groups at a time in front of their stores: conv_bf16.hip's epilogue)
+        const bool has_gate = d.io_bf16 && d.gate != nullptr;
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            f32x4 rv[4];
-            if (has_res) {
+        for (int np = 0; np < TN; np += 2) {
+            f32x4 rv[2][4], gv[2][4];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int n = n0 + (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
-                    rv[rg] = bw_read4(d.res, res_row * (size_t)d.Cout + min(n, d.Cout - 4), rb);
+                    const int n = n0 + (wn * TN + np + nj) * 32 + rg * 8 + (lane >> 5) * 4;
+                    if (has_res) rv[nj][rg] = bw_read4(d.res, res_row * (size_t)d.Cout + min(n, d.Cout - 4), rb);
+                    if (has_gate) gv[nj][rg] = bw_read4(d.gate, (size_t)m * d.Cout + min(n, d.Cout - 4), gb);
                 }
-            }
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
-                const int n = n0 + nl;
-                if (n >= d.Cout) continue;
-                f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
-                v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[rg]);
-                if (d.io_bf16) {
-                    const size_t o = (size_t)m * d.Cout + n;
-                    if (d.gate) {
-                        const f32x4 g = bw_read4(d.gate, o, gb);
-                        for (int i = 0; i < 4; ++i) v[i] = g[i] > 0.f ? v[i] : 0.f;
+            for (int nj = 0; nj < 2; ++nj) {
+                const int ni = np + nj;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int nl = (wn * TN + ni) * 32 + rg * 8 + (lane >> 5) * 4;
+                    const int n = n0 + nl;
+                    if (n >= d.Cout) continue;
+                    f32x4 v = {acc[ni][mi][rg * 4 + 0], acc[ni][mi][rg * 4 + 1], acc[ni][mi][rg * 4 + 2], acc[ni][mi][rg * 4 + 3]};
+                    v = a3d_epilogue_math(d, v, *reinterpret_cast<const f32x4 *>(ss + nl), *reinterpret_cast<const f32x4 *>(ss + BN + nl), has_res, rv[nj][rg]);
+                    if (d.io_bf16) {
+                        const size_t o = (size_t)m * d.Cout + n;
+                        if (has_gate) {
+                            const f32x4 g = gv[nj][rg];
+                            for (int i = 0; i < 4; ++i) v[i] = g[i] > 0.f ? v[i] : 0.f;
+                        }
+                        bw_write4(d.y, o, v, yb);
+                    } else {
+                        store_out(d, v, m, n, b, oh, ow);
                     }
-                    bw_write4(d.y, o, v, yb);
-                } else {
-                    store_out(d, v, m, n, b, oh, ow);
                 }
             }
         }

@@ -143,6 +143,8 @@ int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);
 int a3d_conv_launch_bf16(const a3d_conv_desc *d, hipStream_t s);
 // its large-launch form with both operands by LDS-DMA (conv_bf16w.hip; needs a3d_conv_desc.w_bf16); A3D_ERR_UNSUPPORTED -> the kernel above
 int a3d_conv_launch_bf16w(const a3d_conv_desc *d, hipStream_t s);
+// its pointwise form with the activations stationary in registers (conv_bf16xs.hip; needs a3d_conv_desc.w_bf16); A3D_ERR_UNSUPPORTED -> the kernels above
+int a3d_conv_launch_bf16xs(const a3d_conv_desc *d, hipStream_t s);
 // fp32-grade 3-way bf16 split on the bf16 matrix pipe (conv_bf16x3.hip), selected by a3d_conv_desc.precision == 2.
 int a3d_conv_launch_bf16x3(const a3d_conv_desc *d, hipStream_t s);
 // its wide form (conv_bf16x3_wide.hip: 256 x 256 tiles, pre-split weights by LDS-DMA); A3D_ERR_UNSUPPORTED -> the kernel above

@@ -101,6 +101,9 @@ typedef struct a3d_conv_desc {
                          the two forms reduce in different orders: equal to fp32 rounding, not bit for bit); Winograd layers: 23 = the
                          lockstep loop of the 128-tile fp16x2 GEMM instead of its ping-pong loop, 24 = 64-tile blocks (two workgroups per
                          CU), 25 (precision 2) = 128-tile blocks whatever the problem size -- all the same bits (A/B runs, equality tests);
+                         precision 1 with w_bf16: 30 / 31 = the LDS-DMA kernel with 128- / 256-channel tiles whatever the size, 32 = never it;
+                         33 / 34 = always / never the activation-stationary pointwise kernel (csrc/conv_bf16xs.hip) on a 1x1 layer it can
+                         run (the same bits);
                          >= 100: explicit tile variant.
                          `tune` is the ONLY way to choose a variant: the library reads no environment variable and has no process-global
                          switch (developer builds with -DA3D_ABLATIONS excepted, see csrc/a3d_common.h). */
@@ -185,7 +188,9 @@ typedef struct a3d_conv_desc {
     /* ---- precision 1 (round 5): the filter ALSO as bf16, [Cout][Kpad] in w's layout, rounded to nearest even from w (the training step keeps
      * fp32 master weights and rounds its flat parameter buffer once per step: a3d_f32_to_bf16_scaled).  With it large launches run the
      * kernel that moves both operands global -> LDS by LDS-DMA on 256-pixel tiles (csrc/conv_bf16w.hip); the products are those of the
-     * kernel that rounds w on the fly: bit-identical results.  NULL: that kernel. */
+     * kernel that rounds w on the fly: bit-identical results.  NULL: that kernel.  HBM-bound 1x1 layers (Cin 32 / 128 / 256 / 512, residual and
+     * gate stored bf16 or absent) run csrc/conv_bf16xs.hip with it: a wave's 32 pixels stay in registers as MFMA fragments while the
+     * workgroup walks every output channel -- again the same bits. */
     const void *w_bf16;
 } a3d_conv_desc;
 

@@ -894,3 +894,34 @@ def test_bf16_dma_kernel_equals_the_register_staged_one_bit_for_bit(ops, case):
         pk.w_b16 = pk.w.to(torch.bfloat16)
         ng = ops.conv2d(x, pk, gate=gate, precision=1, act=ops.ACT_NONE, out_dtype=torch.bfloat16, tune=30)
         assert ops.last_conv_variant() == "conv_bf16w_kernel<2>" and torch.equal(ng, og)
+
+
+@pytest.mark.parametrize("case", [(4, 60, 80, 128, 512, "bf16", "bf16", True, True),    # data gradient of a bottleneck's conv1: residual + gate, all stored bf16
+                                  (4, 60, 80, 128, 512, "bf16", "bf16", True, False),   # its forward twin conv3: residual, ReLU
+                                  (3, 31, 39, 256, 1024, "f32", "bf16", False, True),   # fp32-stored input (rounded on the way into the fragments), ragged last pixel tile
+                                  (2, 120, 160, 32, 256, "f32", "bf16", False, True),   # the RPN predictors' data gradient: one ring step per N step
+                                  (5, 60, 80, 512, 128, "bf16", "bf16", False, True),   # Cin 512: 128 fragment registers, 64-channel N steps
+                                  (3, 60, 80, 512, 256, "bf16", "f32", False, False),   # fp32 output, nothing beside it
+                                  (1, 37, 53, 256, 512, "bf16", "bf16", True, True)],   # below the size rule (forced): partial round split along N
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_bf16_pointwise_kernel_with_stationary_activations_equals_the_tiled_one_bit_for_bit(ops, case):
+    """Round 5: conv_bf16xs_kernel (csrc/conv_bf16xs.hip) -- the step's HBM-bound 1x1 launches with a wave's 32 pixels held as MFMA fragments for
+    the whole launch, the bf16 filter copy streamed by LDS-DMA, residual and gate rows requested an N step ahead of their use -- against
+    conv_bf16_kernel: the same rounded operands and the same 16-deep products in the same order -> equal bits."""
+    B, H, W, Cin, Cout, xs, os_, has_res, has_gate = case
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}
+    torch.manual_seed(37)
+    x = torch.randn(B, H, W, Cin, device="cuda").to(dt[xs])
+    pk = ops.pack_conv(torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5, torch.randn(Cout) * 0.1, None, 1, 0, ops.ACT_NONE if has_gate else ops.ACT_RELU)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if has_res else None
+    gate = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if has_gate else None
+    kw = dict(res=res, gate=gate, precision=1, out_dtype=dt[os_])
+    old = ops.conv2d(x, pk, **kw)
+    assert ops.last_conv_variant().startswith("conv_bf16_kernel"), ops.last_conv_variant()
+    pk.w_b16 = pk.w.to(torch.bfloat16)
+    new = ops.conv2d(x, pk, tune=33, **kw)
+    assert ops.last_conv_variant() == f"conv_bf16xs_kernel<{Cin}>", ops.last_conv_variant()
+    assert new.dtype == old.dtype and torch.equal(new, old), float((new.float() - old.float()).abs().max())
+    assert bool(torch.isfinite(new.float()).all()) and float(new.float().abs().max()) > 0
+    kept = ops.conv2d(x, pk, tune=34, **kw)  # tune 34: never this kernel
+    assert not ops.last_conv_variant().startswith("conv_bf16xs") and torch.equal(kept, old)
