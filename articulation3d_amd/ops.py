@@ -62,7 +62,15 @@ def last_conv_variant() -> str:
     return _lib.lib().a3d_last_conv_variant().decode()
 
 
+# The raw handle of the calling thread's current stream, straight from the binding layer: `torch.cuda.current_stream()` builds a Stream object
+# through four layers of device-index helpers (~6 us), and every launch asks -- a third of the host time of the 2-images-per-GPU training
+# step, which is host-bound (tools/probes/train_host_profile.py).
+_raw_stream, _raw_device = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
