@@ -260,7 +260,10 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const a3d_conv_desc d
 }
 
 // second launch of a split-K layer: the splits in order, then the epilogue of the kernel above (scale / shift, residual, activation, gate,
-// fp32 or bf16 stores), per output quad
+// fp32 or bf16 stores), per output quad.
+// (Measured and removed, round 5: ONE launch -- a counter per tile, the workgroup that arrives last adds the splits and applies the
+// epilogue; bit-identical, and the 51 second launches of the 2-image step were gone -- but the release / acquire pair at device scope
+// is a write-back + invalidate of the XCD's whole L2 per workgroup on this chip: the step went 5.94 -> 7.87 ms, +38 us per split-K layer.)
 __global__ __launch_bounds__(256) void conv_bf16_reduce_kernel(const a3d_conv_desc d, const int M) {
     const int n4 = d.Cout >> 2;
     const size_t total = (size_t)M * n4;
