@@ -42,6 +42,7 @@ FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
 # "0": the per-layer launches -- the same bits either way, tests/test_gpu_training.py).
 BATCHED_LAUNCHES = os.environ.get("A3D_TRAIN_BATCHED", "1") != "0"
 WGRAD_SIDE_STREAM = os.environ.get("A3D_TRAIN_WGRAD_STREAM", "1") != "0"  # weight gradients on a side stream beside the data-gradient chain (same bits)
+RPN_BWD_STREAM = os.environ.get("A3D_TRAIN_RPN_STREAM", "1") != "0"  # the RPN head's backward as soon as its loss exists, on a second stream (same bits)
 RES_STAGES = (("res3", 4, 128, 512), ("res4", 6, 256, 1024), ("res5", 3, 512, 2048))  # name, blocks, mid, out
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
 
@@ -215,6 +216,7 @@ class DetectorTrainer:
         L[bp + "pred"] = _Layer(bp + "pred", 32, 1024, 1, 1, 0, ACT_NONE, sources=[(bp + "cls_score", 0, K + 1), (bp + "bbox_pred", K + 1, 4 * K)])
         self.layers = L
         self._wg_stream = torch.cuda.Stream(device=self.dev) if WGRAD_SIDE_STREAM else None
+        self._rpn_stream = torch.cuda.Stream(device=self.dev) if RPN_BWD_STREAM else None
         has_bias = lambda ly: ly.scale is None
         n = sum(ly.rows * ly.k * ly.k * ly.cin + (ly.rows if has_bias(ly) else 0) for ly in L.values())
         n = (n + 3) // 4 * 4
@@ -356,12 +358,8 @@ class DetectorTrainer:
             return self._wgrad_now(ly, x, dy, accumulate)
         # (host cost matters: the 2-image step is host-bound.  One reusable event per call site of the step, set_stream instead of the
         # `with torch.cuda.stream(...)` context manager -- 65 -> ~25 us per weight gradient on the host)
-        main = self._main_stream
-        i = self._wg_calls
-        self._wg_calls += 1
-        if i == len(self._wg_events):
-            self._wg_events.append(torch.cuda.Event())
-        ev = self._wg_events[i]
+        main = self._cur_stream  # (the stream this call is made on: the main one, or the RPN head's)
+        ev = self._next_event()
         ev.record(main)
         x.record_stream(side)
         dy.record_stream(side)
@@ -371,6 +369,60 @@ class DetectorTrainer:
             self._wgrad_now(ly, x, dy, accumulate)
         finally:
             torch.cuda.set_stream(main)
+
+    def _next_event(self):
+        """A reusable ordering event (one per call site of the step; a wait captures the record in front of it, so re-recording is safe)."""
+        i = self._wg_calls
+        self._wg_calls += 1
+        if i == len(self._wg_events):
+            self._wg_events.append(torch.cuda.Event())
+        return self._wg_events[i]
+
+    def _rpn_head_backward(self, names, dheads, t, feats, st, dP=None):
+        """Data and weight gradients of the RPN head (filters shared by the five levels: weight gradients accumulate in level order).
+        dP given: the serial form -- every level's gradient is added to dP[level] (p6's to p5 through the stride-2 subsample) and None is
+        returned.  dP None: the early form -- returns ({level: gradient}, dp6) for the caller to combine."""
+        L, rp = self.layers, "proposal_generator.rpn_head."
+        out, dp6 = {}, None
+        for li, n in enumerate(names):
+            dt = self._conv(dheads[li], L[rp + "pred"].bwd(), gate=t[li], out_dtype=st)
+            self._wgrad(L[rp + "pred"], t[li], dheads[li], accumulate=li > 0)
+            self._wgrad(L[rp + "conv"], feats[n], dt, accumulate=li > 0)
+            if n == "p6":
+                dp6 = self._conv(dt, L[rp + "conv"].bwd(), wino=False)
+                if dP is not None:
+                    T.zero_insert2(dp6, dP["p5"].shape[1], dP["p5"].shape[2], out=dP["p5"], accumulate=True)
+            elif dP is not None:
+                self._conv(dt, L[rp + "conv"].bwd(), res=dP[n], out=dP[n], wino=False)
+            else:
+                out[n] = self._conv(dt, L[rp + "conv"].bwd(), wino=False)
+        return None if dP is not None else (out, dp6)
+
+    def _rpn_head_backward_early(self, names, dheads, t, feats, st):
+        """The RPN head's backward needs nothing but its loss gradient, which exists before the proposals are even selected -- and proposal
+        selection, NMS, matching, ROI sampling and the pooler are latency-bound launches of a few workgroups that leave the chip empty
+        (~1 ms of the 6 ms step at the reference's 2 images per GPU).  So (round 5) it is enqueued on a second stream right behind the RPN
+        loss and runs under that window.  Bits: each pyramid level's gradient is the sum of two terms (ROI pooler + RPN head); the serial
+        form adds the RPN term onto the pooler's (conv epilogue, residual), this form lets the pooler's backward add onto the RPN term --
+        a + b either way; p5's third term (from p6) is added last in both."""
+        main, R = self._cur_stream, self._rpn_stream
+        ev = self._next_event()
+        ev.record(main)
+        for ten in list(dheads) + list(t) + [feats[n] for n in names]:
+            ten.record_stream(R)
+        torch.cuda.set_stream(R)
+        self._cur_stream = R
+        try:
+            R.wait_event(ev)
+            out, dp6 = self._rpn_head_backward(names, dheads, t, feats, st)
+            done = self._next_event()
+            done.record(R)
+        finally:
+            torch.cuda.set_stream(main)
+            self._cur_stream = main
+        for ten in list(out.values()) + [dp6]:
+            ten.record_stream(main)
+        return out, dp6, done
 
     def _wgrad_now(self, ly: _Layer, x, dy, accumulate=False):
         # The slice reductions of the step's weight gradients are folded in ONE launch at the end of the backward pass (self._defer.flush()
@@ -390,7 +442,7 @@ class DetectorTrainer:
         """frames_u8 [B,H,W,3] uint8 BGR on the device; per image gt_boxes [G,4] fp32 / gt_classes [G] int64 (CPU or device).
         Fills self.grads; returns ({loss name: 0-d device tensor}, aux with the sampled index sets)."""
         saved, ops.BF16_SPLITK_AUTO = ops.BF16_SPLITK_AUTO, True  # (split-K by batch size: the training step's launches only, ops.py)
-        self._main_stream, self._wg_calls = torch.cuda.current_stream(), 0
+        self._cur_stream, self._wg_calls = torch.cuda.current_stream(), 0
         if not hasattr(self, "_wg_events"):
             self._wg_events = []
         try:
@@ -460,6 +512,7 @@ class DetectorTrainer:
             labels_d = samples["anchor_labels"].to(torch.int8).to(self.dev)
         rpn_l, dheads = T.rpn_loss(heads, self.strides, self.cell_anchors, labels_d, midx, gtb_d, A=3, weights=s.rpn_weights,
                                    normalizer=float(s.rpn_batch_per_image * B))
+        early = self._rpn_head_backward_early(names, dheads, t, feats, st) if self._rpn_stream is not None else None
         # ---- proposals (no gradient) + ground truth, Matcher, sub-sampling (512 per image, <= a quarter foreground)
         pb, _ps, _lvl, _pos, pcount = ops.rpn_proposals(heads, self.strides, self.cell_anchors, (H, W), pre_topk=s.rpn_pre_topk_train,
                                                         post_topk=s.rpn_post_topk_train, nms_thresh=s.rpn_nms_thresh, min_size=0.0,
@@ -508,19 +561,18 @@ class DetectorTrainer:
         dh1 = self._conv(dh2, L[bh + "fc2"].bwd(), gate=h1, out_dtype=st)
         self._wgrad(L[bh + "fc1"], xrow, dh1)
         dpooled = self._conv(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
-        dP = {n: torch.zeros_like(feats[n]) for n in ("p2", "p3", "p4", "p5")}
-        T.roi_align_fpn_backward([dP[n] for n in ("p2", "p3", "p4", "p5")], scales, roi_boxes, dpooled.view(M, 7, 7, 256), P=7,
-                                 sampling_ratio=0, aligned=True, count=rcount_d)
-        # ---- RPN head backward (weights shared by the five levels: gradients accumulate in level order)
-        for li, n in enumerate(names):
-            dt = self._conv(dheads[li], L[rp + "pred"].bwd(), gate=t[li], out_dtype=st)
-            self._wgrad(L[rp + "pred"], t[li], dheads[li], accumulate=li > 0)
-            self._wgrad(L[rp + "conv"], feats[n], dt, accumulate=li > 0)
-            if n == "p6":
-                dp6 = self._conv(dt, L[rp + "conv"].bwd(), wino=False)
-                T.zero_insert2(dp6, dP["p5"].shape[1], dP["p5"].shape[2], out=dP["p5"], accumulate=True)
-            else:
-                self._conv(dt, L[rp + "conv"].bwd(), res=dP[n], out=dP[n], wino=False)
+        if early is not None:  # the RPN head's term of every level is there already (second stream): the pooler's backward adds onto it
+            dP, dp6, done = early
+            self._cur_stream.wait_event(done)
+            T.roi_align_fpn_backward([dP[n] for n in ("p2", "p3", "p4", "p5")], scales, roi_boxes, dpooled.view(M, 7, 7, 256), P=7,
+                                     sampling_ratio=0, aligned=True, count=rcount_d)
+            T.zero_insert2(dp6, dP["p5"].shape[1], dP["p5"].shape[2], out=dP["p5"], accumulate=True)
+        else:
+            dP = {n: torch.zeros_like(feats[n]) for n in ("p2", "p3", "p4", "p5")}
+            T.roi_align_fpn_backward([dP[n] for n in ("p2", "p3", "p4", "p5")], scales, roi_boxes, dpooled.view(M, 7, 7, 256), P=7,
+                                     sampling_ratio=0, aligned=True, count=rcount_d)
+            # ---- RPN head backward (weights shared by the five levels: gradients accumulate in level order)
+            self._rpn_head_backward(names, dheads, t, feats, st, dP=dP)
         # ---- FPN backward (finest level first: the top-down path carries gradient upwards)
         dprev = {}
         for l in (2, 3, 4, 5):

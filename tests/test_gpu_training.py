@@ -925,3 +925,35 @@ def test_bf16_pointwise_kernel_with_stationary_activations_equals_the_tiled_one_
     assert bool(torch.isfinite(new.float()).all()) and float(new.float().abs().max()) > 0
     kept = ops.conv2d(x, pk, tune=34, **kw)  # tune 34: never this kernel
     assert not ops.last_conv_variant().startswith("conv_bf16xs") and torch.equal(kept, old)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_side_streams_keep_every_bit_of_the_serial_step(hip_model, oracle, precision):
+    """Round 5: the weight gradients run on a side stream beside the data-gradient chain, and the RPN head's backward is enqueued on a second
+    stream as soon as its loss exists (under the proposal selection / sampling window); the pooler's backward then adds ONTO the RPN term
+    of every pyramid level instead of the other way round (a + b either way, p6's term last in both).  Against the one-stream step on the
+    same batch and sampled sets: every loss and every gradient bit for bit, step after step."""
+    from articulation3d_amd.training import DetectorTrainer
+    from oracle import train_oracle as TO
+
+    frames = torch.from_numpy(oracle.synthetic_frames(2)).cuda()
+    tg = TO.synthetic_targets(2)
+    gb, gc = [t[0] for t in tg], [t[1] for t in tg]
+    t0 = DetectorTrainer(hip_model, seed=7, precision=precision)
+    assert t0._wg_stream is not None and t0._rpn_stream is not None  # (the defaults under test)
+    t0._wg_stream = t0._rpn_stream = None  # one stream
+    l0, aux = t0.forward_backward(frames, gb, gc)
+    rc, ri = aux["roi_count"].cpu(), aux["roi_index"].cpu()
+    samples = dict(anchor_labels=aux["anchor_labels"].cpu(), roi_idx=[ri[i, : int(rc[i])].long() for i in range(2)])
+    l0, _ = t0.forward_backward(frames, gb, gc, samples=samples)
+    g0 = {k: v.clone() for k, v in t0.export_grads().items()}
+    t1 = DetectorTrainer(hip_model, seed=7, precision=precision)
+    for _ in range(3):  # (later steps reuse the events and the allocator's blocks of both side streams)
+        l1, _ = t1.forward_backward(frames, gb, gc, samples=samples)
+        torch.cuda.synchronize()
+        g1 = t1.export_grads()
+        for k in l0:
+            assert float(l0[k]) == float(l1[k]), k
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+    assert all(bool(torch.isfinite(v).all()) for v in g0.values()) and sum(float(v.abs().sum()) for v in g0.values()) > 0

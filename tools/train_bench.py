@@ -75,14 +75,15 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
     from articulation3d_amd import ops
     from bench import PIPE_FLOPS_PER_FMA, PIPE_PEAK, dominant_roofline, kernel_sums
 
-    # The instrumented step runs its weight gradients on the main stream (the timed steps above keep them on the side stream): an event
-    # bracket then times one launch alone, not the span it shares the GPU with the other stream.
+    # The instrumented step runs everything on the main stream (the timed steps above keep the weight gradients and the RPN head's backward
+    # on their side streams): an event bracket then times one launch alone, not the span it shares the GPU with another stream.
     side, tr._wg_stream = tr._wg_stream, None
+    rside, tr._rpn_stream = tr._rpn_stream, None
     ops.CONV_TIMING = []
     tr.step(frames, gtb, gtc)
     barrier()
     events, ops.CONV_TIMING = ops.CONV_TIMING, None
-    tr._wg_stream = side
+    tr._wg_stream, tr._rpn_stream = side, rside
     if layers and rank == 0:
         for name, fl, a, b, shape, ex, pipe, _st in events:
             ms = a.elapsed_time(b)
