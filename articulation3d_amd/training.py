@@ -424,6 +424,53 @@ class DetectorTrainer:
             ten.record_stream(main)
         return out, dp6, done
 
+    def _rpn_labels(self, anchors, gt_boxes, gt_classes, samples, seed, B):
+        """Ground truth on the device (fixed-size, counts in a device vector: nothing waits for the host) + the RPN's labels: Matcher + random
+        sub-sampling (256 per image, <= half positive), both on the device.  Depends on the ground truth and the anchor grid only."""
+        s = self.s
+        assert max(len(g) for g in gt_boxes) <= s.max_gt
+        gtb = torch.zeros(B, s.max_gt, 4)
+        gtc = torch.zeros(B, s.max_gt, dtype=torch.int32)
+        gcount = torch.zeros(B, dtype=torch.int32)
+        for i, (gb, gc) in enumerate(zip(gt_boxes, gt_classes)):
+            gtb[i, : len(gb)] = gb.cpu()
+            gtc[i, : len(gb)] = gc.cpu().to(torch.int32)
+            gcount[i] = len(gb)
+        gtb_d, gtc_d, gcount_d = gtb.to(self.dev, non_blocking=True), gtc.to(self.dev, non_blocking=True), gcount.to(self.dev, non_blocking=True)
+        midx, lab = T.match_boxes(anchors, gtb_d, gcount_d, thresholds=s.rpn_iou_thresholds, labels=(0, -1, 1), allow_low_quality=True,
+                                  shared=True)
+        if samples is None:
+            labels_d = T.sample_labels(lab, num=s.rpn_batch_per_image, max_pos=int(s.rpn_batch_per_image * s.rpn_positive_fraction), seed=seed)
+        else:
+            labels_d = samples["anchor_labels"].to(torch.int8).to(self.dev)
+        return gtb_d, gtc_d, gcount_d, midx, lab, labels_d
+
+    def _rpn_labels_early(self, H, W, gt_boxes, gt_classes, samples, seed, B):
+        """The same on the second stream, enqueued before the backbone's forward pass: three small launches and the ground-truth upload leave
+        the step's dependent chain.  The pyramid's map sizes follow from the input size (every stride-2 stage: (h - 1) // 2 + 1)."""
+        f = lambda v: (v - 1) // 2 + 1
+        hw, (h, w) = [], (f(f(H)), f(f(W)))
+        for _ in self.strides:
+            hw.append((h, w))
+            h, w = f(h), f(w)
+        anchors = self._anchors(hw)
+        main, R = self._cur_stream, self._rpn_stream
+        ev = self._next_event()
+        ev.record(main)
+        torch.cuda.set_stream(R)
+        self._cur_stream = R
+        try:
+            R.wait_event(ev)
+            out = self._rpn_labels(anchors, gt_boxes, gt_classes, samples, seed, B)
+            ready = self._next_event()
+            ready.record(R)
+        finally:
+            torch.cuda.set_stream(main)
+            self._cur_stream = main
+        for ten in out:
+            ten.record_stream(main)
+        return hw, out + (ready,)
+
     def _wgrad_now(self, ly: _Layer, x, dy, accumulate=False):
         # The slice reductions of the step's weight gradients are folded in ONE launch at the end of the backward pass (self._defer.flush()
         # in forward_backward): 63 reduce launches of ~17 us each were 11 % of the step at the reference's 2 images per GPU.  Layers whose
@@ -453,13 +500,37 @@ class DetectorTrainer:
     def _forward_backward(self, frames_u8, gt_boxes, gt_classes, samples):
         s, L, m = self.s, self.layers, self.model
         B, H, W, _ = frames_u8.shape
-        self._prepare_filters()
+        # The per-step filter preparation (data-gradient transposes, bf16 copies: three HBM-bound launches over all parameters) does not touch
+        # the frozen stem / res2, so it runs on the side stream beside their forward pass; res3's first launch waits for it.
+        prepared = None
+        if self._wg_stream is not None:
+            main, side = self._cur_stream, self._wg_stream
+            ev = self._next_event()
+            ev.record(main)  # (behind the previous step's optimiser update)
+            torch.cuda.set_stream(side)
+            self._cur_stream = side
+            try:
+                side.wait_event(ev)
+                self._prepare_filters()
+                prepared = self._next_event()
+                prepared.record(side)
+            finally:
+                torch.cuda.set_stream(main)
+                self._cur_stream = main
+        else:
+            self._prepare_filters()
+        seed = (self.seed * 1000003 + self.iter) * 4
+        labels_early, early_hw = None, None
+        if self._rpn_stream is not None:  # ground-truth upload, anchor matching and label sampling: beside the backbone's forward pass
+            early_hw, labels_early = self._rpn_labels_early(H, W, gt_boxes, gt_classes, samples, seed, B)
         saved = {}
         relu_outputs = []  # every ReLU output on the trainable path, in forward order (aux: lets a checker reuse the gates)
         with torch.no_grad():
             x4 = ops.preprocess_u8hwc(frames_u8.contiguous(), self.pixel_mean, self.pixel_std)
             x = m.backbone.bottom_up.res2(m.backbone.bottom_up.stem(x4))  # frozen (FREEZE_AT 2)
         res = {"res2": x}
+        if prepared is not None:
+            self._cur_stream.wait_event(prepared)
         # ---- res3..res5 forward, activations kept
         for name, nblk, _mid, _cout in RES_STAGES:
             for i in range(nblk):
@@ -492,24 +563,12 @@ class DetectorTrainer:
         heads = [self._conv(ti, L[rp + "pred"].fwd()) for ti in t]
         feat_hw = [tuple(feats[n].shape[1:3]) for n in names]
         anchors = self._anchors(feat_hw)
-        # ---- ground truth on the device (fixed-size, counts in a device vector: nothing below waits for the host)
-        assert max(len(g) for g in gt_boxes) <= s.max_gt
-        gtb = torch.zeros(B, s.max_gt, 4)
-        gtc = torch.zeros(B, s.max_gt, dtype=torch.int32)
-        gcount = torch.zeros(B, dtype=torch.int32)
-        for i, (gb, gc) in enumerate(zip(gt_boxes, gt_classes)):
-            gtb[i, : len(gb)] = gb.cpu()
-            gtc[i, : len(gb)] = gc.cpu().to(torch.int32)
-            gcount[i] = len(gb)
-        gtb_d, gtc_d, gcount_d = gtb.to(self.dev, non_blocking=True), gtc.to(self.dev, non_blocking=True), gcount.to(self.dev, non_blocking=True)
-        seed = (self.seed * 1000003 + self.iter) * 4
-        # ---- RPN labels: Matcher + random sub-sampling (256 per image, <= half positive), both on the device
-        midx, lab = T.match_boxes(anchors, gtb_d, gcount_d, thresholds=s.rpn_iou_thresholds, labels=(0, -1, 1), allow_low_quality=True,
-                                  shared=True)
-        if samples is None:
-            labels_d = T.sample_labels(lab, num=s.rpn_batch_per_image, max_pos=int(s.rpn_batch_per_image * s.rpn_positive_fraction), seed=seed)
-        else:
-            labels_d = samples["anchor_labels"].to(torch.int8).to(self.dev)
+        if labels_early is None:
+            gtb_d, gtc_d, gcount_d, midx, lab, labels_d = self._rpn_labels(anchors, gt_boxes, gt_classes, samples, seed, B)
+        else:  # (matched and sampled on the second stream while the backbone ran)
+            assert tuple(feat_hw) == tuple(early_hw), (feat_hw, early_hw)
+            gtb_d, gtc_d, gcount_d, midx, lab, labels_d, ready = labels_early
+            self._cur_stream.wait_event(ready)
         rpn_l, dheads = T.rpn_loss(heads, self.strides, self.cell_anchors, labels_d, midx, gtb_d, A=3, weights=s.rpn_weights,
                                    normalizer=float(s.rpn_batch_per_image * B))
         early = self._rpn_head_backward_early(names, dheads, t, feats, st) if self._rpn_stream is not None else None
@@ -607,9 +666,12 @@ class DetectorTrainer:
                 else:
                     g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
         if self._wg_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._wg_stream)  # every weight gradient has been launched and is waited for here
+            self._cur_stream.wait_stream(self._wg_stream)  # every weight gradient has been launched and is waited for here
         if getattr(self, "_defer", None) is not None:
-            self._defer.flush()  # every parked weight gradient: one reduce launch
+            # every parked weight gradient: one reduce launch.  (Flushed in pieces on the side stream, under the rest of the backward pass:
+            # measured slower the finer the pieces -- 352 | 347 | 342 | 338 images/s at 2 images per GPU for one | 24 | 12 | 6 layers per
+            # flush: the reduce is HBM-bound and takes its bandwidth from the chain it runs beside.)
+            self._defer.flush()
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))
