@@ -550,17 +550,62 @@ class DetectorTrainer:
         # them are stored as bf16 too -- what torch.autocast keeps of them; the pyramid p2..p6 itself stays fp32: the pooler and the proposal
         # decoder read it, and its gradient is accumulated from two branches)
         st = self._st
-        prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd(), out_dtype=st)
-        feats["p5"] = self._conv(prev[5], L["backbone.fpn_output5"].fwd())
-        for l in (4, 3, 2):
-            prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True, out_dtype=st)
-            feats[f"p{l}"] = self._conv(prev[l], L[f"backbone.fpn_output{l}"].fwd())
-        feats["p6"] = ops.subsample2(feats["p5"])
         names = ("p2", "p3", "p4", "p5", "p6")
-        # ---- RPN head
         rp = "proposal_generator.rpn_head."
-        t = [self._conv(feats[n], L[rp + "conv"].fwd(), out_dtype=st) for n in names]
-        heads = [self._conv(ti, L[rp + "pred"].fwd()) for ti in t]
+        tmap, hmap = {}, {}
+
+        def level_heads(n):  # the RPN head on one pyramid level (shared filters; the levels are independent of each other)
+            tmap[n] = self._conv(feats[n], L[rp + "conv"].fwd(), out_dtype=st)
+            hmap[n] = self._conv(tmap[n], L[rp + "pred"].fwd())
+
+        R = self._rpn_stream
+        if R is None:
+            prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd(), out_dtype=st)
+            feats["p5"] = self._conv(prev[5], L["backbone.fpn_output5"].fwd())
+            for l in (4, 3, 2):
+                prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True, out_dtype=st)
+                feats[f"p{l}"] = self._conv(prev[l], L[f"backbone.fpn_output{l}"].fwd())
+            feats["p6"] = ops.subsample2(feats["p5"])
+            for n in names:
+                level_heads(n)
+        else:
+            # The top-down lateral chain (four small launches) and the finest level stay on the main stream; the output convs and RPN heads of
+            # p3..p6 -- each waiting for its own lateral sum only -- run on the second stream beside them (same launches, same bits).
+            main = self._cur_stream
+            lat_done = {}
+            prev[5] = self._conv(res["res5"], L["backbone.fpn_lateral5"].fwd(), out_dtype=st)
+            lat_done[5] = self._next_event()
+            lat_done[5].record(main)
+            for l in (4, 3, 2):
+                prev[l] = self._conv(res[f"res{l}"], L[f"backbone.fpn_lateral{l}"].fwd(), res=prev[l + 1], res_ups=True, out_dtype=st)
+                if l > 2:
+                    lat_done[l] = self._next_event()
+                    lat_done[l].record(main)
+            for l in (5, 4, 3):
+                prev[l].record_stream(R)
+            torch.cuda.set_stream(R)
+            self._cur_stream = R
+            try:
+                for l in (5, 4, 3):
+                    R.wait_event(lat_done[l])
+                    feats[f"p{l}"] = self._conv(prev[l], L[f"backbone.fpn_output{l}"].fwd())
+                    level_heads(f"p{l}")
+                    if l == 5:
+                        feats["p6"] = ops.subsample2(feats["p5"])
+                        level_heads("p6")
+                coarse_done = self._next_event()
+                coarse_done.record(R)
+            finally:
+                torch.cuda.set_stream(main)
+                self._cur_stream = main
+            feats["p2"] = self._conv(prev[2], L["backbone.fpn_output2"].fwd())
+            level_heads("p2")
+            main.wait_event(coarse_done)
+            for n in ("p3", "p4", "p5", "p6"):
+                for ten in (feats[n], tmap[n], hmap[n]):
+                    ten.record_stream(main)
+        t = [tmap[n] for n in names]
+        heads = [hmap[n] for n in names]
         feat_hw = [tuple(feats[n].shape[1:3]) for n in names]
         anchors = self._anchors(feat_hw)
         if labels_early is None:
