@@ -73,10 +73,35 @@ class _Packable(nn.Module):
         super().__init__()
         self._pack_cache = None
         self._pack_key = None
+        self._key_src = None
+
+    # The key is asked for on EVERY forward call (a 1-frame pass makes ~100 of them): walking parameters() / buffers() through the module
+    # machinery cost ~14 us per call -- 1.2 ms of host time per frame in the reference's per-frame loop, which is host-bound.  The (owning
+    # dict, name) slots are therefore found once and only looked up afterwards: a tensor replaced in its slot (load_state_dict copies in
+    # place, .to() / .cuda() replace buffers and parameter data) is seen through the lookup; anything that changes the SET of slots
+    # (attribute assignment on this module, _apply) drops the slot list.
+    def __setattr__(self, name, value):
+        if name not in ("_pack_cache", "_pack_key", "_key_src"):
+            self.__dict__["_key_src"] = None
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, recurse=True):
+        self.__dict__["_key_src"] = None
+        return super()._apply(fn, recurse)
 
     def _key(self):
-        ts = list(self.parameters(recurse=True)) + list(self.buffers(recurse=True))
-        return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
+        src = self.__dict__.get("_key_src")
+        if src is None:
+            src = []
+            for m in self.modules():
+                src += [(m._parameters, k) for k in m._parameters] + [(m._buffers, k) for k in m._buffers]
+            self.__dict__["_key_src"] = src
+        out = []
+        for d, k in src:
+            t = d.get(k)
+            if t is not None:
+                out.append((t.data_ptr(), t._version, t.device))
+        return tuple(out)
 
     def packed(self) -> ops.PackedConv:
         key = self._key()
