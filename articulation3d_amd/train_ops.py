@@ -63,6 +63,9 @@ class DeferredReduces:
         self.items = []
 
 
+_WGRAD_DESC_CACHE: dict = {}
+
+
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, KW: int, stride: int, pad: int,
                scale: Optional[torch.Tensor] = None, accumulate: bool = False, splitk: Optional[int] = None, precision: int = 0,
                defer: Optional[DeferredReduces] = None) -> torch.Tensor:
@@ -75,23 +78,35 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, KH: int, 
     B, H, W, Cin = x.shape
     B2, Ho, Wo, Cout = dy.shape
     assert B == B2 and dw.numel() == Cout * KH * KW * Cin, (x.shape, dy.shape, dw.shape)
-    d = _lib.WgradDesc()
-    d.x, d.dy, d.scale, d.dw = _p(x), _p(dy), _p(scale), _p(dw)
-    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
-    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    d.accumulate = int(accumulate)
-    d.precision = int(precision)
-    d.io_bf16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if dy.dtype == torch.bfloat16 else 0)
-    d.splitk = 1
-    tiles, red = C.c_int(0), C.c_int(0)
-    form = _lib.lib().a3d_wgrad_tiles(C.byref(d), C.byref(tiles), C.byref(red))  # the kernel form the library runs this layer on
-    if splitk:
-        d.splitk = int(splitk)
-    elif form > 0:  # transposed-read form (one 512-thread workgroup per CU, 64-pixel chunks): one round of the chip, >= 4 chunks per slice
-        d.splitk = int(max(1, min(WGRAD_TR_WORKGROUPS // max(tiles.value, 1), red.value // WGRAD_TR_MIN_PIXELS, 256)))
-    else:
-        d.splitk = choose_wgrad_slices(B * Ho * Wo, tiles.value)
-    nbytes = _lib.lib().a3d_wgrad_workspace_bytes(C.byref(d))
+    # (the descriptor's static fields, the kernel form and the slice count are functions of the layer and the batch shape: kept per key, only
+    # the tensor pointers are written per launch -- host time matters at 2 images per GPU)
+    key = (B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, bool(accumulate), int(precision), x.dtype, dy.dtype, splitk, scale is None, WGRAD_TR_WORKGROUPS, WGRAD_TR_MIN_PIXELS)
+    hit = _WGRAD_DESC_CACHE.get(key)
+    if hit is None:
+        d = _lib.WgradDesc()
+        d.x, d.dy, d.scale, d.dw = _p(x), _p(dy), _p(scale), _p(dw)
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        d.accumulate = int(accumulate)
+        d.precision = int(precision)
+        d.io_bf16 = (1 if x.dtype == torch.bfloat16 else 0) | (2 if dy.dtype == torch.bfloat16 else 0)
+        d.splitk = 1
+        tiles, red = C.c_int(0), C.c_int(0)
+        form = _lib.lib().a3d_wgrad_tiles(C.byref(d), C.byref(tiles), C.byref(red))  # the kernel form the library runs this layer on
+        if splitk:
+            d.splitk = int(splitk)
+        elif form > 0:  # transposed-read form (one 512-thread workgroup per CU, 64-pixel chunks): one round of the chip, >= 4 chunks per slice
+            d.splitk = int(max(1, min(WGRAD_TR_WORKGROUPS // max(tiles.value, 1), red.value // WGRAD_TR_MIN_PIXELS, 256)))
+        else:
+            d.splitk = choose_wgrad_slices(B * Ho * Wo, tiles.value)
+        nbytes = _lib.lib().a3d_wgrad_workspace_bytes(C.byref(d))
+        d.x = d.dy = d.scale = d.dw = None
+        if len(_WGRAD_DESC_CACHE) > 4096:
+            _WGRAD_DESC_CACHE.clear()
+        hit = _WGRAD_DESC_CACHE[key] = (bytes(d), form, nbytes)
+    proto, form, nbytes = hit
+    d = _lib.WgradDesc.from_buffer_copy(proto)
+    d.x, d.dy, d.scale, d.dw = x.data_ptr(), dy.data_ptr(), _p(scale), dw.data_ptr()
     if defer is not None and not accumulate:
         ws = defer.workspace(dw, nbytes)
         d.defer_reduce = 1
