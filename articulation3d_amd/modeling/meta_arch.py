@@ -219,7 +219,9 @@ class PlaneRCNN(nn.Module):
             # are one partial round of the chip per head layer, and the decoder's tails fill it).
             main = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream()
+                from ..streams import side
+
+                self._side_stream = side(0)  # (the package's one pool of side streams: streams.py)
             ready = torch.cuda.Event()
             ready.record(main)
             with torch.cuda.stream(self._side_stream):

@@ -197,14 +197,10 @@ def gather_records_async(records: torch.Tensor, rec_count: torch.Tensor, rows: O
     return GatherHandle(finish, (G * rows, R, F))
 
 
-_SIDE = {}
-
-
 def _side_stream(device):
-    s = _SIDE.get(device)
-    if s is None:
-        s = _SIDE[device] = torch.cuda.Stream(device=device)
-    return s
+    from .streams import side  # (the package's one pool of side streams: streams.py)
+
+    return side(0, device)
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, group=None, payload: str = "fp32") -> float:

@@ -15,15 +15,41 @@ from typing import Callable, List, Sequence
 import torch
 
 SMALL_BATCH = int(os.environ.get("A3D_SMALL_BATCH", "2"))  # frames (see above); 0 disables
+N_SIDE = 3
 _side: dict = {}
 
 
+def side(i: int, device=None) -> "torch.cuda.Stream":
+    """Side stream number i (0 .. N_SIDE - 1, larger i wrap) of the package's ONE pool per device.
+
+    Why one pool with fixed roles instead of a stream per user.  ROCm maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES,
+    4 by default) in the order of their FIRST USE, and which queue a stream lands on decides how its kernels interleave with another
+    stream's (tools/probes/stream_overlap_matrix.py, train_stream_queues.py: the training step's two side streams as the 5th and 6th
+    streams of a process -- behind bench.py's copy stream and three detectors' decoder streams -- ran the 16-image step in 18.0 ms
+    instead of 14.9; as the 1st and 2nd they never did).  So the package creates its side streams once, all together and first-used in
+    index order right behind the default stream, and every component takes them by role:
+        0  the depth decoder beside the ROI branch (meta_arch) | the training step's weight gradients | the gather's count read-back
+        1  second branch of a 1-2 frame batch              | the training step's RPN-head stream
+        2  third branch of a 1-2 frame batch               | the clip / record copies of a pipelined caller (bench.py)
+    Two roles of one row never run at the same time; if a caller made them, they would serialise on one stream -- slower, never wrong."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    pool = _side.get(dev)
+    if pool is None:
+        with torch.cuda.device(dev):
+            pool = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE)]
+            for st in pool:  # first use, in index order: the hardware queues are taken now, in this order
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(1)
+            for st in pool:
+                st.synchronize()
+        _side[dev] = pool
+    return pool[i % N_SIDE]
+
+
 def _stream(i: int) -> "torch.cuda.Stream":
-    key = (torch.cuda.current_device(), i)
-    s = _side.get(key)
-    if s is None:
-        s = _side[key] = torch.cuda.Stream()
-    return s
+    return side(i)
 
 
 def _tensors(o):

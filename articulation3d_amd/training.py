@@ -215,8 +215,11 @@ class DetectorTrainer:
         K = self.s.num_classes
         L[bp + "pred"] = _Layer(bp + "pred", 32, 1024, 1, 1, 0, ACT_NONE, sources=[(bp + "cls_score", 0, K + 1), (bp + "bbox_pred", K + 1, 4 * K)])
         self.layers = L
-        self._wg_stream = torch.cuda.Stream(device=self.dev) if WGRAD_SIDE_STREAM else None
-        self._rpn_stream = torch.cuda.Stream(device=self.dev) if RPN_BWD_STREAM else None
+        # (side streams 0 and 1 of the package's one pool -- streams.side: which hardware queue a stream lands on follows from the order
+        # in which a process first uses its streams, and the step's time with it)
+        from .streams import side
+        self._wg_stream = side(0, self.dev) if WGRAD_SIDE_STREAM else None
+        self._rpn_stream = side(1, self.dev) if RPN_BWD_STREAM else None
         has_bias = lambda ly: ly.scale is None
         n = sum(ly.rows * ly.k * ly.k * ly.cin + (ly.rows if has_bias(ly) else 0) for ly in L.values())
         n = (n + 3) // 4 * 4

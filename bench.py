@@ -370,7 +370,9 @@ def main():
         # while step i runs, the records of step i go D2H while step i + 1 runs (two pinned host buffers each way).  Events order them:
         # a step waits for ITS clip's copy, a copy into a buffer waits for the step that last read it, a record copy for the step that
         # wrote it.  What a caller with host frames would run (pipeline.detect_clip takes the same form).
-        copy_stream = torch.cuda.Stream(device=dev)
+        from articulation3d_amd.streams import side
+
+        copy_stream = side(2, dev)  # (the package's one pool of side streams: articulation3d_amd/streams.py)
         dev_buf = [torch.empty_like(frames), torch.empty_like(frames)]
         rec_hosts = [rec_host, torch.empty_like(rec_host).pin_memory()]
         cnt_hosts = [cnt_host, torch.empty_like(cnt_host).pin_memory()]
