@@ -253,6 +253,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (HIP) device: there is no CPU fallback for the product path")
     local_dev = local_rank % torch.cuda.device_count()  # == local_rank on a real N-GPU node
     torch.cuda.set_device(local_dev)
+    from articulation3d_amd.streams import side
+
+    side(0)  # the package's side streams take their hardware queues now, in front of the collective library's (articulation3d_amd/streams.py)
     dev = f"cuda:{local_dev}"
     dist = None
     use_dist = world > 1 or force_dist

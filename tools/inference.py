@@ -128,6 +128,9 @@ def main():
         n_dev = torch.cuda.device_count()  # (does not initialise HIP)
         cfg.MODEL.DEVICE = f"cuda:{local_rank % max(n_dev, 1)}"
         torch.cuda.set_device(local_rank % max(n_dev, 1))
+        from articulation3d_amd.streams import side
+
+        side(0)  # the package's side streams take their hardware queues now, in front of the collective library's (articulation3d_amd/streams.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device(cfg.MODEL.DEVICE))

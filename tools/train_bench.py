@@ -155,6 +155,9 @@ def main():
         raise SystemExit("train_bench.py needs an MI355X (HIP) device")
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
+    from articulation3d_amd.streams import side
+
+    side(0)  # the package's side streams take their hardware queues now, in front of the collective library's (articulation3d_amd/streams.py)
     dev = f"cuda:{local_dev}"
     dist = None
     if world > 1:
