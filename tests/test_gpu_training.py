@@ -957,3 +957,35 @@ def test_side_streams_keep_every_bit_of_the_serial_step(hip_model, oracle, preci
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
     assert all(bool(torch.isfinite(v).all()) for v in g0.values()) and sum(float(v.abs().sum()) for v in g0.values()) > 0
+
+
+def test_bf16_pointwise_kernel_fuzz_against_the_tiled_one(ops):
+    """Random shapes through conv_bf16xs_kernel (tune 33) against conv_bf16_kernel (tune 34): ragged pixel tiles, every Cin it takes, channel
+    counts that split the last round along N in different ways, each storage / residual / gate combination -- equal bits in every case."""
+    import random
+
+    rng = random.Random(5)
+    bf, f32 = torch.bfloat16, torch.float32
+    ran = 0
+    for it in range(120):
+        Cin = rng.choice([32, 128, 256, 512])
+        bn = 64 if Cin == 512 else 128
+        Cout = bn * rng.choice([1, 2, 3, 4, 8])
+        B, H, W = rng.choice([1, 2, 3]), rng.randint(5, 70), rng.randint(5, 90)
+        xdt = rng.choice([bf, f32]) if Cin != 512 else bf
+        odt = rng.choice([bf, f32])
+        has_res, has_gate = rng.random() < 0.5, rng.random() < 0.5
+        torch.manual_seed(1000 + it)
+        x = torch.randn(B, H, W, Cin, device="cuda").to(xdt)
+        pk = ops.pack_conv(torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5, torch.randn(Cout) * 0.1, None, 1, 0, ops.ACT_NONE if has_gate else ops.ACT_RELU)
+        pk.w_b16 = pk.w.to(bf)
+        res = torch.randn(B, H, W, Cout, device="cuda").to(bf) if has_res else None
+        gate = torch.randn(B, H, W, Cout, device="cuda").to(bf) if has_gate else None
+        kw = dict(res=res, gate=gate, precision=1, out_dtype=odt)
+        old = ops.conv2d(x, pk, tune=34, **kw)
+        assert ops.last_conv_variant().startswith("conv_bf16_kernel"), ops.last_conv_variant()
+        new = ops.conv2d(x, pk, tune=33, **kw)
+        assert ops.last_conv_variant() == f"conv_bf16xs_kernel<{Cin}>", (ops.last_conv_variant(), (B, H, W, Cin, Cout))
+        assert torch.equal(new, old), ((B, H, W, Cin, Cout, xdt, odt, has_res, has_gate), float((new.float() - old.float()).abs().max()))
+        ran += 1
+    assert ran == 120
