@@ -1,0 +1,9 @@
+import os, runpy, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT)
+import articulation3d_amd._lib as L
+alt = os.environ.get("A3D_ALT_LIB")
+if alt:
+    L.LIB_PATH = os.path.join(ROOT, "articulation3d_amd", alt)
+sys.argv = sys.argv[1:]
+runpy.run_path(os.path.join(ROOT, sys.argv[0]), run_name="__main__")
