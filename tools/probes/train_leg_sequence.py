@@ -1,5 +1,6 @@
+"""Training legs of different batch sizes one after the other in ONE process (what bench.py does): `train_leg_sequence.py 2,16`."""
 import os, sys, torch
-ROOT="/root/repo" if os.path.exists("/root/repo/bench.py") else os.environ.get("GRAFT_REPO_ROOT")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from train_bench import train_leg
 dev = torch.device("cuda:0")
