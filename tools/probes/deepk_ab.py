@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from articulation3d_amd import ops
 shapes = [(64,30,40,1024,256,1),(64,60,80,512,128,1),(64,15,20,2048,512,1),(64,15,20,512,2048,1),(64,60,80,512,256,1),(64,30,40,1024,2048,2),(64,30,40,256,1024,1)]
 for B,H,W,Cin,Cout,st in shapes:
