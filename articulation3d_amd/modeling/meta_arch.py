@@ -293,7 +293,7 @@ class PlaneRCNN(nn.Module):
         gt_boxes = [x["instances"].gt_boxes.tensor.float() for x in batched_inputs]
         gt_classes = [x["instances"].gt_classes.long() for x in batched_inputs]
         tr = self.trainer()
-        losses, _aux = tr.forward_backward(frames, gt_boxes, gt_classes)
+        losses, _aux = tr.forward_backward(frames, gt_boxes, gt_classes, exchange=True)  # (optimizer.step() finishes the exchange)
         names = list(losses)
         outs = _StepLosses.apply(tr.autograd_anchor(), *[losses[k] for k in names])
         return dict(zip(names, outs))

@@ -234,3 +234,141 @@ def allreduce_gradients(flat_grads: torch.Tensor, group=None, payload: str = "fp
     assert payload == "fp32", payload
     dist.all_reduce(flat_grads, group=group)
     return 1.0 / world
+
+
+# measurement record of the training step's gradient exchange (bench.py / tools/train_bench.py reset and read it): steps finished, segment
+# collectives issued, payload bytes one rank handed to the collective library, host seconds inside segment_ready + finish
+GRAD_STATS = {"steps": 0, "segments": 0, "bytes": 0, "host_s": 0.0}
+
+
+class GradientExchange:
+    """The data-parallel gradient exchange in SEGMENTS, each issued the moment the backward pass has finished writing it -- what
+    DistributedDataParallel's bucketed all-reduce does behind the reference's training loop (tools/train_net.py:96,110-117: buckets are
+    reduced while autograd is still walking the earlier layers).  `allreduce_gradients` is the monolithic form (one collective behind
+    the whole backward pass, fully exposed); this is the form the trainer's step uses.
+
+    segments: (lo, hi) element ranges of the flat gradient buffer in the order the backward pass COMPLETES them (box head, FPN + RPN
+    head, res5, res4, res3 for the detector: the flat buffer is laid out in forward order, so the ranges run back to front).  Every
+    boundary is a multiple of 4 elements (the casts move 4 per lane).
+      begin()                    once per step, before the backward pass
+      segment_ready(i, stream)   right after the LAST launch that writes segment i has been enqueued on `stream`: records an event there;
+                                 the communication stream (streams.side(2)) waits for it, casts the segment (bf16 payload), hands it to
+                                 the collective (async_op: RCCL's own stream runs it) and queues the widening cast behind it -- the host
+                                 never waits, the main stream is not touched
+      finish() -> factor         the current stream waits for the communication stream; returns what the optimiser multiplies the
+                                 gradient by (1 / world for the fp32 payload, 1.0 for bf16: divided before rounding, as in
+                                 allreduce_gradients)
+    Element-wise the arithmetic is that of allreduce_gradients (a sum all-reduce does not mix elements): at world 2 the parameters after
+    any number of steps are bit-identical to the monolithic form's (tests/test_distributed.py, tests/test_gpu_training.py).
+    Test rigs: host tensors go through gloo directly; device tensors on a gloo group (several ranks on one GPU) are staged through the
+    host per segment -- at segment_ready time, so a segment announced too early still shows up as a wrong bit.
+    force=True runs the segments even at world 1 (measurement: every launch, event and collective of the N > 1 step on a 1-GPU box)."""
+
+    def __init__(self, flat_grads: torch.Tensor, segments, group=None, payload: str = "fp32", force: bool = False):
+        assert payload in ("fp32", "bf16"), payload
+        n = flat_grads.numel()
+        segs = [(int(lo), int(hi)) for lo, hi in segments]
+        assert sorted(segs)[0][0] == 0 and sorted(segs)[-1][1] == n and all(a[1] == b[0] for a, b in zip(sorted(segs), sorted(segs)[1:])), \
+            f"segments must tile [0, {n}): {segs}"
+        assert all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in segs), segs  # (the casts move 4 elements per lane)
+        self.flat, self.segments, self.group, self.payload = flat_grads, segs, group, payload
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.active = on and (self.world > 1 or force)
+        self._g16 = None
+        self._pending: list = []
+        self._issued: set = set()
+        self._open = False
+        self._events: dict = {}
+
+    # ---- one step
+    def begin(self):
+        for fin in self._pending:  # (a step whose optimiser update never came: complete its collectives, every rank has issued them)
+            fin()
+        self._pending, self._issued, self._open = [], set(), True
+
+    def segment_ready(self, i: int, stream=None):
+        if not (self.active and self._open):
+            return
+        import time as _time
+
+        t0 = _time.perf_counter()
+        assert i not in self._issued, f"segment {i} announced twice"
+        self._issued.add(i)
+        lo, hi = self.segments[i]
+        seg = self.flat[lo:hi]
+        GRAD_STATS["segments"] += 1
+        GRAD_STATS["bytes"] += (hi - lo) * (2 if self.payload == "bf16" else 4)
+        if not seg.is_cuda:
+            self._pending.append(self._host_segment(seg))
+        elif dist.get_backend(self.group) == "gloo":
+            ev = self._event(i)
+            ev.record(stream or torch.cuda.current_stream())
+            ev.synchronize()  # (test rig: the snapshot is taken NOW -- what an early announcement would get wrong)
+            host = seg.cpu()
+            done = self._host_segment(host)
+            self._pending.append(lambda: (done(), seg.copy_(host)))
+        else:
+            self._device_segment(i, seg, lo, hi, stream or torch.cuda.current_stream())
+        GRAD_STATS["host_s"] += _time.perf_counter() - t0
+
+    def finish(self) -> float:
+        if not (self.active and self._open):
+            return allreduce_gradients(self.flat, self.group, payload=self.payload)
+        import time as _time
+
+        t0 = _time.perf_counter()
+        missing = set(range(len(self.segments))) - self._issued
+        assert not missing, f"GradientExchange.finish(): segments {sorted(missing)} were never announced"
+        for fin in self._pending:
+            fin()
+        self._pending, self._open = [], False
+        if self.flat.is_cuda and dist.get_backend(self.group) != "gloo":
+            torch.cuda.current_stream().wait_stream(self._comm())
+        GRAD_STATS["steps"] += 1
+        GRAD_STATS["host_s"] += _time.perf_counter() - t0
+        return 1.0 if self.payload == "bf16" else 1.0 / self.world
+
+    # ---- forms
+    def _event(self, i):
+        ev = self._events.get(i)
+        if ev is None:
+            ev = self._events[i] = torch.cuda.Event()
+        return ev
+
+    def _comm(self):
+        from .streams import side
+
+        return side(2, self.flat.device)
+
+    def _host_segment(self, seg: torch.Tensor):
+        """Host tensor `seg` (a view of the flat buffer, or a staged copy): the collective starts now, the returned thunk completes it."""
+        if self.payload == "bf16":
+            g16 = (seg * (1.0 / self.world)).to(torch.bfloat16)
+            w = dist.all_reduce(g16, group=self.group, async_op=True)
+            return lambda: (w.wait(), seg.copy_(g16.to(torch.float32)))
+        w = dist.all_reduce(seg, group=self.group, async_op=True)
+        return w.wait
+
+    def _device_segment(self, i, seg, lo, hi, stream):
+        from . import _lib
+
+        comm = self._comm()
+        ev = self._event(i)
+        ev.record(stream)
+        cur = torch.cuda.current_stream()
+        torch.cuda.set_stream(comm)  # (the collective orders itself behind the CURRENT stream of the call)
+        try:
+            comm.wait_event(ev)
+            if self.payload == "bf16":
+                if self._g16 is None:
+                    self._g16 = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
+                g16 = self._g16[lo:hi]
+                st = comm.cuda_stream
+                _lib.check(_lib.lib().a3d_f32_to_bf16_scaled(seg.data_ptr(), g16.data_ptr(), hi - lo, 1.0 / self.world, st), "a3d_f32_to_bf16_scaled")
+                dist.all_reduce(g16, group=self.group, async_op=True).wait()  # (the communication stream waits; the host does not)
+                _lib.check(_lib.lib().a3d_bf16_to_f32(g16.data_ptr(), seg.data_ptr(), hi - lo, st), "a3d_bf16_to_f32")
+            else:
+                dist.all_reduce(seg, group=self.group, async_op=True).wait()
+        finally:
+            torch.cuda.set_stream(cur)

@@ -35,8 +35,7 @@ class DeferredReduces:
         self.device = device
         self.ws = {}      # dw.data_ptr() -> persistent workspace tensor
         self.items = []   # WgradDesc copies of this step
-        self._host = None
-        self._dev = None
+        self._tables = {}  # flush slot -> (host bytes, device copy) of the table last uploaded for it
 
     def workspace(self, dw: torch.Tensor, nbytes: int) -> torch.Tensor:
         t = self.ws.get(dw.data_ptr())
@@ -44,7 +43,9 @@ class DeferredReduces:
             t = self.ws[dw.data_ptr()] = torch.empty(nbytes // 4, device=self.device, dtype=torch.float32)
         return t
 
-    def flush(self):
+    def flush(self, slot: int = 0):
+        """Reduce everything parked since the last flush, on the current stream.  `slot` names the call site when a step flushes in
+        several pieces (the trainer's gradient-exchange segments): each keeps its own uploaded table."""
         n = len(self.items)
         if not n:
             return
@@ -53,13 +54,14 @@ class DeferredReduces:
         for i in range(n):  # (the reduce reads neither operand: keep the table identical from step to step)
             arr[i].x = arr[i].dy = None
         raw = C.string_at(C.addressof(arr), n * sz)
-        if raw != self._host:
+        host, dev = self._tables.get(slot, (None, None))
+        if raw != host:
             # workspaces, gradients and shapes are the same every step (same batch size), so the table is uploaded once; a change
             # (first step, another batch size) drains the stream first -- a pending reduce may still be reading the old table
             torch.cuda.current_stream().synchronize()
-            self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._host = raw
-        _lib.check(_lib.lib().a3d_wgrad_reduce_batch(self._dev.data_ptr(), n, _stream()), "a3d_wgrad_reduce_batch")
+            dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._tables[slot] = (raw, dev)
+        _lib.check(_lib.lib().a3d_wgrad_reduce_batch(dev.data_ptr(), n, _stream()), "a3d_wgrad_reduce_batch")
         self.items = []
 
 

@@ -34,7 +34,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, ops, train_ops as T
-from .parallel import allreduce_gradients
+from .parallel import GradientExchange, allreduce_gradients
 from .ops import ACT_NONE, ACT_RELU, PackedConv
 
 FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
@@ -43,6 +43,11 @@ FPN_STRIDES = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
 BATCHED_LAUNCHES = os.environ.get("A3D_TRAIN_BATCHED", "1") != "0"
 WGRAD_SIDE_STREAM = os.environ.get("A3D_TRAIN_WGRAD_STREAM", "1") != "0"  # weight gradients on a side stream beside the data-gradient chain (same bits)
 RPN_BWD_STREAM = os.environ.get("A3D_TRAIN_RPN_STREAM", "1") != "0"  # the RPN head's backward as soon as its loss exists, on a second stream (same bits)
+# The gradient exchange of `step()`: "1" (default) = in segments under the backward pass (parallel.GradientExchange), "0" = one collective
+# behind it (parallel.allreduce_gradients; the same bits at world 2), "force" = the segmented form even at world 1 (measurement only),
+# "late" / "force-late" = the same segments, every one announced only BEHIND the whole backward pass (the equality partner of the tests: a
+# segment announced too early shows up as a bit that differs from this form's).
+GRAD_OVERLAP = os.environ.get("A3D_TRAIN_GRAD_OVERLAP", "1")
 RES_STAGES = (("res3", 4, 128, 512), ("res4", 6, 256, 1024), ("res5", 3, 512, 2048))  # name, blocks, mid, out
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
 
@@ -145,7 +150,7 @@ class DetectorTrainer:
     copied into the flat buffer at construction and written back by `export_state_dict`)."""
 
     def __init__(self, model, solver: Optional[SolverCfg] = None, seed: int = 2020, process_group=None, precision: str = "bf16x3",
-                 grad_payload: Optional[str] = None, storage: Optional[str] = None):
+                 grad_payload: Optional[str] = None, storage: Optional[str] = None, grad_overlap: Optional[str] = None):
         """precision: "bf16x3" (the default since round 3: fp32-GRADE products from exact 3-way bf16 operand splits, six bf16 MFMAs per
         fp32 multiply-add -- no block exponents, so filters that change every step need no maxima; 140 | 319 images/s at 2 | 16
         images per GPU against 123 | 270 of the fp32-input MFMA), "fp32" (fp32-input MFMA everywhere) or "bf16" -- the reference's
@@ -157,6 +162,9 @@ class DetectorTrainer:
         # step in _prepare_filters -- and for every weight gradient
         # gradient all-reduce payload: bf16 in the bf16 step (configs[4]: DDP's bf16_compress_hook semantics), fp32 otherwise
         self.grad_payload = grad_payload or ("bf16" if precision == "bf16" else "fp32")
+        self.grad_overlap = GRAD_OVERLAP if grad_overlap is None else str(grad_overlap)  # "1" | "0" | "force" (see GRAD_OVERLAP)
+        self._xchg: Optional[GradientExchange] = None
+        self._xchg_live = False
         # storage of the ResNet stages' activations and gradients (res3-res5: the bulk of the step's activation bytes): bf16 in the bf16
         # step -- what autocast itself keeps (conv outputs are bf16 tensors under torch.autocast) -- unless storage="fp32" is asked for.
         # FPN / RPN / box-head tensors, the pyramid gradients (float atomics) and everything a loss kernel reads stay fp32.
@@ -255,6 +263,17 @@ class DetectorTrainer:
                 ly.U = self._U[uoff:uoff + nul].view(16, ly.rows, ly.cin)
                 ly.Ut = self._Ut[uoff:uoff + nul].view(16, ly.cin, ly.rows)
                 uoff += nul
+        # Gradient-exchange segments in the order the backward pass completes them.  The flat buffer is in forward order (res3, res4, res5,
+        # FPN, RPN head, box head), the backward pass walks it back to front, so the segments are contiguous ranges taken from the end.
+        first = {}
+        o = 0
+        for ly in L.values():
+            first.setdefault("box" if ly.name.startswith("roi_heads.") else "fpn" if not ly.name.startswith("backbone.bottom_up.")
+                             else ly.name.split(".")[2], o)
+            o += ly.rows * ly.k * ly.k * ly.cin + (ly.rows if has_bias(ly) else 0)
+        cuts = [first["res3"], first["res4"], first["res5"], first["fpn"], first["box"], n]
+        assert cuts[0] == 0 and all(a < b and a % 4 == 0 for a, b in zip(cuts, cuts[1:])), cuts
+        self.grad_segments = [(cuts[i], cuts[i + 1]) for i in (4, 3, 2, 1, 0)]  # box head | FPN + RPN head | res5 | res4 | res3
         self.load_state_dict(sd)
 
     def _views(self, ly: _Layer, sd_like: bool, buf_w, buf_b):
@@ -474,6 +493,27 @@ class DetectorTrainer:
             ten.record_stream(main)
         return hw, out + (ready,)
 
+    def _segment_done(self, i: int):
+        """Every launch that writes gradient segment i (self.grad_segments) has been enqueued: fold the segment's parked slice reductions
+        and hand it to the gradient exchange.  All weight gradients of a step run in call order on ONE stream (the side stream, or the main
+        one), so 'behind the last of them on that stream' is behind all of them.  Without a live exchange (world 1, forward_backward called
+        on its own) nothing happens here and the one flush at the end of the backward pass folds everything, as before."""
+        if not self._xchg_live:
+            return
+        if self.grad_overlap.endswith("late"):
+            self._late.append(i)
+            return
+        side, main = self._wg_stream, self._cur_stream
+        if side is not None:
+            torch.cuda.set_stream(side)
+        try:
+            if getattr(self, "_defer", None) is not None:
+                self._defer.flush(slot=1 + i)
+        finally:
+            if side is not None:
+                torch.cuda.set_stream(main)
+        self._xchg.segment_ready(i, side if side is not None else main)
+
     def _wgrad_now(self, ly: _Layer, x, dy, accumulate=False):
         # The slice reductions of the step's weight gradients are folded in ONE launch at the end of the backward pass (self._defer.flush()
         # in forward_backward): 63 reduce launches of ~17 us each were 11 % of the step at the reference's 2 images per GPU.  Layers whose
@@ -488,13 +528,22 @@ class DetectorTrainer:
 
     # ------------------------------------------------------------------------------------------ the step
     def forward_backward(self, frames_u8: torch.Tensor, gt_boxes: Sequence[torch.Tensor], gt_classes: Sequence[torch.Tensor],
-                         samples: Optional[dict] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
+                         samples: Optional[dict] = None, exchange: bool = False) -> Tuple[Dict[str, torch.Tensor], dict]:
         """frames_u8 [B,H,W,3] uint8 BGR on the device; per image gt_boxes [G,4] fp32 / gt_classes [G] int64 (CPU or device).
-        Fills self.grads; returns ({loss name: 0-d device tensor}, aux with the sampled index sets)."""
+        Fills self.grads; returns ({loss name: 0-d device tensor}, aux with the sampled index sets).
+        exchange=True (what `step` and the reference-style loop pass): the data-parallel gradient exchange starts INSIDE the backward pass,
+        segment by segment (parallel.GradientExchange), and `optimizer_step` must follow -- until it has, self.grads is in flight."""
         saved, ops.BF16_SPLITK_AUTO = ops.BF16_SPLITK_AUTO, True  # (split-K by batch size: the training step's launches only, ops.py)
         self._cur_stream, self._wg_calls = torch.cuda.current_stream(), 0
         if not hasattr(self, "_wg_events"):
             self._wg_events = []
+        self._xchg_live, self._late = False, []
+        if exchange and self.grad_overlap != "0":
+            if self._xchg is None:
+                self._xchg = GradientExchange(self.grads, self.grad_segments, self.pg, self.grad_payload, force=self.grad_overlap.startswith("force"))
+            if self._xchg.active:
+                self._xchg.begin()
+                self._xchg_live = True
         try:
             return self._forward_backward(frames_u8, gt_boxes, gt_classes, samples)
         finally:
@@ -667,6 +716,7 @@ class DetectorTrainer:
         self._wgrad(L[bh + "fc2"], h1, dh2)
         dh1 = self._conv(dh2, L[bh + "fc2"].bwd(), gate=h1, out_dtype=st)
         self._wgrad(L[bh + "fc1"], xrow, dh1)
+        self._segment_done(0)  # box head + predictor: 13.9 M of the 41 M gradients leave at the very start of the backward pass
         dpooled = self._conv(dh1, L[bh + "fc1"].bwd())  # [M,1,1,12544]
         if early is not None:  # the RPN head's term of every level is there already (second stream): the pooler's backward adds onto it
             dP, dp6, done = early
@@ -689,6 +739,7 @@ class DetectorTrainer:
             if l > 2:
                 T.sumpool2_add(dprev[l - 1], dprev[l])
             self._wgrad(L[f"backbone.fpn_lateral{l}"], res[f"res{l}"], dprev[l])
+        self._segment_done(1)  # FPN + RPN head (the RPN head's weight gradients were enqueued on the same stream earlier)
         # ---- ResNet backward
         dx_up = None  # gradient arriving at a stage output from the stage above (un-gated)
         for name, nblk, _mid, _cout in reversed(RES_STAGES):
@@ -713,6 +764,7 @@ class DetectorTrainer:
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
                     g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
+            self._segment_done({"res5": 2, "res4": 3, "res3": 4}[name])
         if self._wg_stream is not None:
             self._cur_stream.wait_stream(self._wg_stream)  # every weight gradient has been launched and is waited for here
         if getattr(self, "_defer", None) is not None:
@@ -720,6 +772,9 @@ class DetectorTrainer:
             # measured slower the finer the pieces -- 352 | 347 | 342 | 338 images/s at 2 images per GPU for one | 24 | 12 | 6 layers per
             # flush: the reduce is HBM-bound and takes its bandwidth from the chain it runs beside.)
             self._defer.flush()
+        for i in self._late:  # ("late" forms: every segment behind the whole backward pass, on the main stream)
+            self._xchg.segment_ready(i, self._cur_stream)
+        self._late = []
         relu_outputs += list(t) + [h1.view(M, -1), h2.view(M, -1)]
         aux = dict(relu_outputs=relu_outputs, anchor_labels=labels_d, roi_index=roi_index, roi_count=rcount_d, roi_cls=roi_cls,
                    proposals=(pb, pcount), heads=heads, feats=feats, pred=pred.view(M, 32), roi_boxes=roi_boxes, anchor_match=(midx, lab))
@@ -733,12 +788,15 @@ class DetectorTrainer:
 
     def optimizer_step(self):
         s = self.s
-        scale = allreduce_gradients(self.grads, self.pg, payload=self.grad_payload)  # ONE collective: the flat gradient buffer
+        if self._xchg_live:  # the segments left during the backward pass: wait for the communication stream
+            scale, self._xchg_live = self._xchg.finish(), False
+        else:  # ONE collective behind the backward pass: the flat gradient buffer
+            scale = allreduce_gradients(self.grads, self.pg, payload=self.grad_payload)
         T.sgd_momentum(self.params, self.grads, self.momentum, lr=lr_at(self.iter, s), momentum=s.momentum, weight_decay=s.weight_decay,
                        grad_scale=scale, first=self.iter == 0)
         self.iter += 1
 
     def step(self, frames_u8, gt_boxes, gt_classes, samples=None):
-        losses, aux = self.forward_backward(frames_u8, gt_boxes, gt_classes, samples)
+        losses, aux = self.forward_backward(frames_u8, gt_boxes, gt_classes, samples, exchange=True)
         self.optimizer_step()
         return losses, aux

@@ -111,7 +111,7 @@ def instances_to_coco_json(instances: Instances, img_id) -> List[dict]:
 
 
 class PlaneRCNN_Branch:
-    def __init__(self, cfg, cpu_device="cpu", load_weights: bool = True):
+    def __init__(self, cfg, cpu_device="cpu", load_weights: bool = True, predictor=None):
         # The host side of the per-frame loop is small tensor glue (RLE, json, record building).  With torch's default
         # intra-op pool (one OpenMP worker per core, 128-256 on an MI355X host) the workers spin after every tiny CPU op
         # and starve the HIP runtime's own threads: measured 40-70 ms stalls of the next frame every few frames (31 fps
@@ -119,7 +119,8 @@ class PlaneRCNN_Branch:
         n = int(os.environ.get("A3D_HOST_THREADS", "8"))
         if n > 0 and torch.get_num_threads() > n:
             torch.set_num_threads(n)
-        self.predictor = DefaultPredictor(cfg, load_weights=load_weights)
+        # (predictor: an already built DefaultPredictor-like object with `.model` -- a caller that holds the detector does not build a second)
+        self.predictor = predictor if predictor is not None else DefaultPredictor(cfg, load_weights=load_weights)
         self._cpu_device = cpu_device
         self._device = torch.device(cfg.MODEL.DEVICE)
         self._K_inv_dot_xy_1 = torch.FloatTensor(get_K_inv_dot_xy_1()).to(self._device)

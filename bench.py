@@ -638,27 +638,58 @@ def main():
             result["gpu_over_cpu_batch8"] = round(fps / base["batch8_frames_per_s"], 1)
         if use_dist:
             barrier()
+    # ---- numeric leaves the driver's record keeps in full (it stores `roofline`, `cpu_baseline` and `config` whole and only NAMES the other
+    # top-level keys): the like-for-like arithmetics, the operating points of SURVEY 8d and the reference's unchanged per-frame loop
+    if alt:
+        result["roofline"]["like_for_like"] = {
+            k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "frac": v["roofline"]["frac"], "peak": v["roofline"]["peak"],
+                "kernel": v["roofline"]["kernel"]} for k, v in alt.items()}
+        result["roofline"]["like_for_like"]["note"] = ("the same 64-frame step in the two arithmetics that multiply full 24-bit operands, as BASELINE "
+                                                       "configs[2]'s 'fp32' reads: bf16x3 = exact 3-way bf16 operand splits, fp32 = fp32-input MFMA")
+    if "operating_points" in extra:
+        result["roofline"]["operating_points"] = {k[0]: {"value": v["value"], "ms_per_step": v["ms_per_step"], "detections_per_frame": v["detections_per_frame"]}
+                                                  for k, v in extra["operating_points"].items()}
+    if "value_with_transfers" in extra:
+        result["roofline"]["value_transfer_inclusive"] = extra["value_with_transfers"]["value"]
+    if world == 1 and not args.no_operating_points:
+        # the reference's loop shape (tools/inference.py:215-228: one frame per model call, host records per frame), unchanged, on this model
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from loop_bench import loop_b1
+
+        result["roofline"]["loop_b1"] = loop_b1(model, cfg, n=64, conf_threshold=args.score_thresh)
+        result["roofline"]["loop_b1"]["note"] = ("tools/loop_bench.py: PlaneRCNN_Branch.inference -> process -> create_instances per frame, 64 frames after 4 "
+                                                 "untimed ones; the batched figure is `value`")
     if not args.no_train_leg:
         # BASELINE configs[4] where the driver sees it: a short leg of the step1_bbox training step (bf16 autocast arithmetic, as the config
         # asks) at the reference's 2 images per GPU and at 16, each with its own roofline object (dominant kernel + whole step) and, on
-        # rank 0 at N = 1, the CPU port timed on the host cores.  After everything else: it cannot disturb the detection figures.
+        # rank 0 at N = 1, the CPU port timed on the host cores (2-image leg only: the oracle's autograd step takes minutes at 16).  After
+        # everything else: it cannot disturb the detection figures.  The trainer takes the detector that is already resident (its frozen
+        # stem / res2 are used as they are, everything trainable is copied into the flat buffers) instead of building a second one.
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from train_bench import train_leg
+        from train_bench import exchange_probe, train_leg
 
-        del model, out
+        out = None
         torch.cuda.empty_cache()
         legs = {}
         for tb, tsteps in ((2, 10), (16, 10)):
-            r = train_leg(dev, tb, tsteps, 5, precision="bf16", cpu_baseline=(world == 1 and not args.no_cpu_baseline), rank=rank, world=world,
-                          dist=dist if use_dist else None)
+            r = train_leg(dev, tb, tsteps, 5, precision="bf16", cpu_baseline=(world == 1 and tb == 2 and not args.no_cpu_baseline), rank=rank, world=world,
+                          dist=dist if use_dist else None, model=model)
             roof = r["roofline"]
             legs[f"images_per_gpu_{tb}"] = {
                 "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "dtype": r["dtype"],
-                "config": r["config"],
-                "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "pipe", "launches", "avg_launch_ms", "whole_step")},
+                "config": r["config"], "launches_per_step": r.get("launches_per_step"), "collective": r.get("collective"),
+                "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "pipe", "launches", "avg_launch_ms", "whole_step", "source")},
                 "top_kernels": dict(list(roof["all_gemm_kernels"].items())[:6]),
                 **({"cpu_baseline": r["cpu_baseline"], "gpu_over_cpu": r["gpu_over_cpu"]} if "cpu_baseline" in r else {})}
+        if world == 1 and args.dist_backend == "nccl":
+            # the N > 1 step's gradient exchange on this box: every segment collective of the 2-image step on a ONE-rank RCCL group, against
+            # the same step without the exchange -> what the exchange leaves exposed (articulation3d_amd/parallel.py GradientExchange)
+            legs["images_per_gpu_2"]["collective"] = exchange_probe(dev, model, 2, 10, 5, dist_module=dist if use_dist else None)
         result["train_step"] = legs
+        result["roofline"]["train_step"] = {k: {"value": v["value"], "ms_per_step": v["ms_per_step"], "whole_step_frac": v["roofline"]["whole_step"]["frac"],
+                                                "dominant_frac": v["roofline"]["frac"], "launches_per_step": v.get("launches_per_step"),
+                                                **({"exposed_exchange_ms": v["collective"]["exposed_ms"]} if v.get("collective") and "exposed_ms" in v["collective"] else {})}
+                                            for k, v in legs.items()}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -178,6 +179,83 @@ def test_gradient_allreduce_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _xchg_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from articulation3d_amd.parallel import GRAD_STATS, GradientExchange, allreduce_gradients
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 4096 + 512
+    cuts = [0, 512, 1544, 3000, 4096, n]  # five uneven segments, completed back to front as the backward pass does
+    segs = [(cuts[i], cuts[i + 1]) for i in (4, 3, 2, 1, 0)]
+    ok = True
+    for payload in ("fp32", "bf16"):
+        gen = torch.Generator().manual_seed(100 + rank)
+        p_seg, p_mono = torch.zeros(n), torch.zeros(n)
+        g_seg = torch.zeros(n)
+        ex = GradientExchange(g_seg, segs, payload=payload)
+        assert ex.active and ex.world == world
+        for step in range(3):  # three "optimiser steps": parameters must stay bit-identical to the monolithic form's
+            g = torch.randn(n, generator=gen) * (1.0 + step)
+            g_mono = g.clone()
+            f_mono = allreduce_gradients(g_mono, payload=payload)
+            ex.begin()
+            for i, (lo, hi) in enumerate(segs):  # a segment is written, then announced; later segments are still "in the backward pass"
+                g_seg[lo:hi] = g[lo:hi]
+                ex.segment_ready(i)
+            f_seg = ex.finish()
+            ok = ok and f_seg == f_mono and bool(torch.equal(g_seg, g_mono))
+            p_seg -= 0.1 * f_seg * g_seg
+            p_mono -= 0.1 * f_mono * g_mono
+        ok = ok and bool(torch.equal(p_seg, p_mono)) and float(p_seg.abs().sum()) > 0
+    ok = ok and GRAD_STATS["segments"] == 2 * 3 * 5 and GRAD_STATS["steps"] == 6
+    # a segment that was never announced is an error on the rank that forgot it, before anything is applied
+    ex = GradientExchange(torch.zeros(n), segs)
+    ex.begin()
+    for i in range(4):
+        ex.segment_ready(i)
+    try:
+        ex.finish()
+        ok = False
+    except AssertionError:
+        ex.segment_ready(4)  # (complete the collective the other rank is in as well)
+        ex.finish()
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_in_segments_equals_the_monolithic_allreduce_gloo_world2():
+    """the training step's gradient exchange leaves in segments while the backward pass is still running
+    (parallel.GradientExchange; DDP's bucketed all-reduce behind tools/train_net.py:96,110-117).  On two gloo ranks, fp32 and bf16
+    payloads: gradients and the parameters after three steps are bit-identical to the one-collective form's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_gradient_exchange_single_process_is_inactive():
+    from articulation3d_amd.parallel import GradientExchange
+
+    g = torch.arange(16, dtype=torch.float32)
+    ex = GradientExchange(g, [(8, 16), (0, 8)])
+    assert not ex.active
+    ex.begin()
+    ex.segment_ready(0)
+    assert ex.finish() == 1.0 and torch.equal(g, torch.arange(16, dtype=torch.float32))
+    with pytest.raises(AssertionError):
+        GradientExchange(g, [(0, 8), (12, 16)])  # segments must tile the buffer
 
 
 def test_gradient_allreduce_single_process():

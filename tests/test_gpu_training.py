@@ -989,3 +989,44 @@ def test_bf16_pointwise_kernel_fuzz_against_the_tiled_one(ops):
         assert torch.equal(new, old), ((B, H, W, Cin, Cout, xdt, odt, has_res, has_gate), float((new.float() - old.float()).abs().max()))
         ran += 1
     assert ran == 120
+
+
+# ------------------------------------------------------------------------------------------ gradient exchange under the backward pass
+def _exchange_check(args, timeout=1500):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "tools/train_exchange_check.py", *args], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gradient_segments_leave_during_the_backward_pass_bit_identical_one_rccl_rank():
+    """VERDICT r5 item 2.  `DetectorTrainer.step` hands the flat gradient buffer to the collective in five segments (box head | FPN + RPN
+    head | res5 | res4 | res3), each the moment its last weight gradient has been enqueued -- on the real RCCL process group with one
+    rank (the 1-GPU box).  Against the same segments announced only BEHIND the whole backward pass: parameters, momenta and losses after
+    three steps bit-identical, for both payloads.  (The bf16 payload rewrites every segment with what the communication stream read: a
+    segment announced before its last weight gradient landed would differ.)"""
+    d = _exchange_check(["--mode", "world1", "--backend", "nccl", "--steps", "3"])
+    for payload in ("fp32", "bf16"):
+        r = d["result"][payload]
+        assert r["params_equal"] and r["momentum_equal"] and r["losses_equal"] and r["finite"], (payload, r)
+        assert r["segments_per_step"] == [5, 5] and r["forms"] == ["force", "force-late"], r
+    assert d["result"]["bf16"]["payload_bytes_per_step"] * 2 == d["result"]["fp32"]["payload_bytes_per_step"] > 160e6
+
+
+def test_gradient_segments_equal_the_monolithic_allreduce_two_gloo_ranks():
+    """Two ranks (gloo: both on this box's one GPU, different batches): the overlapped segmented exchange against ONE all-reduce behind the
+    backward pass (`A3D_TRAIN_GRAD_OVERLAP=0`, parallel.allreduce_gradients) -- parameters after three steps bit-identical, fp32 and
+    bf16 payloads (tools/train_net.py:96,110-117: DDP's bucketed, overlapped all-reduce)."""
+    d = _exchange_check(["--mode", "world2", "--backend", "gloo", "--steps", "3"])
+    assert d["world"] == 2
+    for payload in ("fp32", "bf16"):
+        r = d["result"][payload]
+        assert r["params_equal"] and r["momentum_equal"] and r["losses_equal"] and r["finite"], (payload, r)
+        assert r["segments_per_step"] == [5, 0], r

@@ -1,5 +1,8 @@
 """The reference's own per-frame loop (tools/inference.py:215-228) on this package: inference -> process -> create_instances,
-one frame at a time, timed; and the batched detect_clip on the same frames."""
+one frame at a time, timed; and the batched detect_clip on the same frames.
+
+    python tools/loop_bench.py            # the developer report (loop, segments, single-frame pass eager / graphed / fixed rows)
+`reference_loop(branch, frames)` and `loop_b1(model, cfg, n)` are what bench.py calls for `roofline.loop_b1`."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
@@ -7,74 +10,104 @@ from articulation3d_amd.utils.arti_vis import PlaneRCNN_Branch, create_instances
 from articulation3d_amd.utils.synthetic import synthetic_frames, calibrate_batchnorm
 from articulation3d_amd.pipeline import detect_clip
 
-cfg = get_cfg(); get_planercnn_cfg_defaults(cfg)
-cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "planercnn_inference.yaml"))
-cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.5
-torch.manual_seed(2020)
-branch = PlaneRCNN_Branch(cfg, load_weights=False)  # random init (no checkpoint offline), calibrated below
-model = branch.predictor.model
-frames = synthetic_frames(40)
-calibrate_batchnorm(model, torch.from_numpy(synthetic_frames(2, 2021)).cuda())
-def loop(fr):
+
+def reference_loop(branch, fr, conf_threshold=0.5):
+    """The loop body of tools/inference.py:215-228, unchanged: one frame per call, host records per frame."""
     out = []
     for im in fr:
         pred = branch.inference(im)
         d = branch.process(pred)
         out.append(create_instances(d["instances"], im.shape[:2], pred_planes=d["pred_plane"].numpy(), pred_rot_axis=d["pred_rot_axis"],
-                                    pred_tran_axis=d["pred_tran_axis"], conf_threshold=0.5))
+                                    pred_tran_axis=d["pred_tran_axis"], conf_threshold=conf_threshold))
     return out
-loop(frames[:4]); torch.cuda.synchronize()
-t = time.perf_counter(); p1 = loop(frames[4:36]); torch.cuda.synchronize(); t1 = (time.perf_counter() - t) / 32
-for _ in range(3):  # warm-up at the timed batch size (allocator growth, one-time filter splits of the bf16x3 mode)
-    detect_clip(model, frames[4:36], batch=32, conf_threshold=0.5)
-torch.cuda.synchronize()
-t = time.perf_counter(); p2 = detect_clip(model, frames[4:36], batch=32, conf_threshold=0.5); torch.cuda.synchronize(); t2 = (time.perf_counter() - t) / 32
-print(f"reference-style loop: {t1 * 1e3:.2f} ms/frame ({1 / t1:.1f} fps); detect_clip(batch 32): {t2 * 1e3:.2f} ms/frame ({1 / t2:.1f} fps); "
-      f"detections {sum(len(p.pred_boxes) for p in p1)} / {sum(len(p.pred_boxes) for p in p2)}")
 
-seg = [0.0, 0.0, 0.0]
-for im in frames[4:36]:
-    t0 = time.perf_counter(); pred = branch.inference(im); torch.cuda.synchronize(); t1 = time.perf_counter()
-    d = branch.process(pred); t2 = time.perf_counter()
-    create_instances(d["instances"], im.shape[:2], pred_planes=d["pred_plane"].numpy(), pred_rot_axis=d["pred_rot_axis"], pred_tran_axis=d["pred_tran_axis"], conf_threshold=0.5)
-    t3 = time.perf_counter()
-    seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2
-print("per frame ms: inference %.2f  process %.2f  create_instances %.2f" % tuple(1e3 * x / 32 for x in seg))
-x = torch.from_numpy(frames[4:5]).cuda()
-for _ in range(3): model.inference_batched(x)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): model.inference_batched(x)
-torch.cuda.synchronize(); print("inference_batched(B=1) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
 
-# the same single-frame pass replayed from a captured HIP graph (PlaneRCNN.inference_graphed): bits and time
-e = model.inference_batched(x, want_masks=True)
-er, ed, ec = e.records.clone(), e.depth.clone(), e.rec_count.clone()
-g = model.inference_graphed(x, want_masks=True)
-torch.cuda.synchronize()
-same = bool(torch.equal(g.records, er) and torch.equal(g.depth, ed) and torch.equal(g.rec_count, ec))
-x2 = torch.from_numpy(frames[9:10]).cuda()
-e2 = model.inference_batched(x2, want_masks=True)
-er2, em2 = e2.records.clone(), e2.masks.clone()
-g2 = model.inference_graphed(x2, want_masks=True)
-torch.cuda.synchronize()
-same = same and bool(torch.equal(g2.records, er2) and torch.equal(g2.masks, em2))
-for _ in range(3): model.inference_graphed(x)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): model.inference_graphed(x)
-torch.cuda.synchronize(); print("inference_graphed(B=1) ms: %.2f  (bits equal to the eager pass: %s)" % ((time.perf_counter() - t0) / 20 * 1e3, same))
-for nb in (2,):
-    xb = torch.from_numpy(frames[4:4 + nb]).cuda()
-    for _ in range(3): model.inference_batched(xb); model.inference_graphed(xb)
+class _Holder:
+    def __init__(self, model):
+        self.model = model
+
+
+def loop_b1(model, cfg, n=64, warm=4, seed=2020, conf_threshold=0.5):
+    """Frames per second of `model` through the reference's unchanged per-frame loop on `n` synthetic frames (after `warm` untimed ones)."""
+    branch = PlaneRCNN_Branch(cfg, load_weights=False, predictor=_Holder(model))
+    frames = synthetic_frames(n + warm, seed)
+    reference_loop(branch, frames[:warm], conf_threshold)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    recs = reference_loop(branch, frames[warm:], conf_threshold)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    return {"frames_per_s": round(1.0 / dt, 2), "ms_per_frame": round(1e3 * dt, 3), "frames": n,
+            "detections_per_frame": round(sum(len(p.pred_boxes) for p in recs) / n, 2)}
+
+
+def main():
+    cfg = get_cfg()
+    get_planercnn_cfg_defaults(cfg)
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "planercnn_inference.yaml"))
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.5
+    torch.manual_seed(2020)
+    branch = PlaneRCNN_Branch(cfg, load_weights=False)  # random init (no checkpoint offline), calibrated below
+    model = branch.predictor.model
+    frames = synthetic_frames(40)
+    calibrate_batchnorm(model, torch.from_numpy(synthetic_frames(2, 2021)).cuda())
+    loop = lambda fr: reference_loop(branch, fr)
+    loop(frames[:4]); torch.cuda.synchronize()
+    t = time.perf_counter(); p1 = loop(frames[4:36]); torch.cuda.synchronize(); t1 = (time.perf_counter() - t) / 32
+    for _ in range(3):  # warm-up at the timed batch size (allocator growth, one-time filter splits of the bf16x3 mode)
+        detect_clip(model, frames[4:36], batch=32, conf_threshold=0.5)
+    torch.cuda.synchronize()
+    t = time.perf_counter(); p2 = detect_clip(model, frames[4:36], batch=32, conf_threshold=0.5); torch.cuda.synchronize(); t2 = (time.perf_counter() - t) / 32
+    print(f"reference-style loop: {t1 * 1e3:.2f} ms/frame ({1 / t1:.1f} fps); detect_clip(batch 32): {t2 * 1e3:.2f} ms/frame ({1 / t2:.1f} fps); "
+          f"detections {sum(len(p.pred_boxes) for p in p1)} / {sum(len(p.pred_boxes) for p in p2)}")
+
+    seg = [0.0, 0.0, 0.0]
+    for im in frames[4:36]:
+        t0 = time.perf_counter(); pred = branch.inference(im); torch.cuda.synchronize(); t1 = time.perf_counter()
+        d = branch.process(pred); t2 = time.perf_counter()
+        create_instances(d["instances"], im.shape[:2], pred_planes=d["pred_plane"].numpy(), pred_rot_axis=d["pred_rot_axis"], pred_tran_axis=d["pred_tran_axis"], conf_threshold=0.5)
+        t3 = time.perf_counter()
+        seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2
+    print("per frame ms: inference %.2f  process %.2f  create_instances %.2f" % tuple(1e3 * x / 32 for x in seg))
+    x = torch.from_numpy(frames[4:5]).cuda()
+    for _ in range(3): model.inference_batched(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): model.inference_batched(xb)
-    torch.cuda.synchronize(); te = (time.perf_counter() - t0) / 20 * 1e3; t0 = time.perf_counter()
-    for _ in range(20): model.inference_graphed(xb)
-    torch.cuda.synchronize(); print("B=%d: eager %.2f ms, graph %.2f ms" % (nb, te, (time.perf_counter() - t0) / 20 * 1e3))
-model.roi_heads.fixed_rows = True  # the eager pass without its one host read (head tensors sized for every detection slot)
-for _ in range(3): model.inference_batched(x)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): model.inference_batched(x)
-torch.cuda.synchronize(); print("inference_batched(B=1, fixed_rows) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
-f = model.inference_batched(x, want_masks=True)
-print("fixed_rows bits equal:", bool(torch.equal(f.records, er) and torch.equal(f.depth, ed)))
-model.roi_heads.fixed_rows = False
+    for _ in range(20): model.inference_batched(x)
+    torch.cuda.synchronize(); print("inference_batched(B=1) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
+
+    # the same single-frame pass replayed from a captured HIP graph (PlaneRCNN.inference_graphed): bits and time
+    e = model.inference_batched(x, want_masks=True)
+    er, ed, ec = e.records.clone(), e.depth.clone(), e.rec_count.clone()
+    g = model.inference_graphed(x, want_masks=True)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(g.records, er) and torch.equal(g.depth, ed) and torch.equal(g.rec_count, ec))
+    x2 = torch.from_numpy(frames[9:10]).cuda()
+    e2 = model.inference_batched(x2, want_masks=True)
+    er2, em2 = e2.records.clone(), e2.masks.clone()
+    g2 = model.inference_graphed(x2, want_masks=True)
+    torch.cuda.synchronize()
+    same = same and bool(torch.equal(g2.records, er2) and torch.equal(g2.masks, em2))
+    for _ in range(3): model.inference_graphed(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): model.inference_graphed(x)
+    torch.cuda.synchronize(); print("inference_graphed(B=1) ms: %.2f  (bits equal to the eager pass: %s)" % ((time.perf_counter() - t0) / 20 * 1e3, same))
+    for nb in (2,):
+        xb = torch.from_numpy(frames[4:4 + nb]).cuda()
+        for _ in range(3): model.inference_batched(xb); model.inference_graphed(xb)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): model.inference_batched(xb)
+        torch.cuda.synchronize(); te = (time.perf_counter() - t0) / 20 * 1e3; t0 = time.perf_counter()
+        for _ in range(20): model.inference_graphed(xb)
+        torch.cuda.synchronize(); print("B=%d: eager %.2f ms, graph %.2f ms" % (nb, te, (time.perf_counter() - t0) / 20 * 1e3))
+    model.roi_heads.fixed_rows = True  # the eager pass without its one host read (head tensors sized for every detection slot)
+    for _ in range(3): model.inference_batched(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): model.inference_batched(x)
+    torch.cuda.synchronize(); print("inference_batched(B=1, fixed_rows) ms: %.2f" % ((time.perf_counter() - t0) / 20 * 1e3))
+    f = model.inference_batched(x, want_masks=True)
+    print("fixed_rows bits equal:", bool(torch.equal(f.records, er) and torch.equal(f.depth, ed)))
+    model.roi_heads.fixed_rows = False
+
+
+if __name__ == "__main__":
+    main()

@@ -57,14 +57,18 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
             dist.barrier()
         torch.cuda.synchronize()
 
+    from articulation3d_amd import parallel as _par
+
     for _ in range(warmup):
         tr.step(frames, gtb, gtc)
     barrier()
+    _par.GRAD_STATS.update(steps=0, segments=0, bytes=0, host_s=0.0)
     t0 = time.perf_counter()
     for _ in range(steps):
         losses, _ = tr.step(frames, gtb, gtc)
     barrier()
     elapsed = time.perf_counter() - t0
+    gstats = dict(_par.GRAD_STATS)
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -94,7 +98,8 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
     issued = sum(v[3] * PIPE_FLOPS_PER_FMA[v[4]] for v in per.values())
     pipes = {v[4] for v in per.values() if v[3]}
     step_peak = max(PIPE_PEAK[q] for q in pipes)
-    roofline["source"] = "one fully instrumented step after the timed loop (every conv / linear / weight-gradient launch bracketed by HIP events)"
+    roofline["source"] = ("one fully instrumented step after the timed loop, run on ONE stream (every conv / linear / weight-gradient launch bracketed by HIP "
+                          "events, each kernel alone on the chip); `value` / `whole_step` use the timed steps, whose side streams overlap")
     roofline["gemm_kernels_ms_per_step"] = round(1e3 * sum(v[1] for v in per.values()), 3)
     roofline["whole_step"] = {"executed_tflop_per_step": round(issued / 1e12, 3), "achieved": round(issued / step_sec / 1e12, 2), "peak": step_peak,
                               "unit": "TFLOP/s", "frac": round(issued / step_sec / 1e12 / step_peak, 4),
@@ -113,10 +118,14 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
                                "losses, SGD momentum), random-init weights with calibrated BN, synthetic frames and boxes (arithmetic: see `dtype`)",
                    "precision": precision, "storage": tr.storage,
                    "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
-                   "gradient_exchange": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "none (1 GPU)"},
+                   "gradient_exchange": ("five segments of the flat gradient buffer, each all-reduced over RCCL under the rest of the backward pass "
+                                         "(parallel.GradientExchange)") if world > 1 else "none (1 GPU)"},
         "losses_last_step": {k: round(float(v), 5) for k, v in losses.items()},
         "roofline": roofline,
     }
+    if world > 1:  # (the exchange as it ran in the timed steps; what it leaves exposed is measured at N = 1 by exchange_probe)
+        result["collective"] = {"segments": gstats["segments"] // steps, "bytes": gstats["bytes"] // steps,
+                                "host_ms_per_step": round(1e3 * gstats["host_s"] / steps, 4), "payload": tr.grad_payload, "overlap": tr.grad_overlap}
     if cpu_baseline and rank == 0:
         from oracle import planercnn_oracle as O, train_oracle as TO
 
@@ -133,6 +142,56 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
                                   "caveat": "a stated baseline, never the target (oracle/train_oracle.py: torch.autograd over the CPU oracle)"}
         result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
     return result
+
+
+def exchange_probe(dev, model, batch, steps, warmup, precision="bf16", dist_module=None):
+    """What the N > 1 step's gradient exchange leaves EXPOSED, measured on one GPU: the step with every segment collective of
+    parallel.GradientExchange issued on a ONE-rank RCCL group (`grad_overlap="force"`: segment flushes, events, casts, all_reduce on RCCL's
+    stream, the optimiser's wait) against the same step without any exchange.  A one-rank all-reduce moves no bytes over xGMI -- the figure
+    is the launch / synchronisation cost of the overlapped form, not the transfer time (DESIGN.md section 6 prices that from link rates).
+    dist_module: torch.distributed when the caller already holds a process group; otherwise a one-rank nccl group is created and destroyed."""
+    import socket
+
+    import torch.distributed as dist
+
+    from articulation3d_amd import parallel
+    from articulation3d_amd.training import DetectorTrainer
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
+    own = not dist.is_initialized()
+    if own:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(dev))
+    if dist.get_world_size() != 1 or dist.get_backend() != "nccl":
+        return None
+    frames = torch.from_numpy(synthetic_frames(batch, seed=2020)).to(dev)
+    tg = synthetic_targets(batch, 2020)
+    gtb, gtc = [t[0] for t in tg], [t[1] for t in tg]
+    ms = {}
+    for form in ("0", "force", "0", "force"):  # (interleaved repeats: the better of two per form)
+        tr = DetectorTrainer(model, seed=2020, precision=precision, grad_overlap=form)
+        for _ in range(warmup):
+            tr.step(frames, gtb, gtc)
+        torch.cuda.synchronize()
+        parallel.GRAD_STATS.update(steps=0, segments=0, bytes=0, host_s=0.0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(frames, gtb, gtc)
+        torch.cuda.synchronize()
+        ms[form] = min(ms.get(form, 1e9), 1e3 * (time.perf_counter() - t0) / steps)
+        stats = dict(parallel.GRAD_STATS)
+        del tr
+    if own:
+        dist.destroy_process_group()
+    return {"segments": stats["segments"] // steps, "bytes": stats["bytes"] // steps, "exposed_ms": round(ms["force"] - ms["0"], 4),
+            "ms_per_step_with_exchange": round(ms["force"], 4), "ms_per_step_without": round(ms["0"], 4),
+            "host_ms_per_step": round(1e3 * stats["host_s"] / steps, 4), "payload": "bf16" if precision == "bf16" else "fp32",
+            "form": "five segments in backward-completion order (box head | FPN + RPN head | res5 | res4 | res3), each cast + all_reduce(async) on the "
+                    "communication stream the moment its last weight gradient is enqueued; ONE-rank RCCL group on this box",
+            "note": "exposed_ms = step with the exchange - step without, same process, best of two interleaved runs of 10 steps each"}
 
 
 def main():
