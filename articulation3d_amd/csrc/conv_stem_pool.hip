@@ -297,12 +297,10 @@ extern "C" int a3d_stem_conv_pool(const a3d_conv_desc *d, void *stream) {
     if ((size_t)d->B * d->H * d->W * 16 >= ((size_t)1 << 31)) return A3D_ERR_UNSUPPORTED;
     const int Hp = (d->Ho - 1) / 2 + 1, Wp = (d->Wo - 1) / 2 + 1;
     a3d_begin();
-    int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    // (one attribute query per call -- a few hundred ns, no 1 KiB hipDeviceProp_t fill on the host-bound 1-2 frame path; no static: the
+    // library keeps no process-global state and a second device of the process may have another CU count)
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     const int form = (int)a3d_dev_knob("A3D_STEM_TILE", 0);  // (developer builds, A/B runs: 2 = the 3 x 8 tile, two workgroups per CU)
     a3d_note_variant("stem_pool_kernel");
     // (measured at 64 frames: 6 x 9 tiles 0.705 ms, 3 x 8 tiles with two workgroups per CU 0.728 -- what a tile costs beside its MFMAs is

@@ -684,6 +684,7 @@ template <int WM, bool F16 = false, bool PS = false, int PP = 0>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kernel(const WinoArgs a, const int ntiles, const int nblk) {
     static_assert(PP == 0 || (F16 && !PS && WM == 4), "ping-pong: the 512-thread fp16x2 form (two waves per SIMD)");
     constexpr bool ML = PP > 0;
+    constexpr bool DMAV = F16;  // fp16x2: V arrives pre-split and pre-scaled, global -> LDS by DMA (every F16 schedule below)
     constexpr int NP = F16 ? 2 : 3;
     constexpr int TN = 2, BKT = 32, BM = 32 * WM, BN = X3W_BN, LKB = X3W_LKB, NT = 128 * WM, NW = 2 * WM;
     constexpr int TPR = BKT / 4, RPP = NT / TPR, XR = BM / RPP;  // 8 lanes x float4 per row, BM/2 rows per pass, 2 passes
@@ -719,7 +720,9 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void wino_gemm_x3w_kerne
     for (int i = 0; i < XR; ++i) {
         const int t = t0 + lr + RPP * i;
         xoff[i] = t < a.T ? (t * a.C + lc) * 4 : -1;
-        sxr[i] = (F16 && t < a.T) ? wino_v_scale(a, t / (a.Ty * a.Tx)) : 1.f;
+        // (F16 launches that move V by LDS-DMA never scale a loader row -- V is stored already scaled -- and the multi-level launcher hands
+        // them no in_amax / Ty / Tx at all: the read must not exist there, not merely be dead)
+        sxr[i] = (F16 && !DMAV && t < a.T) ? wino_v_scale(a, t / (a.Ty * a.Tx)) : 1.f;
     }
     const int lcs = ((((lc >> 3) ^ (lr >> 2)) & 3) << 3) | (lc & 7);  // (RPP is a multiple of 16: both passes share the swizzle)
     // weights: U3 [16][C/32][3][Cout][32] bf16; one (f, chunk, plane) tile of this workgroup's 128 rows is an 8 KiB run = 8 DMA

@@ -79,7 +79,9 @@ class _Packable(nn.Module):
     # machinery cost ~14 us per call -- 1.2 ms of host time per frame in the reference's per-frame loop, which is host-bound.  The (owning
     # dict, name) slots are therefore found once and only looked up afterwards: a tensor replaced in its slot (load_state_dict copies in
     # place, .to() / .cuda() replace buffers and parameter data) is seen through the lookup; anything that changes the SET of slots
-    # (attribute assignment on this module, _apply) drops the slot list.
+    # (attribute assignment on this module, _apply) drops the slot list; a slot added on a CHILD module later (child.register_buffer,
+    # add_module, a replaced grandchild -- none of which pass through this module's __setattr__) is caught by a structural fingerprint kept
+    # beside the list: the slot counts and the child identities of every module walked, compared on each call (~0.5 us for a conv + norm).
     def __setattr__(self, name, value):
         if name not in ("_pack_cache", "_pack_key", "_key_src"):
             self.__dict__["_key_src"] = None
@@ -89,13 +91,26 @@ class _Packable(nn.Module):
         self.__dict__["_key_src"] = None
         return super()._apply(fn, recurse)
 
+    @staticmethod
+    def _shape_of(mods):
+        n, kids = 0, []
+        for m in mods:
+            n += len(m._parameters) + len(m._buffers)
+            kids += [id(c) for c in m._modules.values()]
+        return n, tuple(kids)
+
     def _key(self):
-        src = self.__dict__.get("_key_src")
-        if src is None:
-            src = []
-            for m in self.modules():
+        cached = self.__dict__.get("_key_src")
+        if cached is not None:
+            src, mods, shape = cached
+            if shape != self._shape_of(mods):
+                cached = None
+        if cached is None:
+            src, mods = [], list(self.modules())
+            for m in mods:
                 src += [(m._parameters, k) for k in m._parameters] + [(m._buffers, k) for k in m._buffers]
-            self.__dict__["_key_src"] = src
+            shape = self._shape_of(mods)
+            self.__dict__["_key_src"] = (src, mods, shape)
         out = []
         for d, k in src:
             t = d.get(k)

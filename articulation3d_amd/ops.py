@@ -997,8 +997,13 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
         if pf is None:
             pf = pack_conv_ups_fused(phases)
             phases[0]._fused = pf if pf is not None else False
+        b3 = pinned or DEFAULT_PRECISION == 2
+        # (the bf16x3 launch of the fused form needs the pre-split filter, which _conv2d_launch builds from 192 columns on, and the phase-5
+        # launcher's 2^31-byte filter bound: a narrower or oversized layer runs the four per-phase launches below, as before round 5)
+        if pf and b3 and (pf.cols < 192 or pf.cols * pf.Kpad * 6 >= 2 ** 31):
+            pf = None
         if pf:  # (tune 15 / 16: never / always the patch-resident kernel of csrc/conv_ph4p.hip; 0: by the map's size)
-            return conv2d(x, pf, x2=x2, out=out, precision=2 if (pinned or DEFAULT_PRECISION == 2) else 3, tune=tune)
+            return conv2d(x, pf, x2=x2, out=out, precision=2 if b3 else 3, tune=tune)
     for p in phases:
         conv2d(x, p, x2=x2, out=out)
     return out

@@ -143,3 +143,77 @@ def test_matched_detections_end_to_end(hip_model, oracle, oracle_params, golden_
         assert all(d == 100 for d in s32["detections"])
     else:
         assert sum(s32["detections"]) > 0
+
+
+# ------------------------------------------------------------------------------------------ the flat 1e-4, end to end, on well-conditioned heads
+WELL_GAIN = float(os.environ.get("A3D_E2E_WELL_GAIN", "0.25"))  # rms of the data-dependent part W.h against a bias of norm 1 (see below)
+_HEAD_OUT = (("roi_heads.plane_head.param_pred", "raw_plane", 0, 3), ("roi_heads.axis_head.rotation", "raw_rot", 0, 2),
+             ("roi_heads.axis_head.offset", "raw_rot", 2, 3), ("roi_heads.axis_head.translation", "raw_tran", 0, 2))  # (layer, raw key, columns)
+
+
+def _well_conditioned_params(O, P, frames, thresh, gain):
+    """The last linear layer of each per-ROI head, rescaled BY VALUE for both paths: bias = a seeded vector of norm 1, weight scaled so that
+    the data-dependent part W.h has rms `gain` over the detections of these frames (pass 1 of the oracle supplies that rms; the
+    un-normalised axis offset gets the same treatment).  With the
+    random-init layers a raw head vector r = W.h is a sum of 1024 random-sign terms around zero -- |r| down to 1e-3 of the frame's largest,
+    and the shipped n = r / |r| amplifies any rounding by 1 / |r|; a trained regressor of unit normals produces |r| ~ 1.  Here every |r|
+    stays >= ~0.5 while the direction still moves with the ROI (rms `gain` radians)."""
+    ocfg = O.OracleCfg(score_thresh=thresh)
+    imgs = O.frames_to_chw(frames)
+    first = [O.detect(imgs[i:i + 1], P, ocfg)[0] for i in range(len(imgs))]
+    P2 = dict(P)
+    g = torch.Generator().manual_seed(606)
+    for name, raw, c0, c1 in _HEAD_OUT:
+        r = torch.cat([f[raw][:, c0:c1] for f in first])
+        rms = float(r.pow(2).mean().sqrt())
+        b = torch.randn(c1 - c0, generator=g)
+        P2[name + ".weight"] = P[name + ".weight"] * (gain / rms)
+        P2[name + ".bias"] = (b / b.norm()).to(P[name + ".bias"].dtype)
+    return P2
+
+
+@pytest.mark.parametrize("precision", [3, 2, 0], ids=lambda p: MODES[p])
+def test_flat_1e4_on_well_conditioned_heads_end_to_end(hip_model, oracle, oracle_params, golden_dir, precision):
+    """`north_star`'s criterion as written -- plane normals and axis parameters within 1e-4 relative of the reference
+    path's -- stated END TO END (each path on its own upstream tensors) against the fp32 oracle, in the regime where the criterion is
+    meaningful: raw head vectors of norm >= ~0.5 (see _well_conditioned_params; plane_head.py:80-82, axis_head.py:106,120).  The
+    random-init case above keeps the float64 yardstick, because there the reference's own fp32 arithmetic is 2e-4 .. 1.5e-3 from exact."""
+    from articulation3d_amd import ops
+    from oracle import matching as M
+
+    O, P, model = oracle, oracle_params, hip_model
+    thresh = 0.5
+    sel, frames = _frames(golden_dir, O)
+    P2 = _well_conditioned_params(O, P, frames, thresh, WELL_GAIN)
+    ocfg = O.OracleCfg(score_thresh=thresh)
+    imgs = O.frames_to_chw(frames)
+    o32 = [O.detect(imgs[i:i + 1], P2, ocfg)[0] for i in range(len(imgs))]
+    keys = [n + s for n, _, _, _ in _HEAD_OUT for s in (".weight", ".bias")]
+    saved = ops.DEFAULT_PRECISION
+    ops.DEFAULT_PRECISION = precision
+    model.roi_heads.box_predictor.test_score_thresh = thresh
+    model.load_state_dict({k: P2[k] for k in keys}, strict=False)
+    model.roi_heads.plane_head.keep_raw = model.roi_heads.axis_head.keep_raw = True
+    try:
+        out = model.inference_batched(torch.from_numpy(frames).cuda(), want_masks=True)
+        torch.cuda.synchronize()
+        got = M.gpu_frame_results(out)
+    finally:
+        model.load_state_dict({k: P[k] for k in keys}, strict=False)
+        model.roi_heads.box_predictor.test_score_thresh = 0.0
+        model.roi_heads.plane_head.keep_raw = model.roi_heads.axis_head.keep_raw = False
+        ops.DEFAULT_PRECISION = saved
+    vs32 = [M.compare_frame(g, o) for g, o in zip(got, o32)]
+    s32 = M.summarize(vs32)
+    norms = {name.rsplit(".", 1)[1]: [float(v) for f in o32 for v in f[raw][:, c0:c1].norm(dim=1)] for name, raw, c0, c1 in _HEAD_OUT}
+    report = dict(arithmetic=MODES[precision], gain=WELL_GAIN, detections=s32["detections"],
+                  min_raw_norm={k: min(v) for k, v in norms.items() if v}, max_raw_norm={k: max(v) for k, v in norms.items() if v},
+                  hip_vs_oracle_fp32={k: v for k, v in s32.items() if k.startswith("max_")})
+    print("\nwell-conditioned heads, end to end", json.dumps(report, indent=1))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_well_conditioned_{MODES[precision]}.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    assert sum(s32["detections"]) >= 20 and all(m["matched"] for m in vs32), s32
+    assert min(min(v) for v in norms.values() if v) >= 0.4, report["min_raw_norm"]  # (the regime the test is about)
+    for k in ("plane_rel", "rot_axis_rel", "tran_axis_rel"):  # the flat criterion of BASELINE.json north_star, on the shipped outputs
+        assert s32["max_" + k] <= 1e-4, (k, s32["max_" + k], report)

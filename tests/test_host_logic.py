@@ -366,3 +366,23 @@ def test_split_k_rule_of_the_bf16_conv_kernel_is_a_function_of_the_shape():
     for M, cols, K in ((100, 64, 32 * 24), (2400, 256, 32 * 1000), (1, 32, 32 * 24)):
         sk = ops._bf16_splitk(M, cols, K)
         assert 1 <= sk <= 8 and sk <= K // 32
+
+
+def test_pack_cache_key_sees_slots_added_or_replaced_on_child_modules():
+    """the pack cache looks its (dict, name) slots up once; a buffer registered on a CHILD later, or a child replaced, must
+    still change the key (a stale packed filter would be served silently otherwise)."""
+    import torch
+    from articulation3d_amd.modeling.layers import Conv2d, FrozenBatchNorm2d
+
+    m = Conv2d(8, 8, 1, bias=False, norm=FrozenBatchNorm2d(8))
+    k0 = m._key()
+    assert m._key() == k0
+    m.norm.register_buffer("extra", torch.zeros(1))
+    k1 = m._key()
+    assert k1 != k0 and len(k1) == len(k0) + 1
+    m._modules["norm"] = FrozenBatchNorm2d(8)  # (replaced without passing through this module's __setattr__)
+    k2 = m._key()
+    assert k2 != k1 and len(k2) == len(k0)
+    with torch.no_grad():
+        m.norm.weight.mul_(2.0)  # in-place edits are seen through the version counter, as before
+    assert m._key() != k2
