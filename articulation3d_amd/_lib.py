@@ -263,6 +263,7 @@ SIGNATURES = {
     "a3d_project_hypotheses": (C.c_int, [C.POINTER(SweepDesc), fptr]),
     "a3d_mask_iou_matrix": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_sgd_momentum": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
+    "a3d_sgd_momentum_bf16g": (C.c_int, [fptr, fptr, fptr, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fptr]),
     "a3d_f32_to_bf16_scaled": (C.c_int, [fptr, fptr, C.c_size_t, C.c_float, fptr]),
     "a3d_bf16_to_f32": (C.c_int, [fptr, fptr, C.c_size_t, fptr]),
 }

@@ -19,6 +19,13 @@
 // one-load-at-a-time walk and the batched walk now run in the same time (2.59 ms before the spatial order, 2.39 with it), and
 // giving each wave its own contiguous run of bins instead of every fourth bin was slower (2.52 ms: the four waves of a
 // workgroup no longer share their neighbouring cells in L1).
+//
+// Round 6 (measured, not taken): bins of more than NC = 9 cells (3 x 3 and 4 x 4 sampling lattices: most proposals of p3..p5) walked in
+// groups of 9 loads issued together instead of one load at a time -- bit-identical, 2.44 ms against 2.39-2.44 (102 VGPRs instead of 80).
+// The launch is not latency-serialised: a bin reads ~20 cells of 1 KiB for 1 KiB of output, 64 000 x 49 bins x ~20 KiB = 31 GB through
+// the L1 / texture path at 64 B per clock and CU = 1.6-1.7 ms before anything else; what is left is the duplicate cell reads of
+// neighbouring bins (980 cell loads per ROI against 441 distinct cells), which a rolling window over bin columns would cut by 20 %
+// (a cell column belongs to up to three consecutive bins) and only a two-dimensional register window by the full 2.2 x.
 #include "conv_common.h"  // a3d_pow2_scale: the block exponent of the fp16x2 split (out_h2)
 #ifndef A3D_ROI_NC
 #define A3D_ROI_NC 9

@@ -558,11 +558,15 @@ extern "C" int a3d_box_loss(const a3d_box_loss_desc *d, void *stream) {
 //   d = grad_scale * g + wd * p;  buf = first ? d : momentum * buf + d;  p -= lr * buf
 // grad_scale = 1 / world_size after the gradient all-reduce (sum) of data-parallel training.
 // ------------------------------------------------------------------------------------------------
-__global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf, size_t n4, float lr, float momentum,
+template <bool GB16>  // GB16: the gradient arrives as bf16 (the all-reduced payload itself: no widening pass over the flat buffer)
+__global__ void sgd_kernel(float *__restrict__ p, const void *__restrict__ g, float *__restrict__ buf, size_t n4, float lr, float momentum,
                            float wd, float grad_scale, int first) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 pv = reinterpret_cast<f32x4 *>(p)[i];
-        const f32x4 gv = reinterpret_cast<const f32x4 *>(g)[i];
+        f32x4 gv;
+        if constexpr (GB16) gv = __builtin_convertvector(reinterpret_cast<const b4 *>(g)[i], f32x4);
+        else gv = reinterpret_cast<const f32x4 *>(g)[i];
         const f32x4 dv = grad_scale * gv + wd * pv;
         f32x4 bv = first ? dv : momentum * reinterpret_cast<f32x4 *>(buf)[i] + dv;
         reinterpret_cast<f32x4 *>(buf)[i] = bv;
@@ -570,15 +574,28 @@ __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, f
     }
 }
 
-extern "C" int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
-                                int first, void *stream) {
+static int sgd_launch(float *p, const void *g, bool g_bf16, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale, int first,
+                      void *stream) {
     if (!p || !g || !buf || (n & 3)) return A3D_ERR_ARG;
     const size_t n4 = n >> 2;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     a3d_begin();
-    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, lr, momentum, wd, grad_scale, first);
+    if (g_bf16) hipLaunchKernelGGL(sgd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, lr, momentum, wd, grad_scale, first);
+    else hipLaunchKernelGGL(sgd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, lr, momentum, wd, grad_scale, first);
     return a3d_check_launch();
+}
+
+extern "C" int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
+                                int first, void *stream) {
+    return sgd_launch(p, g, false, buf, n, lr, momentum, wd, grad_scale, first, stream);
+}
+
+// The same update reading the gradient as bf16 -- the payload of the bf16 gradient all-reduce where the collective left it.  Widening is
+// exact, so the update equals a3d_bf16_to_f32 followed by a3d_sgd_momentum bit for bit, without the pass over the flat buffer.
+extern "C" int a3d_sgd_momentum_bf16g(float *p, const void *g_bf16, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
+                                      int first, void *stream) {
+    return sgd_launch(p, g_bf16, true, buf, n, lr, momentum, wd, grad_scale, first, stream);
 }
 
 

@@ -247,8 +247,8 @@ class GradientExchange:
     reduced while autograd is still walking the earlier layers).  `allreduce_gradients` is the monolithic form (one collective behind
     the whole backward pass, fully exposed); this is the form the trainer's step uses.
 
-    segments: (lo, hi) element ranges of the flat gradient buffer in the order the backward pass COMPLETES them (box head, FPN + RPN
-    head, res5, res4, res3 for the detector: the flat buffer is laid out in forward order, so the ranges run back to front).  Every
+    segments: (lo, hi) element ranges of the flat gradient buffer in the order the backward pass COMPLETES them (box head, res5 + FPN +
+    RPN head, res4, res3 for the detector: the flat buffer is laid out in forward order, so the ranges run back to front).  Every
     boundary is a multiple of 4 elements (the casts move 4 per lane).
       begin()                    once per step, before the backward pass
       segment_ready(i, stream)   right after the LAST launch that writes segment i has been enqueued on `stream`: records an event there;
@@ -264,7 +264,7 @@ class GradientExchange:
     host per segment -- at segment_ready time, so a segment announced too early still shows up as a wrong bit.
     force=True runs the segments even at world 1 (measurement: every launch, event and collective of the N > 1 step on a 1-GPU box)."""
 
-    def __init__(self, flat_grads: torch.Tensor, segments, group=None, payload: str = "fp32", force: bool = False):
+    def __init__(self, flat_grads: torch.Tensor, segments, group=None, payload: str = "fp32", force: bool = False, widen: bool = True):
         assert payload in ("fp32", "bf16"), payload
         n = flat_grads.numel()
         segs = [(int(lo), int(hi)) for lo, hi in segments]
@@ -272,6 +272,10 @@ class GradientExchange:
             f"segments must tile [0, {n}): {segs}"
         assert all(lo % 4 == 0 and (hi - lo) % 4 == 0 for lo, hi in segs), segs  # (the casts move 4 elements per lane)
         self.flat, self.segments, self.group, self.payload = flat_grads, segs, group, payload
+        # widen=False (bf16 payload on the RCCL path only): the reduced gradient stays in the bf16 buffer the collective summed in --
+        # `reduced_bf16` -- for an optimiser kernel that reads it there (a3d_sgd_momentum_bf16g: the same update bit for bit, minus one
+        # launch per segment and one pass over the flat buffer); flat_grads then keeps this rank's own gradient
+        self.widen = bool(widen)
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.active = on and (self.world > 1 or force)
@@ -329,6 +333,13 @@ class GradientExchange:
         GRAD_STATS["host_s"] += _time.perf_counter() - t0
         return 1.0 if self.payload == "bf16" else 1.0 / self.world
 
+    @property
+    def reduced_bf16(self):
+        """The all-reduced gradient as bf16 when the last finished step left it there (widen=False, bf16 payload, RCCL path), else None."""
+        if self.widen or self.payload != "bf16" or self._g16 is None or not self.flat.is_cuda or dist.get_backend(self.group) == "gloo":
+            return None
+        return self._g16
+
     # ---- forms
     def _event(self, i):
         ev = self._events.get(i)
@@ -367,7 +378,8 @@ class GradientExchange:
                 st = comm.cuda_stream
                 _lib.check(_lib.lib().a3d_f32_to_bf16_scaled(seg.data_ptr(), g16.data_ptr(), hi - lo, 1.0 / self.world, st), "a3d_f32_to_bf16_scaled")
                 dist.all_reduce(g16, group=self.group, async_op=True).wait()  # (the communication stream waits; the host does not)
-                _lib.check(_lib.lib().a3d_bf16_to_f32(g16.data_ptr(), seg.data_ptr(), hi - lo, st), "a3d_bf16_to_f32")
+                if self.widen:
+                    _lib.check(_lib.lib().a3d_bf16_to_f32(g16.data_ptr(), seg.data_ptr(), hi - lo, st), "a3d_bf16_to_f32")
             else:
                 dist.all_reduce(seg, group=self.group, async_op=True).wait()
         finally:

@@ -340,7 +340,13 @@ def box_loss(pred: torch.Tensor, gt_classes: torch.Tensor, boxes: torch.Tensor, 
 
 def sgd_momentum(p: torch.Tensor, g: torch.Tensor, buf: torch.Tensor, *, lr: float, momentum: float, weight_decay: float,
                  grad_scale: float = 1.0, first: bool = False) -> None:
+    """g: the flat gradient, fp32 -- or bfloat16: the all-reduced bf16 payload as the collective left it (a3d_sgd_momentum_bf16g)."""
     n = _req(p).numel()
-    assert _req(g).numel() == n == _req(buf).numel()
+    assert g.numel() == n == _req(buf).numel() and g.is_contiguous()
+    if g.dtype == torch.bfloat16:
+        _lib.check(_lib.lib().a3d_sgd_momentum_bf16g(_p(p), _p(g), _p(buf), n, lr, momentum, weight_decay, grad_scale, int(first), _stream()),
+                   "a3d_sgd_momentum_bf16g")
+        return
+    _req(g)
     _lib.check(_lib.lib().a3d_sgd_momentum(_p(p), _p(g), _p(buf), n, lr, momentum, weight_decay, grad_scale, int(first), _stream()),
                "a3d_sgd_momentum")

@@ -271,9 +271,12 @@ class DetectorTrainer:
             first.setdefault("box" if ly.name.startswith("roi_heads.") else "fpn" if not ly.name.startswith("backbone.bottom_up.")
                              else ly.name.split(".")[2], o)
             o += ly.rows * ly.k * ly.k * ly.cin + (ly.rows if has_bias(ly) else 0)
-        cuts = [first["res3"], first["res4"], first["res5"], first["fpn"], first["box"], n]
-        assert cuts[0] == 0 and all(a < b and a % 4 == 0 for a, b in zip(cuts, cuts[1:])), cuts
-        self.grad_segments = [(cuts[i], cuts[i + 1]) for i in (4, 3, 2, 1, 0)]  # box head | FPN + RPN head | res5 | res4 | res3
+        cuts = [first["res3"], first["res4"], first["res5"], first["box"], n]
+        assert cuts[0] == 0 and first["res5"] < first["fpn"] < first["box"] and all(a < b and a % 4 == 0 for a, b in zip(cuts, cuts[1:])), cuts
+        # box head (13.9 M, final 0.3 ms into the backward pass) | res5 + FPN + RPN head (19.1 M) | res4 (7.1 M) | res3 (1.2 M: the only
+        # piece whose transfer nothing can hide -- 2.4 MB of bf16).  Four, not more: at the reference's 2 images per GPU every collective
+        # costs ~70 us of host time on a step whose host side is nearly as long as its GPU side.
+        self.grad_segments = [(cuts[i], cuts[i + 1]) for i in (3, 2, 1, 0)]
         self.load_state_dict(sd)
 
     def _views(self, ly: _Layer, sd_like: bool, buf_w, buf_b):
@@ -540,7 +543,8 @@ class DetectorTrainer:
         self._xchg_live, self._late = False, []
         if exchange and self.grad_overlap != "0":
             if self._xchg is None:
-                self._xchg = GradientExchange(self.grads, self.grad_segments, self.pg, self.grad_payload, force=self.grad_overlap.startswith("force"))
+                self._xchg = GradientExchange(self.grads, self.grad_segments, self.pg, self.grad_payload, force=self.grad_overlap.startswith("force"),
+                                              widen=False)
             if self._xchg.active:
                 self._xchg.begin()
                 self._xchg_live = True
@@ -739,7 +743,6 @@ class DetectorTrainer:
             if l > 2:
                 T.sumpool2_add(dprev[l - 1], dprev[l])
             self._wgrad(L[f"backbone.fpn_lateral{l}"], res[f"res{l}"], dprev[l])
-        self._segment_done(1)  # FPN + RPN head (the RPN head's weight gradients were enqueued on the same stream earlier)
         # ---- ResNet backward
         dx_up = None  # gradient arriving at a stage output from the stage above (un-gated)
         for name, nblk, _mid, _cout in reversed(RES_STAGES):
@@ -764,7 +767,7 @@ class DetectorTrainer:
                     dx_up = T.zero_insert2(low, x_in.shape[1], x_in.shape[2])
                 else:
                     g = self._conv(da_, c1.bwd(), res=g, gate=x_in, out_dtype=st)
-            self._segment_done({"res5": 2, "res4": 3, "res3": 4}[name])
+            self._segment_done({"res5": 1, "res4": 2, "res3": 3}[name])  # (res5's segment carries the FPN and the RPN head, finished before it)
         if self._wg_stream is not None:
             self._cur_stream.wait_stream(self._wg_stream)  # every weight gradient has been launched and is waited for here
         if getattr(self, "_defer", None) is not None:
@@ -788,11 +791,14 @@ class DetectorTrainer:
 
     def optimizer_step(self):
         s = self.s
+        g = self.grads
         if self._xchg_live:  # the segments left during the backward pass: wait for the communication stream
             scale, self._xchg_live = self._xchg.finish(), False
+            g16 = self._xchg.reduced_bf16  # (bf16 payload over RCCL: the optimiser reads the sum where the collective left it)
+            g = g16 if g16 is not None else g
         else:  # ONE collective behind the backward pass: the flat gradient buffer
             scale = allreduce_gradients(self.grads, self.pg, payload=self.grad_payload)
-        T.sgd_momentum(self.params, self.grads, self.momentum, lr=lr_at(self.iter, s), momentum=s.momentum, weight_decay=s.weight_decay,
+        T.sgd_momentum(self.params, g, self.momentum, lr=lr_at(self.iter, s), momentum=s.momentum, weight_decay=s.weight_decay,
                        grad_scale=scale, first=self.iter == 0)
         self.iter += 1
 

@@ -271,10 +271,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")  # (only used by the single-process A3D_BENCH_FORCE_DIST form)
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(backend=args.dist_backend)
+        # (RCCL prints a version banner to STDOUT when its communicator comes up; the contract is ONE JSON line there: descriptor 1 points
+        # at stderr while the group is created and its first collective runs, and the C library's buffer is flushed before it returns)
+        import ctypes
+
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
+                dist.all_reduce(torch.zeros(1, device=dev))
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend=args.dist_backend)
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
 
     from articulation3d_amd import ops
     from articulation3d_amd.parallel import gather_records_async

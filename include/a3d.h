@@ -617,6 +617,11 @@ int a3d_box_loss(const a3d_box_loss_desc *d, void *stream);
  * d = grad_scale*g + wd*p;  buf = first ? d : momentum*buf + d;  p -= lr*buf */
 int a3d_sgd_momentum(float *p, const float *g, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
                      int first, void *stream);
+/* The same update with the gradient read as bf16 (the all-reduced bf16 payload where the collective left it: tools/train_net.py:110's
+ * DDP with bf16_compress_hook widens into .grad first; widening is exact, so the result equals a3d_bf16_to_f32 + a3d_sgd_momentum bit
+ * for bit, minus one pass over the flat buffer). */
+int a3d_sgd_momentum_bf16g(float *p, const void *g_bf16, float *buf, size_t n, float lr, float momentum, float wd, float grad_scale,
+                           int first, void *stream);
 
 /* bf16 payload of the data-parallel gradient all-reduce (BASELINE configs[4]; torch DDP's bf16_compress_hook behind
  * tools/train_net.py:110): dst_bf16[i] = bf16(src[i] * scale) (round to nearest even; scale = 1 / world size), and the widening

@@ -1007,8 +1007,8 @@ def _exchange_check(args, timeout=1500):
 
 
 def test_gradient_segments_leave_during_the_backward_pass_bit_identical_one_rccl_rank():
-    """VERDICT r5 item 2.  `DetectorTrainer.step` hands the flat gradient buffer to the collective in five segments (box head | FPN + RPN
-    head | res5 | res4 | res3), each the moment its last weight gradient has been enqueued -- on the real RCCL process group with one
+    """VERDICT r5 item 2.  `DetectorTrainer.step` hands the flat gradient buffer to the collective in four segments (box head | res5 +
+    FPN + RPN head | res4 | res3), each the moment its last weight gradient has been enqueued -- on the real RCCL process group with one
     rank (the 1-GPU box).  Against the same segments announced only BEHIND the whole backward pass: parameters, momenta and losses after
     three steps bit-identical, for both payloads.  (The bf16 payload rewrites every segment with what the communication stream read: a
     segment announced before its last weight gradient landed would differ.)"""
@@ -1016,7 +1016,7 @@ def test_gradient_segments_leave_during_the_backward_pass_bit_identical_one_rccl
     for payload in ("fp32", "bf16"):
         r = d["result"][payload]
         assert r["params_equal"] and r["momentum_equal"] and r["losses_equal"] and r["finite"], (payload, r)
-        assert r["segments_per_step"] == [5, 5] and r["forms"] == ["force", "force-late"], r
+        assert r["segments_per_step"] == [4, 4] and r["forms"] == ["force", "force-late"], r
     assert d["result"]["bf16"]["payload_bytes_per_step"] * 2 == d["result"]["fp32"]["payload_bytes_per_step"] > 160e6
 
 
@@ -1029,4 +1029,4 @@ def test_gradient_segments_equal_the_monolithic_allreduce_two_gloo_ranks():
     for payload in ("fp32", "bf16"):
         r = d["result"][payload]
         assert r["params_equal"] and r["momentum_equal"] and r["losses_equal"] and r["finite"], (payload, r)
-        assert r["segments_per_step"] == [5, 0], r
+        assert r["segments_per_step"] == [4, 0], r

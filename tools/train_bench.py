@@ -118,7 +118,7 @@ def train_leg(dev, batch, steps, warmup, precision="bf16", storage=None, cpu_bas
                                "losses, SGD momentum), random-init weights with calibrated BN, synthetic frames and boxes (arithmetic: see `dtype`)",
                    "precision": precision, "storage": tr.storage,
                    "images_per_gpu": B, "global_batch": B * world, "trainable_parameters": int(tr.params.numel()),
-                   "gradient_exchange": ("five segments of the flat gradient buffer, each all-reduced over RCCL under the rest of the backward pass "
+                   "gradient_exchange": ("four segments of the flat gradient buffer, each all-reduced over RCCL under the rest of the backward pass "
                                          "(parallel.GradientExchange)") if world > 1 else "none (1 GPU)"},
         "losses_last_step": {k: round(float(v), 5) for k, v in losses.items()},
         "roofline": roofline,
@@ -159,6 +159,29 @@ def exchange_probe(dev, model, batch, steps, warmup, precision="bf16", dist_modu
     from articulation3d_amd.utils.synthetic import synthetic_frames
 
     own = not dist.is_initialized()
+    # RCCL prints a version banner to STDOUT (file descriptor 1) when its communicator is created, i.e. at the first collective: the bench
+    # contract is ONE JSON line there, so descriptor 1 points at stderr for the duration of the probe.
+    sys.stdout.flush()
+    keep_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _exchange_probe(dev, model, batch, steps, warmup, precision, dist, own)
+    finally:
+        sys.stdout.flush()
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)  # (the banner sits in the C library's stdout buffer: push it out while descriptor 1 is still stderr)
+        os.dup2(keep_fd, 1)
+        os.close(keep_fd)
+
+
+def _exchange_probe(dev, model, batch, steps, warmup, precision, dist, own):
+    import socket
+
+    from articulation3d_amd import parallel
+    from articulation3d_amd.training import DetectorTrainer
+    from articulation3d_amd.utils.synthetic import synthetic_frames
+
     if own:
         sk = socket.socket()
         sk.bind(("127.0.0.1", 0))
@@ -189,7 +212,7 @@ def exchange_probe(dev, model, batch, steps, warmup, precision="bf16", dist_modu
     return {"segments": stats["segments"] // steps, "bytes": stats["bytes"] // steps, "exposed_ms": round(ms["force"] - ms["0"], 4),
             "ms_per_step_with_exchange": round(ms["force"], 4), "ms_per_step_without": round(ms["0"], 4),
             "host_ms_per_step": round(1e3 * stats["host_s"] / steps, 4), "payload": "bf16" if precision == "bf16" else "fp32",
-            "form": "five segments in backward-completion order (box head | FPN + RPN head | res5 | res4 | res3), each cast + all_reduce(async) on the "
+            "form": "four segments in backward-completion order (box head | res5 + FPN + RPN head | res4 | res3), each cast + all_reduce(async) on the "
                     "communication stream the moment its last weight gradient is enqueued; ONE-rank RCCL group on this box",
             "note": "exposed_ms = step with the exchange - step without, same process, best of two interleaved runs of 10 steps each"}
 
