@@ -19,9 +19,24 @@ N_SIDE = 3
 _side: dict = {}
 
 
+def queue_setting() -> dict:
+    """What decides stream placement in this process: the hardware-queue count the HIP runtime was (or will be) started with.
+    `effective` is False when the runtime was initialised BEFORE this package could set GPU_MAX_HW_QUEUES (a host application that
+    touched the GPU first and did not export the variable itself): then the first-use ORDER of streams matters again and `side(0)`
+    should be called before the application's own streams and before RCCL initialises."""
+    import articulation3d_amd as _pkg  # (sets the default on import)
+
+    v = os.environ.get("GPU_MAX_HW_QUEUES")
+    early = getattr(_pkg, "_hip_up_at_import", False)
+    return {"GPU_MAX_HW_QUEUES": v, "effective": not early, "order_independent": (not early) and v is not None and int(v) >= 8}
+
+
 def side(i: int, device=None) -> "torch.cuda.Stream":
     """Side stream number i (0 .. N_SIDE - 1, larger i wrap) of the package's ONE pool per device.
 
+    (Round 6: the package starts the HIP runtime with GPU_MAX_HW_QUEUES=8 -- articulation3d_amd/__init__.py, queue_setting() --, which
+    makes the placement below independent of first-use order: 15.0 / 15.1 / 15.1 ms per 16-image training step with 0 / 3 / 6 foreign
+    streams first.  The one-pool rule stays: it is what keeps the stream COUNT of the process at four.)
     Why one pool with fixed roles instead of a stream per user.  ROCm maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES,
     4 by default) in the order of their FIRST USE, and which queue a stream lands on decides how its kernels interleave with another
     stream's (tools/probes/stream_overlap_matrix.py, train_stream_queues.py: the training step's two side streams as the 5th and 6th
@@ -30,7 +45,8 @@ def side(i: int, device=None) -> "torch.cuda.Stream":
     index order right behind the default stream, and every component takes them by role:
         0  the depth decoder beside the ROI branch (meta_arch) | the training step's weight gradients | the gather's count read-back
         1  second branch of a 1-2 frame batch              | the training step's RPN-head stream
-        2  third branch of a 1-2 frame batch               | the clip / record copies of a pipelined caller (bench.py)
+        2  third branch of a 1-2 frame batch               | the clip / record copies of a pipelined caller (bench.py) | the training
+           step's gradient exchange (parallel.GradientExchange: casts + the collective's enqueue)
     Two roles of one row never run at the same time; if a caller made them, they would serialise on one stream -- slower, never wrong."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     if dev is None:

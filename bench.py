@@ -31,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: stream placement independent of first-use order (articulation3d_amd/__init__.py)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; never the 2:1-sparsity figure)
