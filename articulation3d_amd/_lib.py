@@ -213,6 +213,7 @@ SIGNATURES = {
     "a3d_mask_rle": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr]),
     "a3d_roi_amax": (C.c_int, [C.POINTER(fptr), C.c_int, fptr, fptr, C.c_int, C.c_int, fptr, fptr]),
     "a3d_conv2d_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), fptr]),
+    "a3d_conv_b2b": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), fptr]),
     "a3d_stem_conv_pool": (C.c_int, [C.POINTER(ConvDesc), fptr]),
     "a3d_tapsum9": (C.c_int, [fptr, C.c_float, fptr, C.c_int, C.c_int, C.c_int, fptr]),
     "a3d_wino_input_transform": (C.c_int, [C.POINTER(ConvDesc), fptr]),

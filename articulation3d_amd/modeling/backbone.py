@@ -60,6 +60,21 @@ class BottleneckBlock(nn.Module):
         y = self.conv2(self.conv1(x))
         return self.conv3(y, res=sc)
 
+    def forward_pair(self, x, a=None, nxt=None):
+        """The block with its first layer possibly done already (`a` = conv1(x), produced by the previous block's launch) and its last
+        layer possibly producing the NEXT block's first (`nxt`): returns (block output, nxt.conv1(block output) or None).
+        conv3 + FrozenBN + residual + ReLU and the next conv1 + FrozenBN + ReLU as ONE launch (ops.conv2d_b2b, csrc/conv_xs_b2b.hip) where
+        the pair has that form -- the block output is written once and not read back by the squeeze that follows it."""
+        from .layers import _CalibrationState
+
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        b = self.conv2(self.conv1(x) if a is None else a)
+        if nxt is not None and not _CalibrationState.active and not self.training:
+            pair = ops.conv2d_b2b(b, self.conv3.packed(), sc, nxt.conv1.packed())
+            if pair is not None:
+                return pair
+        return self.conv3(b, res=sc), None
+
 
 class ResNet(nn.Module):
     def __init__(self, cfg):
@@ -78,6 +93,8 @@ class ResNet(nn.Module):
             for i in range(nblk):
                 blocks.append(BottleneckBlock(in_c, out_c, mid, first_stride if i == 0 else 1))
                 in_c = out_c
+            for prev, blk in zip(blocks, blocks[1:]):  # (layer property: the pairs ops.conv2d_b2b can run as one launch)
+                blk.conv1.b2b_second = (prev.conv3.in_channels, blk.conv1.out_channels) in ops.B2B_PAIRS
             self.add_module(name, nn.Sequential(*blocks))
             stride_total *= first_stride
             self._out_feature_channels[name], self._out_feature_strides[name] = out_c, stride_total
@@ -87,7 +104,10 @@ class ResNet(nn.Module):
         x = self.stem(x4)
         outs = {}
         for name in ("res2", "res3", "res4", "res5"):
-            x = getattr(self, name)(x)
+            blocks = list(getattr(self, name))
+            a = None
+            for i, blk in enumerate(blocks):  # (block i's last layer may hand block i + 1 its first: BottleneckBlock.forward_pair)
+                x, a = blk.forward_pair(x, a, blocks[i + 1] if i + 1 < len(blocks) else None)
             outs[name] = x
         return outs
 

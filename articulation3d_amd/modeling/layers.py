@@ -67,6 +67,7 @@ class _Packable(nn.Module):
     """Caches the packed weights; re-packs when a parameter/buffer was modified or moved."""
 
     pin_precision = None  # 2: the precision audit (PlaneRCNN.audit_precision) pinned this layer to bf16x3; applied to every (re)pack
+    b2b_second = False    # True: second layer of a back-to-back pointwise pair (backbone.ResNet marks them): bf16x3 in every form
     _a3d_name = ""        # qualified module name, filled in by the audit for its report
 
     def __init__(self):
@@ -124,7 +125,13 @@ class _Packable(nn.Module):
             self._pack_cache = self._pack()
             self._pack_key = key
             _publish()
-        self._pack_cache.pin_precision, self._pack_cache.name = self.pin_precision, self._a3d_name
+        pin = self.pin_precision
+        if pin is None and self.b2b_second and ops.B2B_FUSED:
+            # the squeeze behind a block output that the previous block's launch can produce (ops.conv2d_b2b): that launch forms it in the
+            # bf16x3 arithmetic, so the layer runs bf16x3 in EVERY form -- also as a launch of its own (batches under one round of the
+            # chip) -- and a frame's bits do not depend on how it was batched
+            pin = 2
+        self._pack_cache.pin_precision, self._pack_cache.name = pin, self._a3d_name
         return self._pack_cache
 
     def _pack(self):

@@ -930,6 +930,82 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
     return out
 
 
+B2B_FUSED = os.environ.get("A3D_B2B", "1") != "0"  # (False: conv3 and the next block's conv1 as two launches)
+B2B_MIN_PIXELS = 128 * 512  # one round of the chip's 512 workgroup slots (the activation-stationary kernel's own rule)
+# (input channels of the first layer, output channels of the second) of the pairs that run as one launch: res2's conv3 -> conv1 boundaries
+# (64 frames: 0.714 ms against 0.561 + 0.341 for the two launches).  The library also has the res3 form (128, 128): bit-identical as well,
+# but its second GEMM (512 -> 128, six products per multiply-add) leaves 0.484 ms against 0.303 + 0.203 -- a tie, not taken.
+B2B_PAIRS = ((64, 64),)
+
+
+def conv2d_b2b(x: torch.Tensor, p1: PackedConv, res: torch.Tensor, p2: PackedConv):
+    """conv3 (+ FrozenBN + residual + ReLU) of a bottleneck block and conv1 (+ FrozenBN + ReLU) of the NEXT block in one launch
+    (csrc/conv_xs_b2b.hip, include/a3d.h a3d_conv_b2b): returns (y, z) = (conv2d(x, p1, res=res), conv2d(y, p2)) or None when the pair is
+    not of that form (the caller then issues the two launches).  y and its maxima are bit for bit the single launch's; z is the second
+    layer in the bf16x3 arithmetic (full 24-bit operands: the fp16x2 split of y would need y's per-image maximum, which no workgroup
+    knows before the launch ends), bit for bit `conv2d(y, p2, precision=2)`.  Which form runs is a function of the layers and the map,
+    never of the batch beyond the one-round bound every kernel choice of this size class has."""
+    if not B2B_FUSED or DEFAULT_PRECISION != 3 or AUDIT is not None or not x.is_cuda or x.dtype != torch.float32:
+        return None
+    B, H, W, Cin = x.shape
+    M = B * H * W
+    if (p1.KH, p1.KW, p1.stride, p1.pad, p2.KH, p2.KW, p2.stride, p2.pad) != (1, 1, 1, 0, 1, 1, 1, 0) or p1.pin_precision == 2:
+        return None
+    if (Cin, p2.cols) not in B2B_PAIRS or p1.Cin != Cin or p2.Cin != p1.cols or p1.cols % 64 or not (p1.presplit and p2.presplit):
+        return None
+    if p1.Kpad != Cin or p2.Kpad != p2.Cin or p1.pixshuf or p2.pixshuf or p1.phase or p2.phase or p1.stem or p2.stem:
+        return None
+    if M < B2B_MIN_PIXELS or M * p1.cols * 4 >= (1 << 31) or res is None or tuple(res.shape) != (B, H, W, p1.cols):
+        return None
+    _req(x)
+    _req(res)
+    y = torch.empty((B, H, W, p1.cols), device=x.device, dtype=torch.float32)
+    z = torch.empty((B, H, W, p2.cols), device=x.device, dtype=torch.float32)
+    d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+    for d, p, xi, yo in ((d1, p1, x, y), (d2, p2, y, z)):
+        d.x, d.w, d.scale, d.shift, d.y = _p(xi), _p(p.w), _p(p.scale), _p(p.shift), _p(yo)
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, p.Cin, H, W, p.cols
+        d.KH, d.KW, d.stride, d.pad, d.Kpad, d.act, d.splitk = 1, 1, 1, 0, p.Kpad, p.act, 1
+        ya = yo._a3d_amax = amax_slot(B, x.device)
+        d.y_amax = ya.data_ptr()
+    d1.res = res.data_ptr()
+    d1.precision, d2.precision = 3, 2
+    d1.in_amax = amax_of(x).data_ptr()
+    if getattr(p1, "_w_scale", None) is None:
+        p1._w_scale = _pow2_scale_host(float(p1.w.abs().max()))
+    d1.w_scale = p1._w_scale
+    fresh = False
+    if p1.w_h2 is None or p1.w_h2.device != p1.w.device:  # (as _conv2d_launch: the fp16x2 planes of the filter, once per packed layer)
+        p1.w_h2 = torch.empty((p1.Kpad // 16, 2, p1.w.shape[0], 16), device=p1.w.device, dtype=torch.float16)
+        _lib.check(_lib.lib().a3d_split_f16x2_chunk(p1.w.data_ptr(), p1.w_h2.data_ptr(), 1, p1.w.shape[0], p1.Kpad, 16, d1.w_scale, _stream()), "a3d_split_f16x2_chunk")
+        fresh = True
+    if p2.w_x3 is None or p2.w_x3.device != p2.w.device:  # the second filter's exact bf16 planes, once per packed layer
+        p2.w_x3 = torch.empty((p2.Kpad // 16, 3, p2.w.shape[0], 16), device=p2.w.device, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().a3d_split_bf16x3_chunk(p2.w.data_ptr(), p2.w_x3.data_ptr(), 1, p2.w.shape[0], p2.Kpad, 16, _stream()), "a3d_split_bf16x3_chunk")
+        fresh = True
+    if fresh and not os.environ.get("A3D_NO_PUBLISH"):
+        torch.cuda.current_stream().synchronize()  # (published to every stream, as the other per-layer caches)
+    d1.w_x3, d2.w_x3 = p1.w_h2.data_ptr(), p2.w_x3.data_ptr()
+    global _LAST_PRECISION
+    _LAST_PRECISION = 3
+    timing = CONV_TIMING is not None and (CONV_TIMING_ONLY is None or any(v.startswith("conv_h2xs_b2b") for v in CONV_TIMING_ONLY))
+    if timing:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().a3d_conv_b2b(C.byref(d1), C.byref(d2), _stream())
+    if rc == -3:  # A3D_ERR_UNSUPPORTED: not a pair of this form after all
+        return None
+    _lib.check(rc, "a3d_conv_b2b")
+    if timing:
+        e1.record()
+        fl = 2.0 * M * (p1.cols * Cin + p2.cols * p2.Cin)
+        # (executed matrix FLOPs: 3 fp16 products per multiply-add of the first layer, 6 bf16 ones of the second -- booked at the fp16x2
+        # weight of 3 with the second layer counted twice, so that the roofline object's issued-FLOP sum stays right)
+        ex = 2.0 * M * (p1.cols * Cin + 2 * p2.cols * p2.Cin)
+        CONV_TIMING.append((last_conv_variant(), fl, e0, e1, f"{B}x{H}x{W}x{Cin}->{p1.cols}->{p2.cols} k1 b2b", ex, "f16x3", _stream()))
+    return y, z
+
+
 CONV_TIMING_ONLY: Optional[frozenset] = None
 _TIMED_VARIANTS: dict = {}
 

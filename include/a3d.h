@@ -233,6 +233,14 @@ int a3d_wino_gemm(const a3d_conv_desc *d, void *stream);
  * maps, the per-image scales and the recorded maxima.  The partial rounds of the small levels vanish (p3-p6 at 64 frames: 5 + 2 + 1 + 1
  * rounds of the chip -> 6.25) and every output element is computed exactly as by its own launch: bit-identical. */
 int a3d_wino_gemm_levels(const a3d_conv_desc *levels, int n, void *stream);
+/* Back-to-back pointwise pair across a ResNet bottleneck boundary (round 6; detectron2 BottleneckBlock reached from
+ * pkg/modeling/meta_arch/planercnn.py:29,150): d1 = conv3 + FrozenBN + residual + ReLU of block i, d2 = conv1 + FrozenBN + ReLU of block i + 1,
+ * ONE launch.  d1 as for a3d_conv2d_nhwc_f32 on the activation-stationary fp16x2 kernel (1x1 stride 1, precision 3, w_x3, in_amax, w_scale,
+ * res set, Cin 64 or 128); d2: 1x1 stride 1 over d1's output (Cin = d1->Cout, Cout 64 / 128 for d1->Cin 64 / 128), precision 2 with
+ * w_x3 = its bf16x3 planes [Cin/16][3][Cout][16] (a3d_split_bf16x3_chunk), scale / shift / act, y, optional y_amax; no residual.
+ * d1->y (and d1->y_amax) are stored exactly as the single launch stores them; d2->y equals a3d_conv2d_nhwc_f32(d2) on that tensor bit for
+ * bit -- without reading it back from HBM.  A3D_ERR_UNSUPPORTED: not such a pair (issue the two launches). */
+int a3d_conv_b2b(const a3d_conv_desc *d1, const a3d_conv_desc *d2, void *stream);
 /* The kernel instantiation the LAST conv launch of the calling thread dispatched, as it appears in a rocprofv3 kernel trace
  * ("conv_pw_kernel<2,2,16> 128x128 persistent", "wino_gemm_kernel<1,32>", ...); "" before the first launch.  For measurement
  * code: launches are labelled with what the dispatcher did, not with a host-side copy of its selection rules.

@@ -333,6 +333,78 @@ def test_activation_stationary_pointwise_kernel_agrees_bit_for_bit_with_the_tile
     assert float(ops.amax_of(a).max()) > 0
 
 
+@pytest.mark.parametrize("case", [(4, 120, 160, 64, 256, 64), (5, 119, 161, 64, 256, 64), (16, 60, 80, 128, 512, 128), (15, 59, 81, 128, 512, 128)])
+def test_back_to_back_pointwise_pair_equals_its_two_launches_bit_for_bit(ops, case):
+    """Round 6: conv3 + FrozenBN + residual + ReLU of a bottleneck block and conv1 + FrozenBN + ReLU of the next block
+    as ONE launch (ops.conv2d_b2b, csrc/conv_xs_b2b.hip, include/a3d.h a3d_conv_b2b; BottleneckBlock reached from planercnn.py:29,150).
+    The block output y and its recorded per-image maxima equal the activation-stationary kernel's launch bit for bit; the squeezed
+    tensor z and its maxima equal the bf16x3 launch of the second layer ON that y bit for bit -- same exact three-way split, same chunk
+    order, same six products per chunk into one accumulator, same epilogue -- without y being read back.  Both instantiations (res2's
+    64 -> 256 -> 64 and res3's 128 -> 512 -> 128, which ops does not dispatch: a tie in time), ragged pixel counts (a last tile with
+    rows past the end, waves that straddle two images)."""
+    B, H, W, Cin, Cmid, Cout2 = case
+    torch.manual_seed(B * 100 + Cin)
+    x = torch.relu(torch.randn(B, H, W, Cin, device="cuda")) * torch.logspace(-1.5, 1.5, B, device="cuda")[:, None, None, None]
+    res = torch.relu(torch.randn(B, H, W, Cmid, device="cuda")) * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+    bn = lambda c: (1.0 + 0.2 * torch.randn(c), 0.1 * torch.randn(c), 0.05 * torch.randn(c), 1.0 + 0.1 * torch.rand(c), 1e-5)
+    p1 = ops.pack_conv(torch.randn(Cmid, Cin, 1, 1) / Cin ** 0.5, None, bn(Cmid), 1, 0, ops.ACT_RELU)
+    p2 = ops.pack_conv(torch.randn(Cout2, Cmid, 1, 1) / Cmid ** 0.5, None, bn(Cout2), 1, 0, ops.ACT_RELU)
+    y0 = ops.conv2d(x, p1, res=res, precision=3, tune=13)
+    assert ops.last_conv_variant() == f"conv_h2xs_kernel<{Cin}>", ops.last_conv_variant()
+    z0 = ops.conv2d(y0, p2, precision=2)
+    assert ops.last_conv_variant().startswith("conv_x3_kernel"), ops.last_conv_variant()
+    saved = ops.B2B_PAIRS, ops.B2B_MIN_PIXELS
+    ops.B2B_PAIRS, ops.B2B_MIN_PIXELS = ((64, 64), (128, 128)), 1
+    try:
+        pair = ops.conv2d_b2b(x, p1, res, p2)
+    finally:
+        ops.B2B_PAIRS, ops.B2B_MIN_PIXELS = saved
+    assert pair is not None and ops.last_conv_variant() == f"conv_h2xs_b2b_kernel<{Cin},{Cout2}>", ops.last_conv_variant()
+    y1, z1 = pair
+    assert torch.equal(y0, y1) and torch.equal(ops.amax_of(y0), ops.amax_of(y1))
+    assert torch.equal(z0, z1) and torch.equal(ops.amax_of(z0), ops.amax_of(z1))
+    assert float(ops.amax_of(z1).min()) > 0 and bool(torch.isfinite(z1).all())
+    # ... and against float64 on a slice: the second layer carries full 24-bit operands (bf16x3), the first the fp16x2 law
+    xs, rs = x[:1, :8].double(), res[:1, :8].double()
+    yd = torch.relu(torch.einsum("bhwc,oc->bhwo", xs, p1.w.double()[:, :Cin]) * p1.scale.double() + p1.shift.double() + rs)
+    zd = torch.relu(torch.einsum("bhwc,oc->bhwo", yd, p2.w.double()[:, :Cmid]) * p2.scale.double() + p2.shift.double())
+    assert float((z1[:1, :8].double() - zd).abs().max() / zd.abs().max()) < 2e-6
+    # what is not such a pair is refused, not approximated
+    assert ops.conv2d_b2b(x, p1, None, p2) is None and ops.conv2d_b2b(x[:1, :4, :4].contiguous(), p1, res[:1, :4, :4].contiguous(), p2) is None
+
+
+def test_the_squeeze_behind_a_fused_boundary_keeps_its_bits_at_every_batch_size(hip_model, oracle):
+    """The second layer of a back-to-back pair runs bf16x3 in EVERY form (layers._Packable.b2b_second): a frame's res2 output is the same
+    bits whether its batch is large enough for the one-launch form (>= 4 frames: one round of the chip) or not."""
+    from articulation3d_amd import ops
+
+    frames = torch.from_numpy(oracle.synthetic_frames(6, seed=77)).cuda()
+    bu = hip_model.backbone.bottom_up
+    assert [blk.conv1.b2b_second for blk in bu.res2] == [False, True, True] and not any(blk.conv1.b2b_second for blk in bu.res4)
+    x4 = ops.preprocess_u8hwc(frames, hip_model.pixel_mean, hip_model.pixel_std)
+    seen = []
+    real = ops.conv2d_b2b
+    ops.conv2d_b2b = lambda *a, **k: (seen.append(real(*a, **k)) or seen[-1])
+    try:
+        big = bu(x4)
+        n_fused = sum(1 for p in seen if p is not None)
+        seen.clear()
+        small = [bu(x4[i:i + 2].contiguous()) for i in range(0, 6, 2)]
+        n_small = sum(1 for p in seen if p is not None)
+    finally:
+        ops.conv2d_b2b = real
+    assert n_fused == 2 and n_small == 0, (n_fused, n_small)  # (res2's two boundaries at 6 frames; none at 2)
+    for name in ("res2", "res3", "res5"):
+        assert torch.equal(big[name], torch.cat([s[name] for s in small])), name
+    saved, ops.B2B_FUSED = ops.B2B_FUSED, False  # (the switch drops the bf16x3 pin with the fusion: the round-5 arithmetic, for A/B runs)
+    try:
+        old = bu(x4)
+    finally:
+        ops.B2B_FUSED = saved
+    rel = float((old["res2"] - big["res2"]).abs().max() / big["res2"].abs().max())
+    assert 0 < rel < 1e-5, rel
+
+
 def test_plane_split_winograd_equals_the_one_launch_form_bit_for_bit(ops):
     """Small fp16x2 Winograd problems run one plane per workgroup into a3d_conv_desc.wino_m and fold afterwards (wino_fold_kernel): the
     same multiply-adds in the same order as the one-launch kernel -- outputs and recorded maxima are identical."""
