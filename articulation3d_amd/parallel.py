@@ -239,6 +239,9 @@ def allreduce_gradients(flat_grads: torch.Tensor, group=None, payload: str = "fp
 # measurement record of the training step's gradient exchange (bench.py / tools/train_bench.py reset and read it): steps finished, segment
 # collectives issued, payload bytes one rank handed to the collective library, host seconds inside segment_ready + finish
 GRAD_STATS = {"steps": 0, "segments": 0, "bytes": 0, "host_s": 0.0}
+import os as _os
+
+COMM_STREAM = _os.environ.get("A3D_GRAD_COMM_STREAM", "side")
 
 
 class GradientExchange:
@@ -284,12 +287,13 @@ class GradientExchange:
         self._issued: set = set()
         self._open = False
         self._events: dict = {}
+        self._used_streams: list = []
 
     # ---- one step
     def begin(self):
         for fin in self._pending:  # (a step whose optimiser update never came: complete its collectives, every rank has issued them)
             fin()
-        self._pending, self._issued, self._open = [], set(), True
+        self._pending, self._issued, self._open, self._used_streams = [], set(), True, []
 
     def segment_ready(self, i: int, stream=None):
         if not (self.active and self._open):
@@ -328,7 +332,8 @@ class GradientExchange:
             fin()
         self._pending, self._open = [], False
         if self.flat.is_cuda and dist.get_backend(self.group) != "gloo":
-            torch.cuda.current_stream().wait_stream(self._comm())
+            for st in self._used_streams:
+                torch.cuda.current_stream().wait_stream(st)
         GRAD_STATS["steps"] += 1
         GRAD_STATS["host_s"] += _time.perf_counter() - t0
         return 1.0 if self.payload == "bf16" else 1.0 / self.world
@@ -352,6 +357,11 @@ class GradientExchange:
 
         return side(2, self.flat.device)
 
+    def _comm_for(self, producer):
+        """The stream the casts and the collective's enqueue of a segment go to.  "side" (default): the package's communication stream --
+        the producer (the weight-gradient stream) is never held up by a transfer.  "producer" (measurement knob): the producer itself."""
+        return producer if COMM_STREAM == "producer" else self._comm()
+
     def _host_segment(self, seg: torch.Tensor):
         """Host tensor `seg` (a view of the flat buffer, or a staged copy): the collective starts now, the returned thunk completes it."""
         if self.payload == "bf16":
@@ -364,9 +374,11 @@ class GradientExchange:
     def _device_segment(self, i, seg, lo, hi, stream):
         from . import _lib
 
-        comm = self._comm()
+        comm = self._comm_for(stream)
         ev = self._event(i)
         ev.record(stream)
+        if comm not in self._used_streams:
+            self._used_streams.append(comm)
         cur = torch.cuda.current_stream()
         torch.cuda.set_stream(comm)  # (the collective orders itself behind the CURRENT stream of the call)
         try:

@@ -20,23 +20,23 @@ _side: dict = {}
 
 
 def queue_setting() -> dict:
-    """What decides stream placement in this process: the hardware-queue count the HIP runtime was (or will be) started with.
-    `effective` is False when the runtime was initialised BEFORE this package could set GPU_MAX_HW_QUEUES (a host application that
-    touched the GPU first and did not export the variable itself): then the first-use ORDER of streams matters again and `side(0)`
-    should be called before the application's own streams and before RCCL initialises."""
-    import articulation3d_amd as _pkg  # (sets the default on import)
-
+    """What decides stream placement in this process: the hardware-queue count of the HIP runtime (GPU_MAX_HW_QUEUES; unset = the
+    runtime's default of 4) and whether the package's pool was created before any other stream could take a queue
+    (`pool_first`: side() was first called while the process had made no other use of the GPU that this module can see)."""
     v = os.environ.get("GPU_MAX_HW_QUEUES")
-    early = getattr(_pkg, "_hip_up_at_import", False)
-    return {"GPU_MAX_HW_QUEUES": v, "effective": not early, "order_independent": (not early) and v is not None and int(v) >= 8}
+    return {"GPU_MAX_HW_QUEUES": v, "pool_created": bool(_side), "pool_first": bool(_side) and not _late_pool,
+            "note": "4 queues (default): use the pool first (15.1 | 18.1 ms per 16-image training step otherwise); >= 6 queues: order-free but the "
+                    "gradient exchange's cross-stream waits cost 5-6 ms per step (articulation3d_amd/__init__.py)"}
+
+
+_late_pool = False
 
 
 def side(i: int, device=None) -> "torch.cuda.Stream":
     """Side stream number i (0 .. N_SIDE - 1, larger i wrap) of the package's ONE pool per device.
 
-    (Round 6: the package starts the HIP runtime with GPU_MAX_HW_QUEUES=8 -- articulation3d_amd/__init__.py, queue_setting() --, which
-    makes the placement below independent of first-use order: 15.0 / 15.1 / 15.1 ms per 16-image training step with 0 / 3 / 6 foreign
-    streams first.  The one-pool rule stays: it is what keeps the stream COUNT of the process at four.)
+    (Round 6 measured the alternative -- more hardware queues, GPU_MAX_HW_QUEUES -- and did not take it: 6+ queues remove the order
+    dependence but make the gradient exchange's cross-stream waits cost 5-6 ms per step; articulation3d_amd/__init__.py has the numbers.)
     Why one pool with fixed roles instead of a stream per user.  ROCm maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES,
     4 by default) in the order of their FIRST USE, and which queue a stream lands on decides how its kernels interleave with another
     stream's (tools/probes/stream_overlap_matrix.py, train_stream_queues.py: the training step's two side streams as the 5th and 6th
@@ -53,6 +53,11 @@ def side(i: int, device=None) -> "torch.cuda.Stream":
         dev = torch.cuda.current_device()
     pool = _side.get(dev)
     if pool is None:
+        global _late_pool
+        import articulation3d_amd as _pkg
+
+        # (the runtime was already up when the package was imported AND the pool comes later still: first-use order is the caller's)
+        _late_pool = _late_pool or bool(getattr(_pkg, "_hip_up_at_import", False))
         with torch.cuda.device(dev):
             pool = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE)]
             for st in pool:  # first use, in index order: the hardware queues are taken now, in this order

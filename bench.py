@@ -31,7 +31,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: stream placement independent of first-use order (articulation3d_amd/__init__.py)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; never the 2:1-sparsity figure)
@@ -552,7 +551,7 @@ def main():
         roofline["main_stream"] = {"launches": mn, "avg_launch_ms": round(1e3 * ms_ / mn, 4), "achieved": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12, 2),
                                    "frac": round(mx * PIPE_FLOPS_PER_FMA[dpipe] / ms_ / 1e12 / peak, 4),
                                    "note": "the same kernel over its launches on the trunk's stream only (side-stream launches share the chip and read long)"}
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (5, 4, 3, 2)) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{n}_traffic.json") for n in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
     if tpath:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/summarize_pmc_traffic.py)
         tr = json.load(open(tpath))
         rname = rocprof_name(dname)

@@ -194,7 +194,18 @@ def test_bench_default_line_has_the_contract_fields():
     for k in ("images_per_gpu_2", "images_per_gpu_16"):
         t = d["train_step"][k]
         assert t["unit"] == "images/s" and t["value"] > 0 and t["roofline"]["peak"] == 2500.0 and 0 < t["roofline"]["whole_step"]["frac"] < 1
-        assert t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["value"] > 0
+        assert "ONE stream" in t["roofline"]["source"]  # (per-kernel times come from the one-stream instrumented step)
+    t2 = d["train_step"]["images_per_gpu_2"]  # (the CPU port's autograd step: the 2-image leg only -- minutes of host time at 16)
+    assert t2["cpu_baseline"]["kind"] == "port" and t2["cpu_baseline"]["value"] > 0 and "cpu_baseline" not in d["train_step"]["images_per_gpu_16"]
+    # round 6: the N > 1 step's gradient exchange measured on this box (four segments on a one-rank RCCL group), and the numeric leaves the
+    # driver's record keeps in full -- like-for-like arithmetics, operating points, the reference's per-frame loop, the training legs
+    c = t2["collective"]
+    assert c["segments"] == 4 and c["bytes"] > 80e6 and c["payload"] == "bf16" and -0.5 < c["exposed_ms"] < 1.5, c
+    if "alt_modes" in d:
+        assert set(rf["like_for_like"]) >= {"bf16x3", "fp32"} and rf["like_for_like"]["bf16x3"]["value"] == d["alt_modes"]["bf16x3"]["value"]
+    assert set(rf["operating_points"]) == {"A", "B", "C"} and rf["operating_points"]["B"]["value"] == d["operating_points"]["B_thresh0.0"]["value"]
+    assert rf["loop_b1"]["frames"] == 64 and rf["loop_b1"]["frames_per_s"] > 50 and rf["loop_b1"]["detections_per_frame"] > 0
+    assert set(rf["train_step"]) == {"images_per_gpu_2", "images_per_gpu_16"} and rf["train_step"]["images_per_gpu_2"]["exposed_exchange_ms"] == c["exposed_ms"]
 
 
 def test_first_small_batch_of_a_process_equals_the_steady_state():
@@ -246,14 +257,16 @@ def test_single_frame_pass_without_its_host_read_and_as_a_hip_graph():
     assert torch.equal(o.records, ref[1][0]) and torch.equal(o.depth, ref[1][2])
 
 
-def test_stream_placement_does_not_depend_on_first_use_order():
-    """the 16-image training step (weight gradients and the RPN head's backward on the package's side streams) takes
-    the same time whether the package's stream pool is the first thing the process uses or comes behind three foreign streams and an
-    initialised RCCL group -- the package starts the HIP runtime with 8 hardware queues (articulation3d_amd/__init__.py); with the
-    runtime's default of 4 the second order measured 18.1 ms against 15.1 (tools/probes/stream_order_check.py --queues 4)."""
+def test_the_package_rule_for_stream_placement_gives_the_fast_order():
+    """VERDICT r5 item 7.  Stream placement on this runtime follows the ORDER of first use (four hardware queues by default).  The package's
+    rule -- its stream pool first, foreign streams and RCCL afterwards (bench.py, tools/train_bench.py, tools/inference.py) -- must be the
+    fast order of the 16-image training step, with a one-rank RCCL group and three foreign streams present; the opposite order is run too
+    and reported (18.1 against 15.1 ms).  More hardware queues would remove the dependence (6 or 8: both orders 15.0 ms) but make the
+    gradient exchange's cross-stream waits cost 5-6 ms per step -- measured in round 6 and not taken (articulation3d_amd/__init__.py)."""
     r = _run(["tools/probes/stream_order_check.py"], timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
-    for k in ("package_first", "foreign_first"):
-        assert d[k]["queues"]["GPU_MAX_HW_QUEUES"] == "8" and d[k]["queues"]["order_independent"], d
-    assert 0.96 <= d["ratio_foreign_over_package"] <= 1.04, d  # (2 % is the run-to-run spread of the step on one box; 18.1 / 15.1 = 1.20)
+    pf, ff = d["package_first"], d["foreign_first"]
+    assert pf["queues"]["GPU_MAX_HW_QUEUES"] is None and pf["queues"]["pool_first"] is True, d
+    assert pf["ms_per_step"] <= 1.03 * min(pf["ms_per_step"], ff["ms_per_step"]), d  # (the rule's order is never the slow one)
+    print("stream order:", d["ratio_foreign_over_package"], pf["ms_per_step"], ff["ms_per_step"])

@@ -330,7 +330,7 @@ def test_bench_labels_map_onto_the_kernels_of_the_committed_profile():
     sys.path.insert(0, ROOT)
     import bench
 
-    rnd = next(r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_bench.json")) and os.path.exists(os.path.join(ROOT, "profiles", f"{r}_kernel_stats.csv")))
+    rnd = next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_bench.json")) and os.path.exists(os.path.join(ROOT, "profiles", f"{r}_kernel_stats.csv")))
     line = json.loads(open(os.path.join(ROOT, "profiles", f"{rnd}_bench.json")).read().strip().splitlines()[-1])
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.csv"))))
     squeeze = lambda s: re.sub(r"\s+", "", s)

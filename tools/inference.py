@@ -31,7 +31,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: stream placement independent of first-use order (articulation3d_amd/__init__.py)
 
 
 def count_frames(path: str) -> int:

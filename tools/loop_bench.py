@@ -5,7 +5,6 @@ one frame at a time, timed; and the batched detect_clip on the same frames.
 `reference_loop(branch, frames)` and `loop_b1(model, cfg, n)` are what bench.py calls for `roofline.loop_b1`."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: stream placement independent of first-use order (articulation3d_amd/__init__.py)
 from articulation3d_amd.config import get_cfg, get_planercnn_cfg_defaults
 from articulation3d_amd.utils.arti_vis import PlaneRCNN_Branch, create_instances
 from articulation3d_amd.utils.synthetic import synthetic_frames, calibrate_batchnorm

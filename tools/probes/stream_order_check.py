@@ -5,9 +5,9 @@ tests/test_gpu_bench.py::test_stream_placement_does_not_depend_on_first_use_orde
     python tools/probes/stream_order_check.py --child package_first | foreign_first
 
 package_first: streams.side() right after the device is set, then three foreign streams and a one-rank RCCL group (its communicator
-stream).  foreign_first: three foreign streams and RCCL FIRST, the package's pool last -- the order that cost 18.1 instead of 15.1 ms per
-16-image step with the runtime's default of four hardware queues.  The package starts the runtime with GPU_MAX_HW_QUEUES=8
-(articulation3d_amd/__init__.py); `--queues N` overrides it for the children (4 = the runtime default, to see the old behaviour)."""
+stream) -- the package's rule.  foreign_first: three foreign streams and RCCL FIRST, the package's pool last -- the order that costs 18.1
+instead of 15.1 ms per 16-image step with the runtime's default of four hardware queues.  `--queues N` exports GPU_MAX_HW_QUEUES=N to the
+children (round 6 measured 5, 6 and 8: articulation3d_amd/__init__.py says why the default stays)."""
 import argparse
 import json
 import os
@@ -23,7 +23,7 @@ def child(order, batch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import torch
 
-    import articulation3d_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the first HIP call unless the caller exported one)
+    import articulation3d_amd  # noqa: F401
     from articulation3d_amd import streams
     from train_bench import train_leg
 
