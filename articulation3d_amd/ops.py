@@ -1073,6 +1073,8 @@ def conv2d_ups(x: torch.Tensor, phases: Sequence[PackedConv], *, x2: Optional[to
         if pf is None:
             pf = pack_conv_ups_fused(phases)
             phases[0]._fused = pf if pf is not None else False
+        if pf:
+            pf.name = getattr(phases[0], "name", "")  # (measurement tools label launches by layer: tools/kernel_table.py)
         b3 = pinned or DEFAULT_PRECISION == 2
         # (the bf16x3 launch of the fused form needs the pre-split filter, which _conv2d_launch builds from 192 columns on, and the phase-5
         # launcher's 2^31-byte filter bound: a narrower or oversized layer runs the four per-phase launches below, as before round 5)

@@ -386,3 +386,37 @@ def test_pack_cache_key_sees_slots_added_or_replaced_on_child_modules():
     with torch.no_grad():
         m.norm.weight.mul_(2.0)  # in-place edits are seen through the version counter, as before
     assert m._key() != k2
+
+
+def test_design_kernel_table_names_kernels_of_the_committed_trace():
+    """DESIGN.md section 3 answers "which kernel runs layer X in arithmetic Y" from ONE table, generated by
+    tools/kernel_table.py out of the dispatcher's own record (profiles/r06_kernel_table.md).  Every label of its default-arithmetic
+    column must be a kernel of the committed rocprofv3 trace of the same step (profiles/r06_kernel_stats.csv) through bench.rocprof_name,
+    every layer of the detection path must have a row, and DESIGN.md must point at the table."""
+    import csv
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    lines = open(os.path.join(ROOT, "profiles", "r06_kernel_table.md")).read().splitlines()
+    rows = [[c.strip() for c in l.strip("|").split("|")] for l in lines if l.startswith("| `")]
+    assert len(rows) >= 100, len(rows)
+    names = {re.sub(r"\s+", "", r["Name"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv")))}
+    layers = {r[0].strip("`") for r in rows}
+    for want in ("backbone.bottom_up.res4.2.conv2", "backbone.fpn_output2", "proposal_generator.rpn_head.conv", "roi_heads.box_head.fc1",
+                 "roi_heads.plane_head.plane_fc1", "roi_heads.axis_head.axis_R_conv1", "roi_heads.mask_head.deconv"):
+        assert want in layers, want
+    seen = set()
+    for r in rows:
+        for label in re.findall(r"`([^`]+)`", r[2]):  # the fp16x2 column
+            label = re.sub(r" \((first|second|all) [^)]*\)$", "", label)
+            label = re.sub(r" levels\d$", "", label)  # (the multi-level launch: the same kernel, a five-row table in its epilogue)
+            want = re.sub(r"\s+", "", bench.rocprof_name(label))
+            assert any(want in n for n in names), (r[0], label, want)
+            seen.add(label.split("<")[0].split(" ")[0])
+    assert {"conv_h2xs_b2b_kernel", "conv_h2xs_kernel", "wino_gemm_h2w_kernel", "conv_h2w_kernel", "conv_ph4p_kernel", "conv_c3p_kernel", "stem_pool_kernel"} <= seen, seen
+    res42 = next(r for r in rows if r[0] == "`backbone.bottom_up.res4.2.conv2`")
+    assert res42[3] == "`wino_gemm_x3_kernel`" and res42[2] == "`wino_gemm_h2w_kernel<4>`", res42  # (the verdict's own example: res4.2.conv2 in bf16x3)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert "profiles/r06_kernel_table.md" in design and len(design) < 40 * 1024 and os.path.exists(os.path.join(ROOT, "MEASUREMENTS.md"))
