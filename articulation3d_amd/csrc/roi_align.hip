@@ -20,12 +20,12 @@
 // giving each wave its own contiguous run of bins instead of every fourth bin was slower (2.52 ms: the four waves of a
 // workgroup no longer share their neighbouring cells in L1).
 //
-// Round 6 (measured, not taken): bins of more than NC = 9 cells (3 x 3 and 4 x 4 sampling lattices: most proposals of p3..p5) walked in
-// groups of 9 loads issued together instead of one load at a time -- bit-identical, 2.44 ms against 2.39-2.44 (102 VGPRs instead of 80).
-// The launch is not latency-serialised: a bin reads ~20 cells of 1 KiB for 1 KiB of output, 64 000 x 49 bins x ~20 KiB = 31 GB through
-// the L1 / texture path at 64 B per clock and CU = 1.6-1.7 ms before anything else; what is left is the duplicate cell reads of
-// neighbouring bins (980 cell loads per ROI against 441 distinct cells), which a rolling window over bin columns would cut by 20 %
-// (a cell column belongs to up to three consecutive bins) and only a two-dimensional register window by the full 2.2 x.
+// Round 6.  Measured and not taken: bins of more than NC = 9 cells (3 x 3 and 4 x 4 sampling lattices: most proposals of p3..p5) walked in
+// groups of 9 loads issued together instead of one load at a time -- bit-identical, 2.44 ms against 2.39-2.44: the launch is not
+// latency-serialised.  A bin reads ~20 cells of 1 KiB for 1 KiB of output: 64 000 x 49 bins x ~20 KiB = 31 GB through the L1 / texture
+// path, which delivers ~50-80 GB/s per CU on gathers like this one = 1.6-2.4 ms whatever the schedule; what can be cut is the duplicate
+// cell reads of neighbouring bins (980 cell loads per ROI against 441 distinct cells).  TAKEN: the rolling-window walk of the 7 x 7 box
+// pooler (roi_align_fpn_kernel<4, false, true>, below): 675 loads per typical ROI, 2.04 ms against 2.43 (tools/roi_bench.py).
 #include "conv_common.h"  // a3d_pow2_scale: the block exponent of the fp16x2 split (out_h2)
 #ifndef A3D_ROI_NC
 #define A3D_ROI_NC 9
@@ -45,6 +45,7 @@ struct RoiArgs {
     float *out;
     int *out_level;
     int serial;  // A/B + test hook (A3D_ROI_SERIAL=1): the one-load-at-a-time bin walk the batched form replaced
+    int rolling; // round 6 (a3d_roialign_desc.serial == 2): the rolling-window walk below, where the ROI's geometry allows it
     const int *order;  // optional [B*R]: slot walked by workgroup (b, rank); see a3d_roialign_desc.order_ws
     int nblk;
     float *out_amax;            // optional [rows]: max |pooled[row]| over the finite pooled values (a3d_roialign_desc.out_amax)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void roi_order_kernel(const float *boxes, cons
 // the pyramid, and 49 bins are 7 rounds with no idle wave), 4 otherwise.
 typedef _Float16 ra_h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 ra_h16x8 __attribute__((ext_vector_type(8)));
-template <int NW, bool H2>
+template <int NW, bool H2, bool ROLL = false>
 __global__ __launch_bounds__(64 * NW, H2 ? 3 : 1) void roi_align_fpn_kernel(const RoiArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pooled_lds[];  // H2: [P*P][C]
     int slot = blockIdx.x;
@@ -202,6 +203,91 @@ __global__ __launch_bounds__(64 * NW, H2 ? 3 : 1) void roi_align_fpn_kernel(cons
         // (2.5 ms per 64-frame step for a 3.2 GB output).  The common case (<= 16 cells per bin: sampling grids up to 3 x 3) now
         // issues every load of the bin first -- 16 independent requests in flight per wave -- and accumulates afterwards in the
         // SAME order (ky outer, kx inner), so the results are bit-identical to the serialized form.
+        // ---- rolling-window walk (round 6, opt-in: a3d_roialign_desc.serial == 2; 7 x 7 bins, C = 256, four waves) -------------------------
+        // The bin-by-bin walk reads (ny x nx) cells per bin: ~980 cell loads of 1 KiB per ROI for ~441 distinct cells, and the launch is
+        // bound by the L1 / texture path.  Here a wave owns TWO adjacent bin rows (wave 3: the last one alone) and walks the cell COLUMNS of
+        // the ROI once: per column it loads the union of its bin rows' cell rows, forms the two row-weighted column sums, and adds them into
+        // the accumulators of the (at most three) bins whose x window holds the column -- three ROLLING accumulators per bin row, emitted and
+        // shifted when a bin's window ends, so every register index is static.  675 cell loads per typical ROI.  The sums run (column, row)
+        // instead of (row, column): equal to the bin-by-bin form to fp32 rounding, not bit for bit.  ROIs whose geometry does not fit
+        // (a bin without samples, more than three bins on a column = bins narrower than a cell, more than RMAX = 8 cell rows per pair) take the
+        // bin-by-bin walk: the choice is a function of the ROI alone.
+        constexpr int RMAX = 8;
+        bool roll = ROLL && a.rolling && C4 == 64 && a.P == 7 && NW == 4;
+        if (roll) {
+#pragma unroll 1
+            for (int p = 0; p < 7; ++p) {
+                const int ex = X0[p] + NX[p] - 1, ey = Y0[p] + NY[p] - 1;
+                roll = roll && NX[p] > 0 && NY[p] > 0;
+                if (p < 6) roll = roll && X0[p] <= X0[p + 1] && ex <= X0[p + 1] + NX[p + 1] - 1 && Y0[p] <= Y0[p + 1] && ey <= Y0[p + 1] + NY[p + 1] - 1;
+                if (p < 4) roll = roll && X0[p + 3] > ex;
+                if ((p & 1) == 0) roll = roll && (p == 6 ? NY[p] : Y0[p + 1] + NY[p + 1] - Y0[p]) <= RMAX;
+            }
+        }
+        if (roll) {
+            const int phA = 2 * wave, phB = min(2 * wave + 1, 6);
+            const bool two = wave < 3;
+            const int r_lo = Y0[phA];
+            const int nrows = (two ? Y0[phB] + NY[phB] : Y0[phA] + NY[phA]) - r_lo;  // <= RMAX
+            // row weights of the two bin rows over the union of their cell rows: wave-uniform, kept in scalar registers
+            float wA[RMAX], wB[RMAX];
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u) {
+                const int kA = u, kB = r_lo + u - Y0[phB];
+                const float a_ = (u < nrows && kA < NY[phA]) ? WY[phA][kA] : 0.f;
+                const float b_ = (two && u < nrows && kB >= 0 && kB < NY[phB]) ? WY[phB][kB] : 0.f;
+                wA[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a_)));
+                wB[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b_)));
+            }
+            const int x_lo = X0[0], x_hi = X0[6] + NX[6] - 1;
+            const float *base = feat + ((size_t)r_lo * W) * a.C + lane * 4;
+            f32x4 accA[3], accB[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) accA[j] = accB[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int p = 0;  // the lowest bin column whose window has not ended
+            auto load_col = [&](f32x4 (&v)[RMAX], const int x) {  // (a column past x_hi is clamped: loaded, never used)
+                const int xc = min(x, x_hi);
+#pragma unroll
+                for (int u = 0; u < RMAX; ++u)
+                    if (u < nrows) v[u] = *reinterpret_cast<const f32x4 *>(base + ((size_t)u * W + xc) * a.C);
+            };
+            auto use_col = [&](const f32x4 (&v)[RMAX], const int x) {
+                f32x4 cA = {0.f, 0.f, 0.f, 0.f}, cB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < RMAX; ++u)
+                    if (u < nrows) {
+                        cA += wA[u] * v[u];
+                        cB += wB[u] * v[u];
+                    }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int q = min(p + j, 6), k = x - X0[q];
+                    const float w = (p + j < 7 && k >= 0 && k < NX[q]) ? WX[q][k] : 0.f;
+                    accA[j] += w * cA;
+                    accB[j] += w * cB;
+                }
+                while (p < 7 && x == X0[p] + NX[p] - 1) {  // bin column p is complete (two bins may end on one column)
+                    emit(phA * 7 + p, lane * 4, accA[0] / count);
+                    if (two) emit(phB * 7 + p, lane * 4, accB[0] / count);
+                    accA[0] = accA[1];
+                    accA[1] = accA[2];
+                    accA[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    accB[0] = accB[1];
+                    accB[1] = accB[2];
+                    accB[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ++p;
+                }
+            };
+            // two columns in flight: column x + 1 is requested before column x is consumed
+            f32x4 v0[RMAX], v1[RMAX];
+            load_col(v0, x_lo);
+            for (int x = x_lo; x <= x_hi; x += 2) {
+                load_col(v1, x + 1);
+                use_col(v0, x);
+                load_col(v0, x + 2);
+                if (x + 1 <= x_hi) use_col(v1, x + 1);
+            }
+        } else {
         constexpr int NC = A3D_ROI_NC;  // cells held in registers per bin (sampling grid + 1 in each direction)
         const int nbins = a.P * a.P;
         auto issue = [&](f32x4 (&v)[NC], int bin) -> int {  // all loads of one bin, nothing waited for
@@ -268,6 +354,7 @@ __global__ __launch_bounds__(64 * NW, H2 ? 3 : 1) void roi_align_fpn_kernel(cons
                 emit(bin, c4 * 4, acc / count);
             }
         }
+        }  // (bin-by-bin walk)
     } else
     // general path (very large sampling grids): per-sample evaluation, as torchvision writes it
     for (int bin = wave; bin < a.P * a.P; bin += NW) {
@@ -371,6 +458,7 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     a.out = d->out;
     a.out_level = d->out_level;
     a.serial = d->serial == 1;
+    a.rolling = d->serial == 2;
     a.order = nullptr;
     a.nblk = d->B * d->R;
     a.out_amax = d->out_amax;
@@ -402,7 +490,10 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
         }
         return a3d_check_launch();
     }
-    hipLaunchKernelGGL((roi_align_fpn_kernel<4, false>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.rolling && d->P == 7 && d->C == 256)  // (its own instantiation: the rolling walk's registers must not cost the other poolers their occupancy)
+        hipLaunchKernelGGL((roi_align_fpn_kernel<4, false, true>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((roi_align_fpn_kernel<4, false>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();
 }
 

@@ -156,15 +156,28 @@ def test_torch_ops_give_the_same_bits_as_the_ctypes_wrappers():
     big = torch.cat([xy, xy + wh], -1).cuda()
     cnt = torch.tensor([600, 333], dtype=torch.int32).cuda()
     live = torch.cat([torch.arange(600), 600 + torch.arange(333)])
-    ref = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
-    ops.ROI_SPATIAL_ORDER = False
-    ops.ROI_SERIAL = True
+    rolling = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)  # (the default since round 6: the rolling-window walk)
+    saved_roll, ops.ROI_ROLLING = ops.ROI_ROLLING, False
     try:
-        plain = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
+        ref = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
+        ops.ROI_SPATIAL_ORDER = False
+        ops.ROI_SERIAL = True
+        try:
+            plain = ops.roi_align_fpn(feats, scales, big, cnt, 7, 0, True)
+        finally:
+            ops.ROI_SPATIAL_ORDER = True
+            ops.ROI_SERIAL = False
     finally:
-        ops.ROI_SPATIAL_ORDER = True
-        ops.ROI_SERIAL = False
+        ops.ROI_ROLLING = saved_roll
     assert torch.equal(ref[live], plain[live])
+    # the rolling-window walk of the 7x7 pooler sums (column, row) instead of (row, column): equal to the bin-by-bin walk to fp32
+    # rounding, and a function of the ROI alone -- the same box gives the same bits in another batch composition and slot order
+    assert saved_roll and float((rolling[live] - ref[live]).abs().max() / ref[live].abs().max()) < 1e-6
+    assert not torch.equal(rolling[live], ref[live])  # (it IS another summation order: the test would not notice a silent fallback otherwise)
+    perm = torch.randperm(333)
+    shuffled = ops.roi_align_fpn([f[1:2].contiguous() for f in feats], scales, big[1:2, :333][:, perm].contiguous(),
+                                 torch.tensor([333], dtype=torch.int32).cuda(), 7, 0, True)
+    assert torch.equal(shuffled[:333], rolling[600 + perm])
     gb = torch.zeros(2, ops.GROUP_CAP, 4).cuda()
     gb[:, :50] = boxes
     gv = torch.zeros(2, ops.GROUP_CAP, dtype=torch.int32).cuda()

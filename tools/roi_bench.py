@@ -48,6 +48,7 @@ def main():
     for name, boxes, count, P, ratio, aligned in cases:
         n = int(count.sum())
         f = lambda: ops.roi_align_fpn(lv, scales, boxes, count, P, ratio, aligned)
+        ops.ROI_ROLLING = False  # (the three bin-by-bin forms first: they agree bit for bit)
         ops.ROI_SERIAL = True
         y_s = f()
         t_s = timeit(f)
@@ -58,12 +59,18 @@ def main():
         ops.ROI_SPATIAL_ORDER = True
         y_b = f()
         t_b = timeit(f)
+        y_r, t_r = None, float("nan")
+        if P == 7:
+            ops.ROI_ROLLING = True
+            y_r = f()
+            t_r = timeit(f)
+        ops.ROI_ROLLING = True
         R = boxes.shape[1]
         live = torch.cat([torch.arange(int(c)) + b * R for b, c in enumerate(count.tolist())]).cuda()
         same = bool(torch.equal(y_s[live], y_b[live]) and torch.equal(y_u[live], y_b[live]))
         wbytes = n * P * P * 256 * 4
         print(f"{name:28s} rois {n:6d}  serialized {t_s:7.3f} ms  batched {t_u:7.3f} ms  + spatial order {t_b:7.3f} ms  output {wbytes / 1e9:5.2f} GB -> {wbytes / t_b / 1e6:7.1f} GB/s written"
-              f"  bit-identical={same}", flush=True)
+              f"  bit-identical={same}" + ("" if y_r is None else f"  | rolling window {t_r:7.3f} ms, max |diff| / max {float((y_r[live] - y_b[live]).abs().max() / y_b[live].abs().max()):.2e}"), flush=True)
 
 
 if __name__ == "__main__":
