@@ -60,16 +60,17 @@ class BottleneckBlock(nn.Module):
         y = self.conv2(self.conv1(x))
         return self.conv3(y, res=sc)
 
-    def forward_pair(self, x, a=None, nxt=None):
+    def forward_pair(self, x, a=None, nxt=None, frozen=False):
         """The block with its first layer possibly done already (`a` = conv1(x), produced by the previous block's launch) and its last
         layer possibly producing the NEXT block's first (`nxt`): returns (block output, nxt.conv1(block output) or None).
         conv3 + FrozenBN + residual + ReLU and the next conv1 + FrozenBN + ReLU as ONE launch (ops.conv2d_b2b, csrc/conv_xs_b2b.hip) where
-        the pair has that form -- the block output is written once and not read back by the squeeze that follows it."""
+        the pair has that form -- the block output is written once and not read back by the squeeze that follows it.
+        frozen: the caller vouches that these layers do not train (the trainer's stem / res2 under FREEZE_AT 2), whatever the module mode."""
         from .layers import _CalibrationState
 
         sc = self.shortcut(x) if self.shortcut is not None else x
         b = self.conv2(self.conv1(x) if a is None else a)
-        if nxt is not None and not _CalibrationState.active and not self.training:
+        if nxt is not None and not _CalibrationState.active and (frozen or not self.training):
             pair = ops.conv2d_b2b(b, self.conv3.packed(), sc, nxt.conv1.packed())
             if pair is not None:
                 return pair
@@ -100,15 +101,19 @@ class ResNet(nn.Module):
             self._out_feature_channels[name], self._out_feature_strides[name] = out_c, stride_total
             out_c, mid = out_c * 2, mid * 2
 
+    def forward_stage(self, name: str, x, frozen: bool = False):
+        """One residual stage; block i's last layer may hand block i + 1 its first (BottleneckBlock.forward_pair)."""
+        blocks = list(getattr(self, name))
+        a = None
+        for i, blk in enumerate(blocks):
+            x, a = blk.forward_pair(x, a, blocks[i + 1] if i + 1 < len(blocks) else None, frozen=frozen)
+        return x
+
     def forward(self, x4) -> Dict[str, torch.Tensor]:
         x = self.stem(x4)
         outs = {}
         for name in ("res2", "res3", "res4", "res5"):
-            blocks = list(getattr(self, name))
-            a = None
-            for i, blk in enumerate(blocks):  # (block i's last layer may hand block i + 1 its first: BottleneckBlock.forward_pair)
-                x, a = blk.forward_pair(x, a, blocks[i + 1] if i + 1 < len(blocks) else None)
-            outs[name] = x
+            x = outs[name] = self.forward_stage(name, x)
         return outs
 
     def output_shape(self):

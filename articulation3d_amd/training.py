@@ -583,7 +583,7 @@ class DetectorTrainer:
         relu_outputs = []  # every ReLU output on the trainable path, in forward order (aux: lets a checker reuse the gates)
         with torch.no_grad():
             x4 = ops.preprocess_u8hwc(frames_u8.contiguous(), self.pixel_mean, self.pixel_std)
-            x = m.backbone.bottom_up.res2(m.backbone.bottom_up.stem(x4))  # frozen (FREEZE_AT 2)
+            x = m.backbone.bottom_up.forward_stage("res2", m.backbone.bottom_up.stem(x4), frozen=True)  # frozen (FREEZE_AT 2): the inference launches
         res = {"res2": x}
         if prepared is not None:
             self._cur_stream.wait_event(prepared)

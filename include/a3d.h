@@ -357,8 +357,13 @@ typedef struct a3d_roialign_desc {
                           power of two that puts out_amax[row] in [2^14, 2^15) -- a3d_conv_desc.x_h2 of the box head's fc1
                           (roi_heads.py:185-187).  The workgroup keeps the row in LDS until its maximum is known.  Same pooled
                           values as `out` (the split is exact to 2^-22 of the row's maximum). */
-    int serial;        /* schedule only: 1 = a bin's cell loads one at a time (the form the batched loads replaced; kept for the
-                          bit-equality test and tools/roi_bench.py).  0 = the default. */
+    int serial;        /* walk of a ROI's cells.  0 = bin by bin, a bin's loads issued together.  1 = bin by bin, one load at a time (the
+                          same bits as 0: schedule only; kept for the bit-equality test and tools/roi_bench.py).  2 (round 6; P = 7,
+                          C = 256, `out`) = the rolling-window walk: a wave owns two adjacent bin rows and walks the ROI's cell
+                          columns once -- 675 instead of 980 cell loads per typical ROI -- summing in (column, row) order: equal to
+                          0 / 1 to fp32 rounding, not bit for bit; ROIs whose geometry does not fit (a bin without samples, bins
+                          narrower than a cell, more than 8 cell rows per bin-row pair) take walk 0 -- a function of the ROI alone.
+                          The Python layer passes 2 for the 7x7 box pooler (ops.ROI_ROLLING). */
 } a3d_roialign_desc;
 
 int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream);

@@ -134,7 +134,13 @@ def test_presplit_pooler_rows_are_the_split_of_the_fp32_rows(ops, compact):
         off = ops.count_offsets(count, R)
         rows = int(off[-1])
         kw = dict(row_offset=off, rows=rows)
-    f32 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True, **kw)
+    # (the pre-split pooler walks bin by bin: its rows are the split of THAT walk's fp32 rows; the default fp32 pooler's rolling-window walk
+    # of round 6 sums in another order -- equal to fp32 rounding, tests/test_known_answers.py)
+    saved, ops.ROI_ROLLING = ops.ROI_ROLLING, False
+    try:
+        f32 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True, **kw)
+    finally:
+        ops.ROI_ROLLING = saved
     h2 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True, presplit=True, **kw)
     assert h2.dtype == torch.float16 and tuple(h2.shape) == (rows, 1, 1, 49 * 16, 2, 16)
     live = torch.zeros(rows, dtype=torch.bool, device="cuda")
@@ -158,7 +164,11 @@ def test_box_head_on_presplit_rows_equals_the_fp32_rows(ops):
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
     torch.manual_seed(9)
     fc1 = ops.pack_linear(torch.randn(1024, 12544) / 112.0, torch.randn(1024) * 0.1, chw=(256, 7, 7), act=ops.ACT_RELU)
-    f32 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True)
+    saved, ops.ROI_ROLLING = ops.ROI_ROLLING, False  # (the pre-split pooler's walk: bin by bin, see the test above)
+    try:
+        f32 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True)
+    finally:
+        ops.ROI_ROLLING = saved
     h2 = ops.roi_align_fpn(feats, scales, boxes, count, 7, 0, True, zero=True, presplit=True)
     y0 = ops.linear(ops.keep_amax(f32.view(B * R, -1), f32), fc1)
     y1 = ops.linear(h2, fc1)
