@@ -118,38 +118,83 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
         s_krem = k;
         s_cnt = 0;
     }
+    // Round 6: the walks over the level's logits issue their loads EIGHT at a time.  Each of the 6-7 radix passes and the final pick reads one
+    // 64-byte-strided logit per anchor from L2; with the load, its test and an LDS atomic in one loop body the compiler issued load, wait,
+    // atomic per anchor -- 56 dependent L2 round trips per thread and pass on the finest level (57 600 anchors), ~400 per launch: the
+    // latency of this kernel (0.17-0.30 ms), of every single-frame pass and of the training step's proposal stage.  Same keys, same
+    // passes, same selection: bit for bit.
+    constexpr int UB = 8;
+    auto walk = [&](auto &&visit) {
+        for (int i0 = threadIdx.x; i0 < n; i0 += blockDim.x * UB) {
+            u64 c[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                c[u] = composite(min(i, n - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (i0 + u * (int)blockDim.x < n) visit(c[u]);
+        }
+    };
     // radix select (8 bits per pass, most significant first) of the k-th largest composite key
     for (int shift = total_bits - 8; shift >= 0; shift -= 8) {
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         const u64 prefix = s_prefix;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const u64 c = composite(i);
+        walk([&](const u64 c) {
             if ((c >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(c >> shift) & 255u], 1u);
-        }
+        });
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int krem = s_krem, bin = 255;
-            unsigned cum = 0;
-            for (; bin > 0; --bin) {
-                if (cum + hist[bin] >= (unsigned)krem) break;
-                cum += hist[bin];
+        // The bin that holds the k-th key: the first bin, from 255 downwards, at which the running count reaches what is still wanted (bin 0
+        // if none does).  Round 6: by wave 0 -- lane l owns bins 4 l .. 4 l + 3, a shuffle scan gives it the count above its bins, the
+        // highest lane whose bins cross the mark wins -- instead of one thread walking up to 255 LDS reads one after the other in each of the
+        // 6-7 passes (~10 us a pass).  (Measured and dropped in the same round: ballot-aggregated histogram atomics, 171 -> 262 us.)
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const unsigned krem = (unsigned)s_krem;
+            unsigned h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[q] = hist[4 * lane + q];
+            const unsigned tot = h[0] + h[1] + h[2] + h[3];
+            unsigned above = tot;  // inclusive suffix sum over lanes l' >= l ...
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_down(above, off, 64);
+                if (lane + off < 64) above += v;
             }
-            s_krem = krem - (int)cum;
-            s_prefix = (prefix << 8) | (u64)bin;
+            above -= tot;  // ... made exclusive: keys in bins above this lane's
+            int fbin = -1;
+            unsigned fcum = 0, cum = above;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const int bin = 4 * lane + q;
+                if (fbin < 0 && (bin == 0 || cum + h[q] >= krem)) {
+                    fbin = bin;
+                    fcum = cum;
+                }
+                cum += h[q];
+            }
+            const u64 found = __ballot(fbin >= 0);  // (lane 0 always finds: bin 0 is the fall-through)
+            const int win = 63 - __builtin_clzll(found);
+            const int bin = __builtin_amdgcn_readlane(fbin, win);
+            const unsigned cumw = (unsigned)__builtin_amdgcn_readlane((int)fcum, win);
+            if (lane == 0) {
+                s_krem = (int)(krem - cumw);
+                s_prefix = (prefix << 8) | (u64)bin;
+            }
         }
         __syncthreads();
     }
     const u64 T = s_prefix;
     for (int i = threadIdx.x; i < CAP; i += blockDim.x) sel[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const u64 c = composite(i);
+    walk([&](const u64 c) {
         if (c >= T) {
             const int slot = atomicAdd(&s_cnt, 1);
             if (slot < CAP) sel[slot] = c;
         }
-    }
+    });
     bitonic_sort_desc(sel, CAP);
     for (int r = threadIdx.x; r < CAP; r += blockDim.x) {
         float box[4] = {0.f, 0.f, 0.f, 0.f};
@@ -260,12 +305,15 @@ __global__ __launch_bounds__(1024) void box_candidates_kernel(const BoxCandArgs 
 // ------------------------------------------------------------------------------------------------
 // CAP = 1024: the suppression words live in LDS (128 KiB).  CAP = 2048 (training's PRE_NMS_TOPK 2000): 2048 x 32 words =
 // 512 KiB per group do not fit, they go to a global scratch area (`gmask`, L2-resident) -- same algorithm, same results.
-template <int CAP>
+// GM: the suppression words live in global memory (`gmask`, filled by nms_mask_kernel<CAP>): always at CAP 2048; at CAP 1024 when the launch
+// has fewer groups than the chip has CUs (round 6) -- one workgroup per group computing its 512 K IoUs alone left a single frame's five RPN
+// groups at 0.19 ms on five CUs; spread over the chip the words take ~10 us and the group's own workgroup only scans.  Same words, same scan.
+template <int CAP, bool GM = (CAP > 1024)>
 __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                          const int *__restrict__ g_n, int *__restrict__ g_keep,
                                                          float thr, u64 *__restrict__ gmask, const int have_mask, const int inner) {
     constexpr int W = CAP / 64;  // suppression words per row
-    __shared__ u64 smask[CAP == 1024 ? 1024 * 16 : 1];
+    __shared__ u64 smask[GM ? 1 : CAP * (CAP / 64)];
     __shared__ f32x4 sb[CAP];
     __shared__ unsigned char sv[CAP];
     // One workgroup per CU (144 KiB of LDS), so 64 frames x 5 levels = 320 groups take two rounds of the chip.  Groups are g = image *
@@ -273,7 +321,7 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
     // groups (240 anchors) for the second one instead of a random fifth of everything.
     const int nimg = gridDim.x / inner;
     const int g = (blockIdx.x % nimg) * inner + blockIdx.x / nimg;
-    u64 *mask = (CAP == 1024) ? smask : gmask + (size_t)g * CAP * W;
+    u64 *mask = GM ? gmask + (size_t)g * CAP * W : smask;
     const int n = min(g_n[g], CAP);
     for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
         sb[i] = *reinterpret_cast<const f32x4 *>(g_boxes + ((size_t)g * CAP + i) * 4);
@@ -314,23 +362,33 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
             const int row = (wi << 6) + lane;
             const u64 diag = (row < n) ? mask[row * W + wi] : 0;
             const u64 validbits = __ballot(row < n && sv[row]);
-            u64 cur = __shfl(R, wi, 64);  // removed bits of this block so far
+            // The 64-step chain of a block runs on the SCALAR unit (round 6): removed / kept words are wave-uniform, a row's diagonal word
+            // comes out of its lane by v_readlane with a constant lane.  (With __shfl the compiler kept the chain in vector registers:
+            // two ds_bpermute + a wait per step, ~100 cycles x 64 steps x 16 blocks = 45 us per 1000-box group on ONE wave -- the
+            // latency of this launch, of every single-frame pass and of the training step's proposal stage.)  Same bit logic: same keep masks.
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            const unsigned rlo = (unsigned)R, rhi = (unsigned)(R >> 32);
+            u64 cur = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, wi) << 32) | (unsigned)__builtin_amdgcn_readlane((int)rlo, wi);  // removed bits of this block so far
             u64 kept = 0;
-            for (int bq = 0; bq < 64; ++bq) {
-                const u64 d = __shfl(diag, bq, 64);
-                const bool alive = ((validbits >> bq) & 1) && !((cur >> bq) & 1);
-                if (alive) {
-                    kept |= (u64)1 << bq;
-                    cur |= d;
-                }
+            // (one step per KEPT box of the block, not per box: the lowest box still alive is kept, its row's diagonal word -- bits of the
+            // LATER boxes it suppresses -- joins the removed set, and everything removed drops out of the candidates)
+            u64 avail = validbits & ~cur;
+            while (avail) {
+                const int bq = __builtin_ctzll(avail);
+                const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, bq) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, bq);
+                kept |= (u64)1 << bq;
+                cur |= d;
+                avail &= ~cur & ~((u64)1 << bq);
             }
             if (row < CAP) g_keep[(size_t)g * CAP + row] = (int)((kept >> lane) & 1);
             const int w = lane % W, sub = lane / W;  // 64 / W row subsets of W rows each
             u64 acc = 0;
-            if constexpr (CAP == 1024) {
-                for (int t = 0; t < W; ++t) {
+            if constexpr (!GM) {
+#pragma unroll
+                for (int t = 0; t < W; ++t) {  // (branch-free: sixteen independent LDS reads in flight instead of a read behind every test)
                     const int rr = sub * W + t;
-                    if ((kept >> rr) & 1) acc |= mask[((wi << 6) + rr) * W + w];
+                    const u64 m = mask[((wi << 6) + rr) * W + w];
+                    acc |= ((kept >> rr) & 1) ? m : 0;
                 }
             } else {
                 // the words live in global memory here: the kept rows of this lane's subset in batches of eight requests in flight (one
@@ -359,9 +417,10 @@ __global__ __launch_bounds__(1024) void group_nms_kernel(const float *__restrict
 
 // Suppression words of a 2048-slot group computed by 16 workgroups instead of one (the single-workgroup form spends
 // 2 ms per launch on the 2M IoUs of a full group while 246 CUs idle): grid (G, 16), block y owns rows [128y, 128y+128).
+template <int CAP>
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                        const int *__restrict__ g_n, float thr, u64 *__restrict__ gmask) {
-    constexpr int CAP = 2048, W = 32;
+    constexpr int W = CAP / 64;
     const int ROWS = CAP / (int)gridDim.y;  // (128 rows per workgroup at 16 workgroups per group; 32 at 64, where few groups would leave the chip idle)
     __shared__ f32x4 sb[CAP];
     __shared__ unsigned char sv[CAP];
@@ -461,10 +520,16 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restric
 }
 
 // ================================= C ABI ==========================================================
+// Launches with fewer groups than this compute their suppression words chip-wide into global scratch (nms_mask_kernel<1024>) and scan from
+// there (group_nms_kernel<1024, true>); from here on a group's own workgroup keeps them in LDS.  192 groups x 128 KiB = 24 MiB of scratch.
+#define A3D_NMS_SPLIT_GROUPS 192
 extern "C" size_t a3d_group_buffers_bytes(int n_groups) {
-    // boxes(16) + scores(4) + pos(4) + valid(4) + keep(4) per slot, + n per group
-    return (size_t)n_groups * GROUP_CAP * 32 + (size_t)n_groups * 4 + 256;
+    // boxes(16) + scores(4) + pos(4) + valid(4) + keep(4) per slot, + n per group (+ the global suppression words of a small launch)
+    size_t b = (size_t)n_groups * GROUP_CAP * 32 + (size_t)n_groups * 4 + 256;
+    if (n_groups <= A3D_NMS_SPLIT_GROUPS) b += 8 + (size_t)n_groups * GROUP_CAP * (GROUP_CAP / 64) * sizeof(u64);
+    return b;
 }
+
 
 // Workspace of a3d_rpn_proposals: group buffers with 1024 slots (pre_topk <= 1024) or 2048 slots plus the global
 // suppression words of the 2048-candidate NMS (training's PRE_NMS_TOPK_TRAIN 2000).
@@ -495,8 +560,17 @@ static GroupBufs carve(void *ws, int G, int cap = GROUP_CAP) {
     p += (size_t)G * cap * 4;
     gb.n = (int *)p;
     p += (size_t)G * 4 + 256;
-    gb.mask = (u64 *)(((uintptr_t)p + 7) & ~(uintptr_t)7);  // (only the 2048-slot form owns bytes here)
+    gb.mask = (u64 *)(((uintptr_t)p + 7) & ~(uintptr_t)7);  // (the 2048-slot form, and 1024-slot launches of <= A3D_NMS_SPLIT_GROUPS groups, own bytes here)
     return gb;
+}
+// the 1024-slot NMS of G groups whose buffers `gb` were carved from a3d_group_buffers_bytes(G)
+static void launch_group_nms_1024(const GroupBufs &gb, int G, float thr, int inner, hipStream_t s) {
+    if (G <= A3D_NMS_SPLIT_GROUPS) {  // few groups: the words by the whole chip (32-row blocks), then one scanning workgroup per group
+        hipLaunchKernelGGL(nms_mask_kernel<1024>, dim3(G, 32), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, thr, gb.mask);
+        hipLaunchKernelGGL((group_nms_kernel<1024, true>), dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, thr, gb.mask, 1, inner);
+    } else {
+        hipLaunchKernelGGL((group_nms_kernel<1024, false>), dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, thr, nullptr, 0, inner);
+    }
 }
 
 extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
@@ -538,14 +612,14 @@ extern "C" int a3d_rpn_proposals(const a3d_rpn_desc *d, void *stream) {
     a3d_begin();
     if (cap == GROUP_CAP) {
         hipLaunchKernelGGL(rpn_select_kernel<1024>, dim3(d->L, d->B), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0, d->L);
+        launch_group_nms_1024(gb, G, d->nms_thresh, d->L, s);
         hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
     } else {
         hipLaunchKernelGGL(rpn_select_kernel<2048>, dim3(d->L, d->B), dim3(1024), 0, s, a);
         // (the suppression words of a group by 16 workgroups -- or 64 where the batch is a few images: the first row block of a group carries
         // most of its upper-triangular work, and 10 groups x 16 blocks left the launch at the length of that one block: 0.23 ms)
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(G, G <= 40 ? 64 : 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
+        hipLaunchKernelGGL(nms_mask_kernel<2048>, dim3(G, G <= 40 ? 64 : 16), dim3(256), 0, s, gb.boxes, gb.valid, gb.n, d->nms_thresh, gb.mask);
         hipLaunchKernelGGL(group_nms_kernel<2048>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, gb.mask, 1, d->L);
         hipLaunchKernelGGL((merge_topk_kernel<2048, 16384>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n,
                            d->L, d->post_topk, d->out_boxes, d->out_scores, d->out_level, d->out_pos, d->out_count);
@@ -584,7 +658,7 @@ extern "C" int a3d_box_detections(const a3d_boxdet_desc *d, void *stream) {
     a.g_n = gb.n;
     a3d_begin();
     hipLaunchKernelGGL(box_candidates_kernel, dim3(d->C, d->B), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(G), dim3(1024), 0, s, gb.boxes, gb.valid, gb.n, gb.keep, d->nms_thresh, nullptr, 0, d->C);
+    launch_group_nms_1024(gb, G, d->nms_thresh, d->C, s);
     hipLaunchKernelGGL((merge_topk_kernel<1024, MERGE_CAP>), dim3(d->B), dim3(1024), 0, s, gb.boxes, gb.scores, gb.pos, gb.keep, gb.n, d->C,
                        d->topk, d->out_boxes, d->out_scores, d->out_classes, d->out_pos, d->out_count);
     return a3d_check_launch();
@@ -595,7 +669,7 @@ extern "C" int a3d_group_nms(const float *g_boxes, const int *g_valid, const int
                              float thresh, void *stream) {
     if (!g_boxes || !g_valid || !g_n || !g_keep || n_groups <= 0) return A3D_ERR_ARG;
     a3d_begin();
-    hipLaunchKernelGGL(group_nms_kernel<1024>, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
+    hipLaunchKernelGGL((group_nms_kernel<1024, false>), dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, g_boxes, g_valid, g_n,
                        g_keep, thresh, nullptr, 0, 1);
     return a3d_check_launch();
 }
