@@ -492,6 +492,11 @@ extern "C" int a3d_roi_align_fpn(const a3d_roialign_desc *d, void *stream) {
     }
     if (a.rolling && d->P == 7 && d->C == 256)  // (its own instantiation: the rolling walk's registers must not cost the other poolers their occupancy)
         hipLaunchKernelGGL((roi_align_fpn_kernel<4, false, true>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
+    else if (d->P >= 12)
+        // the 14 x 14 poolers (mask, plane / axis): 196 bins per ROI and a handful of ROIs per frame -- sixteen waves per ROI instead of four
+        // (round 6: a single frame's four detections were four workgroups walking 49 bins per wave one memory round trip at a time, 95 us a
+        // launch).  Bins are computed exactly as before, only dealt to more waves: the same bits, the same per-ROI maximum.
+        hipLaunchKernelGGL((roi_align_fpn_kernel<16, false>), dim3(d->B * d->R), dim3(1024), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((roi_align_fpn_kernel<4, false>), dim3(d->B * d->R), dim3(256), 0, (hipStream_t)stream, a);
     return a3d_check_launch();

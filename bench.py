@@ -693,7 +693,7 @@ def main():
                           dist=dist if use_dist else None, model=model)
             roof = r["roofline"]
             legs[f"images_per_gpu_{tb}"] = {
-                "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "dtype": r["dtype"],
+                "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "timing": r["timing"], "dtype": r["dtype"],
                 "config": r["config"], "launches_per_step": r.get("launches_per_step"), "collective": r.get("collective"),
                 "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "pipe", "launches", "avg_launch_ms", "whole_step", "source")},
                 "top_kernels": dict(list(roof["all_gemm_kernels"].items())[:6]),
