@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
     __shared__ u64 sel[CAP];
     __shared__ unsigned int hist[256];
     __shared__ u64 s_prefix;
-    __shared__ int s_krem, s_cnt;
+    __shared__ int s_krem, s_cnt, s_done;
     const int l = blockIdx.x, b = blockIdx.y, g = b * a.L + l;
     const RpnLevel &lv = a.lv[l];
     const int n = lv.Hf * lv.Wf * a.A;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
         s_prefix = 0;
         s_krem = k;
         s_cnt = 0;
+        s_done = 0;
     }
     // Round 6: the walks over the level's logits issue their loads EIGHT at a time.  Each of the 6-7 radix passes and the final pick reads one
     // 64-byte-strided logit per anchor from L2; with the load, its test and an LDS atomic in one loop body the compiler issued load, wait,
@@ -180,11 +181,16 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const RpnSelectArgs a)
             const int bin = __builtin_amdgcn_readlane(fbin, win);
             const unsigned cumw = (unsigned)__builtin_amdgcn_readlane((int)fcum, win);
             if (lane == 0) {
+                // (when the chosen bin and the bins above it hold EXACTLY what is still wanted, every key of that bin is selected: the bin's
+                // lower bound is the threshold and the remaining passes -- typically the 16 index bits behind a unique score -- add nothing)
+                const bool exact = cumw + hist[bin] == krem;
                 s_krem = (int)(krem - cumw);
-                s_prefix = (prefix << 8) | (u64)bin;
+                s_prefix = exact ? (((prefix << 8) | (u64)bin) << shift) : ((prefix << 8) | (u64)bin);
+                s_done = exact ? 1 : 0;
             }
         }
         __syncthreads();
+        if (s_done) break;
     }
     const u64 T = s_prefix;
     for (int i = threadIdx.x; i < CAP; i += blockDim.x) sel[i] = 0;
