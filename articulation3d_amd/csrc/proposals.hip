@@ -427,7 +427,7 @@ template <int CAP>
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__ g_boxes, const int *__restrict__ g_valid,
                                                        const int *__restrict__ g_n, float thr, u64 *__restrict__ gmask) {
     constexpr int W = CAP / 64;
-    const int ROWS = CAP / (int)gridDim.y;  // (128 rows per workgroup at 16 workgroups per group; 32 at 64, where few groups would leave the chip idle)
+    const int ROWS = CAP / (int)gridDim.y;  // (rows per workgroup: 128 at 16 workgroups per 2048-slot group, 32 at 64 -- and at 32 per 1024-slot group)
     __shared__ f32x4 sb[CAP];
     __shared__ unsigned char sv[CAP];
     const int g = blockIdx.x;
@@ -440,29 +440,35 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float *__restrict__
     }
     __syncthreads();
     const int nwords = (n + 63) >> 6;
+    const int r1 = min(r0 + ROWS, n);
     u64 *mask = gmask + (size_t)g * CAP * W;
+    // Round 6: a WAVE forms one 64-box word per step -- lane t owns box j = 64 w + t of the word (in registers across the rows), the row's box
+    // is an LDS broadcast, the word is the ballot of the 64 comparisons.  (Before, a THREAD looped over the 64 boxes of its word: half
+    // the lanes of a wave sat in the lower triangle, the rest diverged on per-box tests, and every pair re-read box j from LDS -- 0.33 ms
+    // chip-wide for the 320 groups of a 64-frame step.)  Same pairs, same expression per pair: the same words.
+    // words that hold no pair (at or below the diagonal, past the last box, rows of dead boxes): zero
     for (int wd = threadIdx.x; wd < ROWS * W; wd += blockDim.x) {
         const int i = r0 + wd / W, w = wd % W;
-        if (i >= n) continue;
-        u64 bits = 0;
-        if (w < nwords && (w << 6) + 63 > i && sv[i]) {
+        if (i < n && !(w < nwords && (w << 6) + 63 > i && sv[i])) mask[(size_t)i * W + w] = 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int w = r0 >> 6; w < nwords; ++w) {  // (a word below r0 >> 6 lies under the diagonal for every row of this block)
+        const int j = (w << 6) + lane;
+        const f32x4 bj = sb[min(j, CAP - 1)];
+        const bool vj = j < n && sv[min(j, CAP - 1)];
+        const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+        for (int i = r0 + wave; i < r1; i += nw) {
+            if (!((w << 6) + 63 > i) || !sv[i]) continue;  // (wave-uniform)
             const f32x4 bi = sb[i];
             const float ai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
-            const int j0 = w << 6;
-            for (int t = 0; t < 64; ++t) {
-                const int j = j0 + t;
-                if (j <= i || j >= n || !sv[j]) continue;
-                const f32x4 bj = sb[j];
-                const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
-                const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
-                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-                const float inter = iw * ih;
-                const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
-                const float ovr = inter / (ai + aj - inter);
-                if (ovr > thr) bits |= (u64)1 << t;
-            }
+            const float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+            const float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+            const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+            const float inter = iw * ih;
+            const float ovr = inter / (ai + aj - inter);
+            const u64 bits = __ballot(vj && j > i && ovr > thr);
+            if (lane == 0) mask[(size_t)i * W + w] = bits;
         }
-        mask[(size_t)i * W + w] = bits;
     }
 }
 
@@ -526,9 +532,11 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float *__restric
 }
 
 // ================================= C ABI ==========================================================
-// Launches with fewer groups than this compute their suppression words chip-wide into global scratch (nms_mask_kernel<1024>) and scan from
-// there (group_nms_kernel<1024, true>); from here on a group's own workgroup keeps them in LDS.  192 groups x 128 KiB = 24 MiB of scratch.
-#define A3D_NMS_SPLIT_GROUPS 192
+// Launches of up to this many groups compute their suppression words chip-wide into global scratch (nms_mask_kernel<1024>) and scan from there
+// (group_nms_kernel<1024, true>); larger ones keep them in the LDS of a group's own workgroup.  The words of a full group are 512 K IoUs --
+// ~0.2 ms of ONE CU: a single frame's five RPN groups ran on five CUs (0.19 ms a launch, now 0.05), and the 320 groups of a 64-frame step
+// took two rounds of the 256 CUs (0.47 ms, the second round a quarter full).  1024 groups x 128 KiB = 128 MiB of scratch at most.
+#define A3D_NMS_SPLIT_GROUPS 1024
 extern "C" size_t a3d_group_buffers_bytes(int n_groups) {
     // boxes(16) + scores(4) + pos(4) + valid(4) + keep(4) per slot, + n per group (+ the global suppression words of a small launch)
     size_t b = (size_t)n_groups * GROUP_CAP * 32 + (size_t)n_groups * 4 + 256;
