@@ -307,7 +307,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v2_kernel(const a3d_co
         const int m = (int)(i / n4);
         const int n = (int)(i - (size_t)m * n4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < d.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(d.workspace + ((size_t)z * Mmax + m) * d.Cout + n);
+        // (eight slices requested before the first is added: the head FCs' reduce -- 276 rows x 32 slices -- is a few waves per CU, and one
+        // load per add left it at the latency of 32 dependent-looking round trips, 74 us for 36 MB.  Slices are added in z order as before.)
+        const float *wq = d.workspace + (size_t)m * d.Cout + n;
+        const size_t zs = (size_t)Mmax * d.Cout;
+        int z = 0;
+        for (; z + 8 <= d.splitk; z += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const f32x4 *>(wq + (size_t)(z + q) * zs);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += t[q];
+        }
+        for (; z < d.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(wq + (size_t)z * zs);
         size_t res_row;
         int b, oh, ow;
         out_rows(d, m, res_row, b, oh, ow);
