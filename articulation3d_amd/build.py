@@ -32,6 +32,7 @@ SOURCES = {
     "conv_bf16x3_wide.hip": [],
     "conv_xs_h2.hip": [],
     "conv_xs_b2b.hip": [],
+    "conv_sg_h2.hip": [],
     "conv_ph4p.hip": [],
     "conv_wgrad_tr.hip": [],
     "conv_stem_pool.hip": [],

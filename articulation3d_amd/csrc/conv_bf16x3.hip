@@ -564,6 +564,10 @@ int a3d_conv_launch_bf16x3(const a3d_conv_desc *d0, hipStream_t s) {
         d = &dd;
     }
     if (d->precision == 3 && (!d->in_amax || !(d->w_scale > 0.f))) return A3D_ERR_ARG;
+    if (d->precision == 3 && (d->tune == 0 || d->tune == 17)) {  // small grids (single frames): a wave per 32 x 32 tile, no LDS (bit-identical results)
+        const int rs = a3d_conv_launch_sg_h2(d, s);
+        if (rs != A3D_ERR_UNSUPPORTED) return rs;
+    }
     if (d->precision == 3 && (d->tune == 0 || d->tune == 13)) {  // HBM-bound 1x1 layers, Cin <= 256: x read once (bit-identical results)
         const int rx = a3d_conv_launch_xs_h2(d, s);
         if (rx != A3D_ERR_UNSUPPORTED) return rx;

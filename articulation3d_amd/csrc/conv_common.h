@@ -135,6 +135,11 @@ int a3d_conv_launch_v2(const a3d_conv_desc *d, hipStream_t s);
 // layer, tune 14 keeps it off.  A3D_ERR_UNSUPPORTED: not such a layer.
 int a3d_conv_launch_xs_h2(const a3d_conv_desc *d, hipStream_t s);
 
+// fp16x2 pointwise layers on SMALL grids (one frame): one wave per 32 x 32 output tile, operands straight into registers
+// (conv_sg_h2.hip; the same bits); launches of up to A3D_SG_MAX_WAVES such tiles; tune 17 = whatever the size.
+#define A3D_SG_MAX_WAVES 1280
+int a3d_conv_launch_sg_h2(const a3d_conv_desc *d, hipStream_t s);
+
 // Persistent pointwise kernel (conv_pw.hip): 1x1 stride-1 layers with K <= 2048 and enough tiles to keep a persistent
 // grid busy.  Returns A3D_ERR_UNSUPPORTED otherwise.  `force` skips the grid-size heuristic (A/B measurements).
 int a3d_conv_launch_pw(const a3d_conv_desc *d, hipStream_t s, int force);

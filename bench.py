@@ -83,6 +83,9 @@ def rocprof_name(variant: str) -> str:
     m = re.match(r"conv_h2xs_b2b_kernel<(\d+),(\d+)>$", v)  # (the back-to-back pointwise pair: <Cin / 16, N groups, chunks per stage, Cout2 / 32, prefetch>)
     if m:
         return {"64": "conv_xs_b2b_kernel<4, 2, 2, 2, true>", "128": "conv_xs_b2b_kernel<8, 2, 2, 4, false>"}[m.group(1)]
+    m = re.match(r"conv_h2sg_kernel<(\d)>$", v)  # (small-grid pointwise kernel: <chunks in flight per wave>)
+    if m:
+        return f"conv_sg_kernel<{m.group(1)}>"
     if v == "wino_gemm_h2w_kernel<2> planes + wino_fold_kernel":  # (the plane-split form of small problems: its GEMM launch)
         return "wino_gemm_x3w_kernel<2, true, true, 0>"
     m = re.match(r"wino_gemm_(x3|h2)w_kernel<(\d)>$", v)

@@ -95,7 +95,9 @@ typedef struct a3d_conv_desc {
                          9 = the wide direct kernel whatever the problem size, 10 / 11 = its narrow kernel with 128 x 64 /
                          128 x 128 tiles, 12 = per-lane accumulator stores instead of the row-major epilogue through LDS (the
                          same bits; A/B runs); precision 3: 13 / 14 = always / never the activation-stationary pointwise kernel on an
-                         eligible 1x1 layer (Cin 64 / 128 / 256, Cout % 128 == 0; the same bits); 15 / 16 = the tap-outer / the patch-resident
+                         eligible 1x1 layer (Cin 64 / 128 / 256, Cout % 128 == 0; the same bits); 17 = the small-grid pointwise kernel (one wave per
+                         32 x 32 output tile, csrc/conv_sg_h2.hip; Cin % 64 == 0, Cout % 32 == 0) whatever the grid size -- tune 0 takes it for
+                         launches of up to 1280 such tiles (single frames), 10 / 11 never (the same bits); 15 / 16 = the tap-outer / the patch-resident
                          form of a 3x3 s1 p1 layer (phase 5: every launch is patch-resident by default, 15 is the bit-equality link to
                          the four-launch form; phase 0: 16 forces the patch-resident kernel on a layer whose map its tiles fit badly;
                          the two forms reduce in different orders: equal to fp32 rounding, not bit for bit); Winograd layers: 23 = the

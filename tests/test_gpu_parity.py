@@ -333,6 +333,39 @@ def test_activation_stationary_pointwise_kernel_agrees_bit_for_bit_with_the_tile
     assert float(ops.amax_of(a).max()) > 0
 
 
+@pytest.mark.parametrize("case", [(1, 30, 40, 1024, 256, 1, "none"), (1, 15, 20, 2048, 512, 1, "none"), (1, 15, 20, 512, 2048, 1, "res"), (1, 60, 80, 512, 256, 2, "none"),
+                                  (1, 30, 40, 1024, 256, 1, "ups"), (3, 13, 17, 192, 96, 1, "res"), (2, 29, 31, 64, 128, 2, "none"), (1, 1, 1, 256, 32, 1, "none"),
+                                  (5, 9, 7, 320, 64, 1, "res")])
+def test_small_grid_pointwise_kernel_agrees_bit_for_bit_with_the_tiled_one(ops, case):
+    """conv_h2sg_kernel (conv_sg_h2.hip: one wave per 32 x 32 output tile, operand fragments straight into a register ring, no LDS, no
+    barrier -- what the deep 1x1 layers of the trunk run as when ONE frame arrives, the reference's own loop, tools/inference.py:215-228)
+    against conv_h2_kernel on the same layer: same split, same k order, same three products per chunk into one accumulator, same epilogue
+    -- outputs AND recorded per-image maxima are identical, so the launcher chooses by grid size and a frame's bits do not depend on its
+    batch.  Strides, residual rows (plain and from the 2 x coarser level), both ring depths, ragged pixel counts, waves that straddle
+    images of magnitudes 10^4 apart."""
+    B, H, W, Cin, Cout, stride, resk = case
+    torch.manual_seed(B * 1000 + Cin + Cout)
+    x = torch.relu(torch.randn(B, H, W, Cin, device="cuda")) * torch.logspace(-2, 2, B, device="cuda")[:, None, None, None]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    kw = {}
+    if resk == "res":
+        kw = dict(res=torch.randn(B, Ho, Wo, Cout, device="cuda"))
+    elif resk == "ups":
+        kw = dict(res=torch.randn(B, Ho // 2, Wo // 2, Cout, device="cuda"), res_ups=True)
+    pk = ops.pack_conv(torch.randn(Cout, Cin, 1, 1) / Cin ** 0.5, torch.randn(Cout) * 0.1, None, stride, 0, ops.ACT_RELU)
+    a = ops.conv2d(x, pk, precision=3, tune=17, **kw)
+    assert ops.last_conv_variant() == f"conv_h2sg_kernel<{8 if Cin % 128 == 0 else 4}>", ops.last_conv_variant()
+    b = ops.conv2d(x, pk, precision=3, tune=10 if Cout <= 64 else 11, **kw)
+    assert ops.last_conv_variant().startswith("conv_h2_kernel"), ops.last_conv_variant()
+    assert torch.equal(a, b)
+    assert torch.equal(ops.amax_of(a), ops.amax_of(b)) and torch.equal(ops.amax_of(a), a.abs().flatten(1).amax(1))
+    # the launcher's rule: this form up to ~1200 tiles (one frame on the stride-16 / 32 levels, 1-4 frames on the deepest), the tiled kernels above
+    c = ops.conv2d(x, pk, precision=3, **kw)
+    tiles = -(-B * Ho * Wo // 32) * (Cout // 32)
+    assert ops.last_conv_variant().startswith("conv_h2sg_kernel" if tiles <= 1280 else ("conv_h2_kernel", "conv_h2w_kernel", "conv_h2xs")), (tiles, ops.last_conv_variant())
+    assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("case", [(4, 120, 160, 64, 256, 64), (5, 119, 161, 64, 256, 64), (16, 60, 80, 128, 512, 128), (15, 59, 81, 128, 512, 128)])
 def test_back_to_back_pointwise_pair_equals_its_two_launches_bit_for_bit(ops, case):
     """Round 6: conv3 + FrozenBN + residual + ReLU of a bottleneck block and conv1 + FrozenBN + ReLU of the next block

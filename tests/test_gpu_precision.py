@@ -49,7 +49,8 @@ def _ref64(x, w, bias, stride, pad):
 
 
 LAW_CASES = [  # name, (B, H, W, Cin, Cout, k, stride), conv2d kwargs, expected kernel prefix, winograd?
-    ("direct-1x1", (2, 24, 40, 256, 256, 1, 1), {}, "conv_h2_kernel", False),
+    ("direct-1x1", (2, 24, 40, 256, 256, 1, 1), {}, "conv_h2sg_kernel", False),   # (480 tiles of 32 x 32: the small-grid form, csrc/conv_sg_h2.hip)
+    ("direct-1x1-tiled", (2, 24, 40, 256, 256, 1, 1), dict(tune=11), "conv_h2_kernel", False),
     ("direct-3x3", (2, 24, 40, 128, 128, 3, 1), {}, "conv_h2_kernel", False),
     ("direct-3x3-s2", (2, 25, 39, 128, 128, 3, 2), {}, "conv_h2_kernel", False),
     ("wide-fc", (600, 1, 1, 4096, 512, 1, 1), dict(tune=9), "conv_h2w_kernel", False),

@@ -92,7 +92,7 @@ def test_dual_dma_conv_equals_the_register_staged_kernels(ops, case):
     Wo = (c["W"] + 2 * c["p"] - c["k"]) // c["s"] + 1
     res = torch.randn(c["B"], Ho, Wo, pk.cols, device="cuda") if c["res"] else None
     y_ref = ops.conv2d(x, pk, x2=x2, res=res, wino=False, precision=3)  # the dispatcher's direct kernel (narrow or wide)
-    assert ops.last_conv_variant().startswith(("conv_h2_kernel", "conv_h2w_kernel", "conv_h2xs")), ops.last_conv_variant()
+    assert ops.last_conv_variant().startswith(("conv_h2_kernel", "conv_h2w_kernel", "conv_h2xs", "conv_h2sg")), ops.last_conv_variant()
     if x2 is None:
         y_dd = ops.conv2d(ops.presplit_f16x2(x), pk, res=res)
     else:

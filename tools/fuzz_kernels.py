@@ -5,7 +5,7 @@ of the modes fp16x2 (3), bf16x3 (2) and fp32-input MFMA (0):
   * the dispatcher's choice against a float64 convolution of the same operands (first and last image), relative to the image's
     output scale -- the fp32-grade bar of tests/test_gpu_parity.py;
   * every FORM that claims the dispatcher's bits must deliver them: narrow 128 x 64 / 128 x 128 tiles (tune 10 / 11), the wide 256 x 256
-    kernel (tune 9), per-lane instead of row-major epilogue (tune 12), the activation-stationary pointwise kernel on / off (tune 13 / 14),
+    kernel (tune 9), per-lane instead of row-major epilogue (tune 12), the activation-stationary pointwise kernel on / off (tune 13 / 14), the small-grid pointwise kernel (tune 17),
     pre-split activations through the dual-DMA kernel, Winograd one-launch / plane-split, the bf16x3 narrow Winograd GEMM (tune 8), the
     fp32 one-launch against the two-launch Winograd (tune 7), the persistent pointwise kernel on / off (tune 6 / 5), fused against
     four-launch upsampled convs.  A form the launcher refuses for the shape (A3D_ERR_UNSUPPORTED) is skipped, not failed.
@@ -177,7 +177,7 @@ def run(seed: int = 7, budget_s: float = 60.0, verbose: bool = True, max_cases: 
                     if own and plain:
                         forms += [(f"tune {t}", lambda t=t: launch(mode, x, pk, tune=t, precision=mode, **kw)[0]) for t in (9, 10, 11, 12)]
                     if own and mode == 3 and kind == "1x1":
-                        forms += [(f"tune {t}", lambda t=t: launch(3, x, pk, tune=t, precision=3, **kw)[0]) for t in (13, 14)]
+                        forms += [(f"tune {t}", lambda t=t: launch(3, x, pk, tune=t, precision=3, **kw)[0]) for t in (13, 14, 17)]  # (17: the small-grid form)
                     if own and mode == 3 and plain and x.shape[-1] % 16 == 0:
                         forms.append(("pre-split activations", lambda: launch(3, ops.presplit_f16x2(x), pk, **kw)[0]))
                     if mode == 3 and v0.startswith("wino"):
