@@ -13,8 +13,8 @@
 // one-wave workgroups instead of 40 four-wave ones: 13.9 us against 27.8; 15x20 2048 -> 512 17.2 against 46.6 (kernel trace, MI355X).
 // What bounds it then is operand re-reads: a 32 x 32 tile fetches 8 bytes per multiply-add pair row, 82 MB through the L2s for the
 // 6.4 MB of that layer -- so the form pays up to ~1200 tiles and loses to the 128-wide tiles above (A3D_SG_MAX_WAVES; measured at 1, 2
-// and 4 frames, tools/probes/sg_probe.py).  Measured and not taken: a 16-chunk ring (348 registers, no faster: the launch is not
-// latency-bound any more), two or four waves per workgroup (they share one L1 / texture path: 1.2 - 2.2 x slower).
+// and 4 frames, tools/probes/sg_probe.py).  Measured and not taken: a 16-chunk ring (348 registers; no faster alone, 25.6 against 23.6 us
+// per launch inside the one-frame pass), two or four waves per workgroup (they share one L1 / texture path: 1.2 - 2.2 x slower).
 //
 // Per output element the operations are conv_x3_kernel's (same split, same k order, h.h + h.l + l.h per 16-deep chunk into ONE fp32
 // accumulator of the same MFMA shape with the filter as operand A, same epilogue): bit-identical, so a frame's bits still do not
