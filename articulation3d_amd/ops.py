@@ -724,6 +724,41 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
                    m_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tune: int = 0,
                    wino: Optional[bool] = None, gate: Optional[torch.Tensor] = None, precision=None, dot=None) -> torch.Tensor:
     _req(x)
+    # Launch plans.  For a module-cached layer called the way the detector calls it (no options, output allocated here) everything in the
+    # descriptor but six tensor pointers is a function of (layer, input shape, residual form, arithmetic mode): the finished descriptor is
+    # kept on the PackedConv and later calls write the pointers into a copy -- ~15 -> ~6 us of host time per launch.  The reference's
+    # per-frame loop makes ~100 such calls per frame and its single-frame pass is as long on the host as on the GPU (MEASUREMENTS.md,
+    # round 6, item 12).  Anything else takes the full path below, which is also what creates the plan.
+    plan_key = None
+    if (LAUNCH_PLANS and CONV_TIMING is None and x2 is None and m_dev is None and out is None and gate is None and dot is None and not ups and splitk == 1
+            and tune == 0 and wino is None and precision is None and act is None and not (p.phase or p.pixshuf or p.stem) and p.presplit
+            and (_WINO_SHARE is None or x.data_ptr() not in _WINO_SHARE)):
+        plan_key = (x.shape, res is not None, bool(res_ups), DEFAULT_PRECISION, p.pin_precision, WINO_PLANE_SPLIT, WINO_TUNE, WINO_MAX_HW, BF16_SPLITK_AUTO,
+                    x.device, p.w.data_ptr())
+        plans = p.__dict__.get("_plans")
+        plan = plans.get(plan_key) if plans else None
+        if plan is not None:
+            proto, oshape, need_in, need_y, ws_n, m_n, prec = plan
+            out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+            d = _lib.ConvDesc.from_buffer_copy(proto)
+            d.x, d.y = x.data_ptr(), out.data_ptr()
+            if res is not None:
+                d.res = _req(res).data_ptr()
+            if need_in:
+                d.in_amax = amax_of(x).data_ptr()
+            if need_y:
+                ya = out._a3d_amax = amax_slot(oshape[0], x.device)
+                d.y_amax = ya.data_ptr()
+            if ws_n:
+                ws = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+                d.workspace = ws.data_ptr()
+            if m_n:
+                wino_m = torch.empty(m_n, device=x.device, dtype=torch.float32)
+                d.wino_m = wino_m.data_ptr()
+            global _LAST_PRECISION
+            _LAST_PRECISION = prec
+            _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+            return out
     B, H, W, Cin = x.shape
     Cin2 = 0
     if x2 is not None:
@@ -793,7 +828,6 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
             and p.Kpad == p.KH * p.KW * p.Cin and p.Cin % 32 == 0):
         splitk = _bf16_splitk(B * Ho * Wo, p.cols, p.Kpad)  # (bf16 arithmetic: small grids with long reductions)
         d.splitk = splitk
-    global _LAST_PRECISION
     _LAST_PRECISION = int(precision)
     d.phase = int(p.phase)
     if d.precision == 3:  # fp16x2: per-image scales of the activations (recorded by their producers), one static scale of the filter
@@ -873,6 +907,7 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         d.w_x3 = p.w_x3.data_ptr()
     fused_wino = False
     shared = None  # [input tensor, its transformed tiles V or None]: see share_wino_input
+    nbytes = mbytes = 0
     if use_wino or splitk > 1:
         if use_wino and _WINO_SHARE is not None and x2 is None:
             shared = _WINO_SHARE.get(x.data_ptr())
@@ -927,9 +962,15 @@ def _conv2d_launch(x: torch.Tensor, p: PackedConv, *, x2: Optional[torch.Tensor]
         finally:
             _TIMED_VARIANTS[tkey] = frozenset(t[0] for t in CONV_TIMING[n_before:])
     _lib.check(_lib.lib().a3d_conv2d_nhwc_f32(C.byref(d), _stream()), "a3d_conv2d_nhwc_f32")
+    if plan_key is not None and shared is None:
+        if p.__dict__.get("_plans") is None or len(p._plans) > 64:
+            p._plans = {}
+        p._plans[plan_key] = (bytes(d), tuple(out.shape), bool(d.in_amax), bool(d.y_amax), nbytes // 4 if ws is not None else 0,
+                              mbytes // 4 if d.wino_m else 0, int(precision))
     return out
 
 
+LAUNCH_PLANS = os.environ.get("A3D_LAUNCH_PLANS", "1") != "0"  # (False: every launch fills its descriptor from scratch; the same launches)
 B2B_FUSED = os.environ.get("A3D_B2B", "1") != "0"  # (False: conv3 and the next block's conv1 as two launches)
 B2B_MIN_PIXELS = 128 * 512  # one round of the chip's 512 workgroup slots (the activation-stationary kernel's own rule)
 # (input channels of the first layer, output channels of the second) of the pairs that run as one launch: res2's conv3 -> conv1 boundaries

@@ -366,6 +366,43 @@ def test_small_grid_pointwise_kernel_agrees_bit_for_bit_with_the_tiled_one(ops, 
     assert torch.equal(a, c)
 
 
+def test_launch_plans_repeat_the_full_path_bit_for_bit(ops):
+    """ops._conv2d_launch keeps the finished descriptor of a module-cached layer per (input shape, residual form, arithmetic mode) and
+    writes only the tensor pointers on later calls (host time of the reference's per-frame loop).  A planned launch must be the launch
+    the full path makes: same kernel, same bits, same recorded maxima -- for direct, small-grid, Winograd (workspace + plane-split
+    scratch) and residual forms, in the three arithmetics; a call with any option goes the full way and leaves the plan alone."""
+    torch.manual_seed(9)
+    cases = [(1, 30, 40, 1024, 256, 1, 1, False), (2, 60, 80, 256, 256, 1, 1, True), (1, 30, 40, 256, 256, 3, 1, False), (3, 15, 20, 512, 512, 3, 1, False),
+             (2, 61, 79, 128, 128, 3, 2, False), (1, 60, 80, 64, 64, 3, 1, False)]
+    saved = ops.DEFAULT_PRECISION
+    try:
+        for mode in (3, 2, 0):
+            ops.DEFAULT_PRECISION = mode
+            for B, H, W, Cin, Cout, k, st, with_res in cases:
+                x = torch.relu(torch.randn(B, H, W, Cin, device="cuda")) * torch.logspace(-1, 1, B, device="cuda")[:, None, None, None]
+                Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+                res = torch.randn(B, Ho, Wo, Cout, device="cuda") if with_res else None
+                pk = ops.pack_conv(torch.randn(Cout, Cin, k, k) / (k * Cin ** 0.5), torch.randn(Cout) * 0.1, None, st, k // 2, ops.ACT_RELU)
+                ops.LAUNCH_PLANS = False
+                ref = ops.conv2d(x, pk, res=res)
+                vref, aref = ops.last_conv_variant(), getattr(ref, "_a3d_amax", None)
+                assert not getattr(pk, "_plans", None)
+                ops.LAUNCH_PLANS = True
+                first = ops.conv2d(x, pk, res=res)   # full path, creates the plan
+                assert len(pk._plans) == 1
+                again = ops.conv2d(x, pk, res=res)   # planned
+                assert ops.last_conv_variant() == vref, (mode, vref, ops.last_conv_variant())
+                assert torch.equal(ref, first) and torch.equal(ref, again), (mode, B, H, W, Cin, Cout, k)
+                if aref is not None:
+                    assert torch.equal(aref, again._a3d_amax)
+                other = ops.conv2d(x[:1].contiguous(), pk, res=None if res is None else res[:1].contiguous())  # another shape: its own plan
+                assert torch.equal(other[0], ref[0]) and len(pk._plans) == (2 if B > 1 else 1)
+                ops.conv2d(x, pk, res=res, act=ops.ACT_NONE)  # an option: the full path, no new plan
+                assert len(pk._plans) == (2 if B > 1 else 1)
+    finally:
+        ops.DEFAULT_PRECISION, ops.LAUNCH_PLANS = saved, True
+
+
 @pytest.mark.parametrize("case", [(4, 120, 160, 64, 256, 64), (5, 119, 161, 64, 256, 64), (16, 60, 80, 128, 512, 128), (15, 59, 81, 128, 512, 128)])
 def test_back_to_back_pointwise_pair_equals_its_two_launches_bit_for_bit(ops, case):
     """Round 6: conv3 + FrozenBN + residual + ReLU of a bottleneck block and conv1 + FrozenBN + ReLU of the next block
