@@ -677,7 +677,7 @@ def main():
         from loop_bench import loop_b1
 
         result["roofline"]["loop_b1"] = loop_b1(model, cfg, n=64, conf_threshold=args.score_thresh)
-        result["roofline"]["loop_b1"]["note"] = ("tools/loop_bench.py: PlaneRCNN_Branch.inference -> process -> create_instances per frame, 64 frames after 24 "
+        result["roofline"]["loop_b1"]["note"] = ("tools/loop_bench.py: PlaneRCNN_Branch.inference -> process -> create_instances per frame, 64 frames after 64 "
                                                  "OTHER untimed ones (a video's steady state: every per-frame detection count seen once); the batched figure is `value`")
     if not args.no_train_leg:
         # BASELINE configs[4] where the driver sees it: a short leg of the step1_bbox training step (bf16 autocast arithmetic, as the config

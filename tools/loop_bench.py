@@ -27,10 +27,11 @@ class _Holder:
         self.model = model
 
 
-def loop_b1(model, cfg, n=64, warm=24, seed=2020, conf_threshold=0.5):
+def loop_b1(model, cfg, n=64, warm=64, seed=2020, conf_threshold=0.5):
     """Frames per second of `model` through the reference's unchanged per-frame loop on `n` synthetic frames, after `warm` OTHER untimed frames:
     a video's steady state -- every detection count a frame can have (the ROI heads' launch shapes) has then been seen once, the allocator has
-    grown (24 frames; with 4 the first timed frames still paid those one-time costs: 205 against 228-237 frames/s for the same 64 frames)."""
+    grown (64 frames; with 4 | 24 the timed frames still paid one-time costs -- a full-path launch and fresh allocations for every new detection
+    count: 205 | 213 against 228-237 frames/s for the same 64 frames on a warm model)."""
     branch = PlaneRCNN_Branch(cfg, load_weights=False, predictor=_Holder(model))
     frames = synthetic_frames(n + warm, seed)
     reference_loop(branch, frames[:warm], conf_threshold)
