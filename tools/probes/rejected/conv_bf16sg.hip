@@ -2,12 +2,15 @@
 // 32 x 32 output tile, operand fragments straight into a register ring, no LDS, no barrier -- conv_sg_h2.hip's form on the one-product
 // bf16 pipe.
 //
-// What it is for.  At the reference's 2 images per GPU (BASELINE configs[4]) the 1x1 layers of res4 / res5 and their data gradients are
-// a few dozen 128 x 64 tiles each: conv_bf16_kernel<1> walks 32 - 64 chunks per tile one memory round trip at a time, or splits the
-// reduction over workgroups and folds the partial sums in a second launch (conv_bf16_reduce_kernel) -- 87 + 43 launches on the step's
-// critical stream (profiles/r05_train_streams_b2.txt: 1.7 of its 4.6 ms).  Here a wave owns 32 pixels x 32 output channels for the whole
-// reduction and keeps R chunks of both operands in flight (bf16-stored activations: 16 B per lane and chunk; the bf16 filter copy
-// a3d_conv_desc.w_bf16 [Cout][Kpad]: 16 B), one MFMA per chunk; no partial sums, no second launch.
+// What it is for.  At the reference's 2 images per GPU (BASELINE configs[4]) the deep 1x1 layers of res4 / res5, the top laterals and their
+// data gradients are a few dozen 128 x 64 tiles each: conv_bf16_kernel<1> splits their reduction over workgroups and folds the partial
+// sums in a second launch (conv_bf16_reduce_kernel) -- 43 second launches on the step's critical stream of 193.  Here a wave owns 32 pixels
+// x 32 output channels for the whole reduction and keeps R chunks of both operands in flight (bf16-stored activations: 16 B per lane and
+// chunk; the bf16 filter copy a3d_conv_desc.w_bf16 [Cout][Kpad]: 16 B), one MFMA per chunk; no partial sums, no second launch.
+// Measured (tools/probes/rejected/bsg_probe.py, profiles/r06_bf16sg_probe.txt; kernel time at 2 images, tiled + fold | this kernel):
+// res4 conv1 15.5 | 14.7 us, res5.0 conv1 14.7 | 10.4, lateral5 14.1 | 10.4, res5 conv1 15.4 | 16.6 -- the seven split layers 106 | 101 us:
+// a tie in kernel time (a 32 x 32 tile re-reads its operands through the L2s), taken for the launch it removes from the chain.  On layers
+// the tiled kernel runs UNSPLIT it loses (res4 conv3 11.7 | 16.2) and is not used.
 //
 // Per output element: the operands conv_bf16_kernel rounds (RNE) or reads, the same 16-deep products in ascending k into one fp32
 // accumulator with the filter as operand A, the same epilogue (scale / shift, residual, activation, gate, fp32 or bf16 store): the bits
@@ -133,8 +136,9 @@ int launch_bsg(const a3d_conv_desc *d, hipStream_t s) {
 }
 }  // namespace
 
-// A3D_ERR_UNSUPPORTED: not a layer / not a launch of this form (the caller goes on to the tiled kernels).  tune 35: whatever the grid size,
-// 36: never.  a3d_conv_desc.splitk > 1 on an eligible launch is a HINT this form does not need: the whole reduction runs in one launch.
+// A3D_ERR_UNSUPPORTED: not a layer / not a launch of this form (the caller goes on to the tiled kernels).  tune 0: the launches the caller
+// asks to split (a3d_conv_desc.splitk > 1: the whole reduction then runs here in ONE launch, the workspace stays unused); tune 35: any
+// eligible layer whatever the grid size; 36: never.
 int a3d_conv_launch_bf16sg(const a3d_conv_desc *d, hipStream_t s) {
     if (d->precision != 1 || !d->w_bf16 || !(d->tune == 0 || d->tune == 35)) return A3D_ERR_UNSUPPORTED;
     if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->Kpad != d->Cin || d->stride < 1) return A3D_ERR_UNSUPPORTED;
@@ -146,7 +150,7 @@ int a3d_conv_launch_bf16sg(const a3d_conv_desc *d, hipStream_t s) {
     if ((size_t)d->B * d->H * d->W * d->Cin * 4 >= ((size_t)1 << 31) || (size_t)d->Cout * d->Kpad * 2 >= ((size_t)1 << 31) || M >= ((size_t)1 << 26))
         return A3D_ERR_UNSUPPORTED;
     const size_t waves = ((M + 31) / 32) * (size_t)(d->Cout / 32);
-    if (d->tune == 0 && waves > A3D_BF16SG_MAX_WAVES) return A3D_ERR_UNSUPPORTED;
+    if (d->tune == 0 && (d->splitk == 1 || waves > A3D_BF16SG_MAX_WAVES)) return A3D_ERR_UNSUPPORTED;
     const int nk = d->Cin / 16;
     return nk % 16 == 0 ? launch_bsg<16>(d, s) : nk % 8 == 0 ? launch_bsg<8>(d, s) : launch_bsg<4>(d, s);
 }
